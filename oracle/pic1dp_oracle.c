@@ -1,0 +1,889 @@
+/*
+ * pic1dp_oracle.c -- CPU restatement of the PIC1D-PETSc time-step hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see pic1dp_oracle.h for the rules and the parity
+ * status: RNG pinned by the reference module, push/deposit/solve unpinned).
+ *
+ * Every function cites the reference lines it restates.  Expressions keep the
+ * reference's Fortran evaluation order (left to right for equal precedence,
+ * "**" binds tighter than unary minus, integer operands are converted to
+ * double where they meet a double).  Build: gcc -O2 -ffp-contract=off.
+ */
+#include "pic1dp_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_PI 3.14159265358979323846264 /* PETSC_PI */
+#define ORC_SQRT_EPS 1.490116119384766e-08 /* PETSC_SQRT_MACHINE_EPSILON */
+
+/* ======================================================================
+ * multirand -- src/multirand.F90
+ * ====================================================================== */
+
+static inline uint64_t xorshl(uint64_t x, int s) { return x ^ (x << s); }
+static inline uint64_t xorshr(uint64_t x, int s) { return x ^ (x >> s); }
+
+/* George Marsaglia's KISS64, src/multirand.F90:921-945 */
+static uint64_t kiss64(orc_multirand *g) {
+  uint64_t *q = g->seeds;
+  uint64_t x = q[0], t = (x << 58) + q[3];
+  if ((x >> 63) == (t >> 63))
+    q[3] = (x >> 6) + (x >> 63);
+  else
+    q[3] = (x >> 6) - ((x + t) >> 63) + 1;
+  q[0] = x + t;
+  q[1] = xorshl(q[1], 13);
+  q[1] = xorshr(q[1], 17);
+  q[1] = xorshl(q[1], 43);
+  q[2] = 6906969069ULL * q[2] + 1234567ULL;
+  return q[0] + q[1] + q[2];
+}
+
+/* MT19937-64, src/multirand.F90:952-997 */
+static uint64_t mt19937_64(orc_multirand *g) {
+  enum { NN = 312, MM = 156 };
+  const uint64_t UM = 0xFFFFFFFF80000000ULL, LM = 0x7FFFFFFFULL;
+  const uint64_t mag01[2] = {0ULL, 0xB5026F5AA96619E9ULL};
+  uint64_t *mt = g->seeds, x;
+  if (g->iseed >= NN) {
+    int i;
+    for (i = 0; i < NN - MM; i++) {
+      x = (mt[i] & UM) | (mt[i + 1] & LM);
+      mt[i] = mt[i + MM] ^ (x >> 1) ^ mag01[x & 1ULL];
+    }
+    for (; i < NN - 1; i++) {
+      x = (mt[i] & UM) | (mt[i + 1] & LM);
+      mt[i] = mt[i + (MM - NN)] ^ (x >> 1) ^ mag01[x & 1ULL];
+    }
+    x = (mt[NN - 1] & UM) | (mt[0] & LM);
+    mt[NN - 1] = mt[MM - 1] ^ (x >> 1) ^ mag01[x & 1ULL];
+    g->iseed = 0;
+  }
+  x = mt[g->iseed++];
+  x ^= (x >> 29) & 0x5555555555555555ULL;
+  x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+  x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+  x ^= (x >> 43);
+  return x;
+}
+
+/* SuperKISS64, src/multirand.F90:1004-1039 */
+static uint64_t superkiss64(orc_multirand *g) {
+  enum { NN = 20632, ICARRY = NN, IXCNG = NN + 1, IXS = NN + 2 };
+  uint64_t *q = g->seeds;
+  if (g->iseed >= NN) {
+    uint64_t carry = q[ICARRY];
+    for (int i = 0; i < NN; i++) {
+      uint64_t h = carry & 1ULL;
+      uint64_t z = ((q[i] << 41) >> 1) + ((q[i] << 39) >> 1) + (carry >> 1);
+      carry = (q[i] >> 23) + (q[i] >> 25) + (z >> 63);
+      q[i] = ~((z << 1) + h);
+    }
+    q[ICARRY] = carry;
+    g->iseed = 0;
+  }
+  q[IXCNG] = q[IXCNG] * 6906969069ULL + 123ULL;
+  q[IXS] = xorshl(q[IXS], 13);
+  q[IXS] = xorshr(q[IXS], 17);
+  q[IXS] = xorshl(q[IXS], 43);
+  return q[g->iseed++] + q[IXCNG] + q[IXS];
+}
+
+int64_t orc_multirand_int64(orc_multirand *g) {
+  uint64_t r;
+  if (g->al_int == 2)
+    r = mt19937_64(g);
+  else if (g->al_int == 3)
+    r = superkiss64(g);
+  else
+    r = kiss64(g);
+  return (int64_t)r;
+}
+
+/* INT2REAL64, src/multirand.F90:49: i / (2**64-1 as double = 2**64) + 0.5 */
+static inline double int2real64(int64_t i) {
+  return (double)i / 18446744073709551615.0 + 0.5;
+}
+
+double orc_multirand_real64(orc_multirand *g) {
+  return int2real64(orc_multirand_int64(g));
+}
+
+void orc_multirand_int_array64(orc_multirand *g, int64_t *a, int64_t n) {
+  for (int64_t i = 0; i < n; i++) a[i] = orc_multirand_int64(g);
+}
+
+/* src/multirand.F90:664-707 (exclude0/exclude1 absent on the path) */
+void orc_multirand_real_array64(orc_multirand *g, double *a, int64_t n) {
+  for (int64_t i = 0; i < n; i++) a[i] = int2real64(orc_multirand_int64(g));
+}
+
+/* Marsaglia polar method, src/multirand.F90:838-872 */
+void orc_multirand_gaussian_array64(orc_multirand *g, double *a, int64_t n) {
+  const double max64 = 9223372036854775807.0;
+  int64_t lo = 0;
+  if (g->gaussian64buf_filled && n > 0) {
+    a[lo++] = g->gaussian64buf;
+    g->gaussian64buf_filled = 0;
+  }
+  for (int64_t i = lo; i < n; i += 2) {
+    double x, y, w;
+    do {
+      x = (double)orc_multirand_int64(g) / max64;
+      y = (double)orc_multirand_int64(g) / max64;
+      w = x * x + y * y;
+    } while (!(w > 0.0 && w < 1.0));
+    w = sqrt((-2.0 * log(w)) / w);
+    a[i] = x * w;
+    if (i + 1 < n) {
+      a[i + 1] = y * w;
+    } else {
+      g->gaussian64buf = y * w;
+      g->gaussian64buf_filled = 1;
+    }
+  }
+}
+
+orc_multirand *orc_multirand_new(void) {
+  return (orc_multirand *)calloc(1, sizeof(orc_multirand));
+}
+void orc_multirand_free(orc_multirand *g) { free(g); }
+
+/* default seeds of the self-test, src/multirand.F90:475-518 */
+void orc_multirand_default_seeds(orc_multirand *g, int al_int) {
+  uint64_t *q = g->seeds;
+  g->al_int = al_int;
+  if (al_int == 2) {
+    q[0] = 5489ULL;
+    for (int i = 1; i < 312; i++)
+      q[i] = 6364136223846793005ULL * xorshr(q[i - 1], 62) + (uint64_t)i;
+    g->iseed = 312;
+  } else if (al_int == 3) {
+    q[20632] = 36243678541ULL;
+    q[20633] = 12367890123456ULL;
+    q[20634] = 521288629546311ULL;
+    for (int i = 0; i < 20632; i++) {
+      q[20633] = q[20633] * 6906969069ULL + 123ULL;
+      q[20634] = xorshl(q[20634], 13);
+      q[20634] = xorshr(q[20634], 17);
+      q[20634] = xorshl(q[20634], 43);
+      q[i] = q[20633] + q[20634];
+    }
+    g->iseed = 20632;
+  } else {
+    q[0] = 1234567890987654321ULL;
+    q[1] = 362436362436362436ULL;
+    q[2] = 1066149217761810ULL;
+    q[3] = 123456123456123456ULL;
+  }
+}
+
+/* KAT vectors transcribed (data) from src/multirand.F90:396-425 */
+static const int64_t kat_kiss64[10] = {
+    8932985056925012148LL,  5710300428094272059LL,  -104233206776033023LL,
+    -4143107803135683366LL, 542381058189297533LL,   -4244931820854714191LL,
+    6853720724624422285LL,  -767542866500872268LL,  -257204313086867125LL,
+    8128797625455304420LL};
+static const int64_t kat_mt_head[10] = {
+    -3932459287431434586LL, 4620546740167642908LL, -5337173792191653896LL,
+    -983805426561117294LL,  355488278567739596LL,  7469126240319926998LL,
+    4635995468481642529LL,  418970542659199878LL,  -8842573084457035060LL,
+    6358044926049913402LL};
+static const int64_t kat_mt_tail[10] = {
+    -7948593974297132281LL, 1921007855220546564LL, 7643484074408755248LL,
+    -7128315020423208677LL, 1370093900783164344LL, 6776537281339823025LL,
+    3450492372588984223LL,  -9045729527952115285LL, 7896519943553875907LL,
+    -4143300141377237606LL};
+static const int64_t kat_sk_head[10] = {
+    6140839658375754198LL,  -95225469143006167LL,  -9148462456964506707LL,
+    3912874252778582253LL,  6801212277726928591LL, -809575511391043410LL,
+    -397286769868273005LL,  4963780769400405858LL, 2406624640673457322LL,
+    1246843699883922102LL};
+static const int64_t kat_sk_tail[10] = {
+    -1387224431860786161LL, -8846516422183390713LL, 8111357788999165247LL,
+    444070776306226770LL,   -7730678117654887867LL, -296399128303442035LL,
+    -1658509282659454084LL, -8190332265239255687LL, -1492517620356299342LL,
+    -5016179395587873849LL};
+
+/* src/multirand.F90:390-553; returns 0 when every check passes */
+int orc_multirand_selftest(orc_multirand *g, int al_int) {
+  const int ntest = 10;
+  const int64_t *head, *tail = NULL;
+  int itail = 0, bad = 0;
+  /* boundary checks :441-471 */
+  int64_t k = INT64_MAX;
+  if (int2real64(k) != 1.0) bad = 1;
+  k = INT64_MIN;
+  if (int2real64(k) != 0.0) bad = 1;
+  orc_multirand_default_seeds(g, al_int);
+  if (al_int == 2) {
+    head = kat_mt_head;
+    tail = kat_mt_tail;
+    itail = 312 - ntest / 2;
+  } else if (al_int == 3) {
+    head = kat_sk_head;
+    tail = kat_sk_tail;
+    itail = 20632 - ntest / 2;
+  } else {
+    head = kat_kiss64;
+  }
+  for (int i = 0; i < ntest; i++)
+    if (orc_multirand_int64(g) != head[i]) return 1;
+  if (tail) {
+    for (int i = ntest + 1; i <= itail; i++) (void)orc_multirand_int64(g);
+    for (int i = 0; i < ntest; i++)
+      if (orc_multirand_int64(g) != tail[i]) return 1;
+  }
+  return bad;
+}
+
+static const int64_t primes1[100] = {
+    15484219, 15484223, 15484243, 15484247, 15484279, 15484333, 15484363,
+    15484387, 15484393, 15484409, 15484421, 15484453, 15484457, 15484459,
+    15484471, 15484489, 15484517, 15484519, 15484549, 15484559, 15484591,
+    15484627, 15484631, 15484643, 15484661, 15484697, 15484709, 15484723,
+    15484769, 15484771, 15484783, 15484817, 15484823, 15484873, 15484877,
+    15484879, 15484901, 15484919, 15484939, 15484951, 15484961, 15484999,
+    15485039, 15485053, 15485059, 15485077, 15485083, 15485143, 15485161,
+    15485179, 15485191, 15485221, 15485243, 15485251, 15485257, 15485273,
+    15485287, 15485291, 15485293, 15485299, 15485311, 15485321, 15485339,
+    15485341, 15485357, 15485363, 15485383, 15485389, 15485401, 15485411,
+    15485429, 15485441, 15485447, 15485471, 15485473, 15485497, 15485537,
+    15485539, 15485543, 15485549, 15485557, 15485567, 15485581, 15485609,
+    15485611, 15485621, 15485651, 15485653, 15485669, 15485677, 15485689,
+    15485711, 15485737, 15485747, 15485761, 15485773, 15485783, 15485801,
+    15485807, 15485837};
+static const int64_t primes2[100] = {
+    7001, 7013, 7019, 7027, 7039, 7043, 7057, 7069, 7079, 7103, 7109, 7121,
+    7127, 7129, 7151, 7159, 7177, 7187, 7193, 7207, 7211, 7213, 7219, 7229,
+    7237, 7243, 7247, 7253, 7283, 7297, 7307, 7309, 7321, 7331, 7333, 7349,
+    7351, 7369, 7393, 7411, 7417, 7433, 7451, 7457, 7459, 7477, 7481, 7487,
+    7489, 7499, 7507, 7517, 7523, 7529, 7537, 7541, 7547, 7549, 7559, 7561,
+    7573, 7577, 7583, 7589, 7591, 7603, 7607, 7621, 7639, 7643, 7649, 7669,
+    7673, 7681, 7687, 7691, 7699, 7703, 7717, 7723, 7727, 7741, 7753, 7757,
+    7759, 7789, 7793, 7817, 7823, 7829, 7841, 7853, 7867, 7873, 7877, 7879,
+    7883, 7901, 7907, 7919};
+
+static int64_t iabs64(int64_t a) { return a < 0 ? -a : a; }
+
+/* src/multirand.F90:132-383 */
+int orc_multirand_init(orc_multirand *g, int al_int, int seed_type, int mype,
+                       int warmup, int selftest) {
+  int rc = 0;
+  int64_t nseed;
+  if (al_int != 2 && al_int != 3) al_int = 1;
+  nseed = al_int == 2 ? 312 : (al_int == 3 ? 20635 : 4);
+  g->al_int = al_int;
+  if (selftest) rc = orc_multirand_selftest(g, al_int);
+  g->al_int = al_int;
+
+  if (seed_type == 3) {
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (!f) {
+      seed_type = 2;
+    } else {
+      if (fread(g->seeds, 8, (size_t)nseed, f) != (size_t)nseed) rc = 3;
+      if (al_int == 1) {
+        while (g->seeds[1] == 0)
+          if (fread(&g->seeds[1], 8, 1, f) != 1) break;
+        while (g->seeds[0] == 0 && g->seeds[3] == 0) {
+          if (fread(&g->seeds[0], 8, 1, f) != 1) break;
+          if (fread(&g->seeds[3], 8, 1, f) != 1) break;
+        }
+      } else if (al_int == 3) {
+        while (g->seeds[20634] == 0)
+          if (fread(&g->seeds[20634], 8, 1, f) != 1) break;
+      }
+      fclose(f);
+    }
+  }
+  if (seed_type != 3) {
+    int64_t clock, add;
+    uint64_t *tmp;
+    if (al_int == 3 && g->seeds[20634] == 0)
+      return 2; /* the reference loops forever at :346-348 */
+    if (seed_type == 2) {
+      struct timespec ts;
+      clock_gettime(CLOCK_MONOTONIC, &ts);
+      clock = (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+    } else {
+      clock = primes1[1];
+    }
+    /* :307-320 -- KISS seeds from clock and mype */
+    add = primes1[iabs64(clock + primes2[iabs64(clock) % 100] * mype) % 100] *
+          mype;
+    for (int i = 0; i < 4; i++) g->seeds[i] = (uint64_t)(clock + add);
+    for (int64_t i = 0; i < 4; i++) {
+      int64_t s = (int64_t)g->seeds[i];
+      s += primes2[iabs64(s + primes1[iabs64(clock) % 100] * i) % 100] * i;
+      g->seeds[i] = (uint64_t)s;
+    }
+    /* :322-350 -- KISS randomises the seed array */
+    tmp = (uint64_t *)malloc(sizeof(uint64_t) * ORC_MULTIRAND_NSEED);
+    memcpy(tmp, g->seeds, sizeof(uint64_t) * ORC_MULTIRAND_NSEED);
+    for (int i = 0; i < 20; i++) tmp[0] = kiss64(g);
+    for (int64_t i = 1; i < nseed; i++) tmp[i] = kiss64(g);
+    if (al_int == 1) {
+      while (tmp[1] == 0) tmp[1] = kiss64(g);
+      while (tmp[0] == 0 && tmp[3] == 0) {
+        tmp[0] = kiss64(g);
+        tmp[3] = kiss64(g);
+      }
+    }
+    memcpy(g->seeds, tmp, sizeof(uint64_t) * (size_t)nseed);
+    free(tmp);
+  }
+  if (al_int == 2)
+    g->iseed = 312;
+  else if (al_int == 3)
+    g->iseed = 20632;
+  for (int64_t i = 0; i < (int64_t)warmup * nseed; i++)
+    (void)orc_multirand_int64(g);
+  return rc;
+}
+
+/* ======================================================================
+ * ownership -- PETSC_DECIDE split: n/size + (rank < n%size)
+ * (PetscSplitOwnership; used at src/pic1dp_particle.F90:89-94,129)
+ * ====================================================================== */
+int64_t orc_local_size(int64_t n, int rank, int size) {
+  return n / size + ((n % size) > rank ? 1 : 0);
+}
+
+/* src/pic1dp_particle.F90:240-248 */
+int64_t orc_particle_np(const orc_input *in, int isp, int mype, int npe) {
+  int64_t nlocal = orc_local_size(in->nparticle_max, mype, npe);
+  int64_t spare = in->nparticle_max - in->species_nparticle_init[isp];
+  int64_t unload = spare / npe;
+  if (mype == 0) unload += spare % npe;
+  return nlocal - unload;
+}
+
+/* ======================================================================
+ * particle_load -- src/pic1dp_particle.F90:162-265 (one species)
+ * ====================================================================== */
+void orc_particle_load_species(const orc_input *in, int isp, orc_multirand *g,
+                               int64_t n, double *x, double *v, double *p,
+                               double *w) {
+  const double T = in->species_temperature[isp];
+  const double T2 = in->species_temperature2[isp];
+  const double m = in->species_mass[isp];
+  const double den = in->species_density[isp];
+  const double v0 = in->species_v0[isp];
+  const double ninit = (double)in->species_nparticle_init[isp];
+  const double lx = in->lx, vmax = in->v_max;
+
+  if (in->imarker == 1) { /* :172-178 */
+    const double sig = sqrt(T / m);
+    const double pc = den * lx / ninit;
+    orc_multirand_gaussian_array64(g, v, n);
+    for (int64_t i = 0; i < n; i++) {
+      v[i] = v[i] * sig + v0;
+      p[i] = pc;
+    }
+  } else { /* :179-218 */
+    orc_multirand_real_array64(g, v, n);
+    for (int64_t i = 0; i < n; i++) v[i] = (v[i] - 0.5) * 2.0 * vmax;
+    if (in->iptcldist == 1) { /* :183-186 */
+      const double K = den * lx * 2.0 * vmax / ninit;
+      const double s2pi = sqrt(2.0 * ORC_PI);
+      for (int64_t i = 0; i < n; i++) {
+        double v2 = v[i] * v[i];
+        p[i] = K * v2 * exp(-v2 / 2.0) / s2pi;
+      }
+    } else if (in->iptcldist == 2) { /* :188-196 */
+      const double K = den * lx * 2.0 * vmax / ninit;
+      const double two_tm = 2.0 * T / m;
+      const double nrm = sqrt(8.0 * ORC_PI * T / m);
+      for (int64_t i = 0; i < n; i++) {
+        double vp = v[i] + v0, vm = v[i] - v0;
+        p[i] = K * (exp(-(vp * vp) / two_tm) + exp(-(vm * vm) / two_tm)) / nrm;
+      }
+    } else if (in->iptcldist == 3) { /* :198-209 */
+      const double K = 1.0 * lx * 2.0 * vmax / ninit;
+      const double two_tm = 2.0 * T / m, two_tm2 = 2.0 * T2 / m;
+      const double nrm = sqrt(2.0 * ORC_PI * T / m);
+      const double nrm2 = sqrt(2.0 * ORC_PI * T2 / m);
+      const double beam = 1.0 - den;
+      for (int64_t i = 0; i < n; i++) {
+        double vm = v[i] - v0;
+        p[i] = K * (den * exp(-(v[i] * v[i]) / two_tm) / nrm +
+                    beam * exp(-(vm * vm) / two_tm2) / nrm2);
+      }
+    } else { /* :211-217 */
+      const double K = den * lx * 2.0 * vmax / ninit;
+      const double two_tm = 2.0 * T / m;
+      const double nrm = sqrt(2.0 * ORC_PI * T / m);
+      for (int64_t i = 0; i < n; i++) {
+        double vm = v[i] - v0;
+        p[i] = K * exp(-(vm * vm) / two_tm) / nrm;
+      }
+    }
+  }
+  /* :222-223 uniform in x */
+  orc_multirand_real_array64(g, x, n);
+  for (int64_t i = 0; i < n; i++) x[i] = x[i] * lx;
+  /* :225-232 initial mode perturbation */
+  for (int64_t i = 0; i < n; i++) w[i] = 0.0;
+  for (int im = 0; im < in->init_nmode; im++) {
+    const double k = 2.0 * ORC_PI / lx * (double)in->init_mode[im];
+    const double ac = in->init_mode_cos[im], as = in->init_mode_sin[im];
+    for (int64_t i = 0; i < n; i++)
+      w[i] = w[i] + ac * cos(k * x[i]) + as * sin(k * x[i]);
+  }
+  /* :234-237, input_pertb_shape == 1.0 (src/pic1dp_input.F90:271) */
+  for (int64_t i = 0; i < n; i++) w[i] = w[i] * p[i] * 1.0;
+  /* :260-264 nonlinear: p = f/g = f0/g + delta f/g */
+  if (in->linear == 0)
+    for (int64_t i = 0; i < n; i++) p[i] = p[i] + w[i];
+}
+
+/* ======================================================================
+ * interaction_collect_charge, iptclshape == 4
+ * ====================================================================== */
+
+/* src/pic1dp_interaction.F90:96-114 */
+void orc_deposit_species_idx(const orc_input *in, int64_t np, double *x,
+                             const double *q, double *charge1, int32_t *ix_out,
+                             int64_t *count) {
+  const double lx = in->lx;
+  const int32_t nx = in->nx;
+  const double dnx = (double)nx;
+  for (int64_t ip = 0; ip < np; ip++) {
+    double px = fmod(x[ip], lx);  /* :102 */
+    if (px < 0.0) px = px + lx;   /* :104 */
+    x[ip] = px;
+    double sx = px / lx * dnx;    /* :106 */
+    int32_t ix = (int32_t)floor(sx);
+    sx = 1.0 - (sx - (double)ix); /* :108 */
+    /* memory safety only: px + lx can round to lx; the
+     * reference would write out of bounds, fold to cell 0 instead */
+    if (ix >= nx) ix = 0;
+    if (ix_out) ix_out[ip] = ix;
+    if (count) count[ix]++;
+    charge1[ix] = charge1[ix] + sx * q[ip]; /* :110 */
+    ix = ix + 1;
+    if (ix > nx - 1) ix = 0;
+    charge1[ix] = charge1[ix] + (1.0 - sx) * q[ip]; /* :113 */
+  }
+}
+
+void orc_deposit_species(const orc_input *in, int64_t np, double *x,
+                         const double *q, double *charge1) {
+  orc_deposit_species_idx(in, np, x, q, charge1, NULL, NULL);
+}
+
+/* src/pic1dp_interaction.F90:138-148 */
+void orc_chargeden_from_charge(const orc_input *in, const double *charge1,
+                               double *chargeden) {
+  const double dnx = (double)in->nx;
+  for (int ix = 0; ix < in->nx; ix++) {
+    double c = charge1[ix] * dnx / in->lx;
+    if (in->deltaf == 0)
+      for (int s = 0; s < in->nspecies; s++)
+        c = c - in->species_charge[s] * in->species_density[s];
+    chargeden[ix] = c;
+  }
+}
+
+/* ======================================================================
+ * interaction_push_particle
+ * ====================================================================== */
+
+/* src/pic1dp_interaction.F90:178-189 (VecCopy over the whole local vector) */
+void orc_push_backup(int64_t nalloc, const double *x, const double *v,
+                     const double *w, double *xb, double *vb, double *wb,
+                     int deltaf) {
+  memcpy(xb, x, sizeof(double) * (size_t)nalloc);
+  memcpy(vb, v, sizeof(double) * (size_t)nalloc);
+  if (deltaf == 1) memcpy(wb, w, sizeof(double) * (size_t)nalloc);
+}
+
+/* -d f0/dv / f0, src/pic1dp_interaction.F90:274-326 */
+static inline double dlnf0(const orc_input *in, int isp, double v) {
+  const double T = in->species_temperature[isp];
+  const double T2 = in->species_temperature2[isp];
+  const double m = in->species_mass[isp];
+  const double den = in->species_density[isp];
+  const double v0 = in->species_v0[isp];
+  if (in->iptcldist == 1) { /* :276 */
+    return v - 2.0 / v;
+  } else if (in->iptcldist == 2) { /* :278-292 */
+    const double two_tm = 2.0 * T / m;
+    double vp = v + v0, vm = v - v0;
+    double ep = exp(-(vp * vp) / two_tm), em = exp(-(vm * vm) / two_tm);
+    return (vp * ep + vm * em) / (ep + em) * m / T;
+  } else if (in->iptcldist == 3) { /* :294-321 */
+    const double tm = T / m, tm2 = T2 / m;
+    const double two_tm = 2.0 * T / m, two_tm2 = 2.0 * T2 / m;
+    const double stm = sqrt(tm), stm2 = sqrt(tm2);
+    const double beam = 1.0 - den;
+    double vm = v - v0;
+    double e1 = exp(-(v * v) / two_tm), e2 = exp(-(vm * vm) / two_tm2);
+    double num = den * v / tm * e1 / stm + beam * vm / tm2 * e2 / stm2;
+    double dnm = den * e1 / stm + beam * e2 / stm2;
+    return num / dnm;
+  }
+  return (v - v0) / (T / m); /* :323-325 */
+}
+
+/* src/pic1dp_interaction.F90:238-339 */
+void orc_push_species(const orc_input *in, int isp, int irk, const double *E,
+                      int64_t np, double *x, double *v, const double *p,
+                      double *w, const double *xb, const double *vb,
+                      const double *wb) {
+  const double dt = irk == 1 ? 0.5 * in->dt : in->dt; /* :179,192 */
+  const double lx = in->lx;
+  const int32_t nx = in->nx;
+  const double dnx = (double)nx;
+  const double Z = in->species_charge[isp], m = in->species_mass[isp];
+  for (int64_t ip = 0; ip < np; ip++) {
+    double sx = x[ip] / lx * dnx; /* :250 */
+    int32_t ix = (int32_t)floor(sx);
+    sx = 1.0 - (sx - (double)ix); /* :252 */
+    if (ix >= nx) ix = 0;         /* memory safety, see deposit */
+    double e = E[ix] * sx;        /* :254 */
+    ix = ix + 1;
+    if (ix > nx - 1) ix = 0;
+    e = e + E[ix] * (1.0 - sx); /* :257 */
+    double pv = v[ip];
+    x[ip] = xb[ip] + dt * pv; /* :261 */
+    if (in->deltaf == 1) {
+      double tmp1 = in->linear == 1 ? p[ip] * e : (p[ip] - w[ip]) * e;
+      double tmp2 = dlnf0(in, isp, pv);
+      w[ip] = wb[ip] + dt * tmp1 * tmp2 * Z / m; /* :329 */
+    }
+    if (in->linear == 0) v[ip] = vb[ip] + dt * e * Z / m; /* :336 */
+  }
+}
+
+/* ======================================================================
+ * field -- src/pic1dp_field.F90
+ * ====================================================================== */
+
+/* operators of field_init, :158-210 */
+orc_field *orc_field_new(const orc_input *in) {
+  orc_field *f = (orc_field *)calloc(1, sizeof(orc_field));
+  const int nx = in->nx, nm = in->nmode;
+  f->nx = nx;
+  f->nmode = nm;
+  f->fourier_re = (double *)malloc(sizeof(double) * (size_t)nx * nm);
+  f->fourier_im = (double *)malloc(sizeof(double) * (size_t)nx * nm);
+  f->grad_inv = (double *)malloc(sizeof(double) * (size_t)nm);
+  for (int im = 0; im < nm; im++) /* :165-166 */
+    f->grad_inv[im] = 1.0 / (2.0 * ORC_PI / in->lx * (double)in->modes[im]);
+  for (int ix = 0; ix < nx; ix++)
+    for (int im = 0; im < nm; im++) { /* :187-188, :195-196 */
+      double th = 2.0 * ORC_PI / (double)nx * (double)in->modes[im] * (double)ix;
+      f->fourier_re[(size_t)ix * nm + im] = cos(th);
+      f->fourier_im[(size_t)ix * nm + im] = -sin(th);
+    }
+  return f;
+}
+
+void orc_field_free(orc_field *f) {
+  if (!f) return;
+  free(f->fourier_re);
+  free(f->fourier_im);
+  free(f->grad_inv);
+  free(f);
+}
+
+/* field_solve_electric, :231-257, one-rank PETSc SeqAIJ summation order:
+ * MatMultTranspose accumulates y[col] += a(row,col)*x[row] over ascending
+ * rows; MatMult / MatMultAdd sum a row's entries in ascending column order;
+ * VecScale multiplies by the scalar (here a pre-formed reciprocal). */
+void orc_field_solve(const orc_input *in, const orc_field *f,
+                     const double *rho, double *E, double *mode_re,
+                     double *mode_im) {
+  const int nx = f->nx, nm = f->nmode;
+  const double dnx = (double)in->nx;
+  const double sc_im = -1.0 / dnx, sc_re = 1.0 / dnx;
+  for (int im = 0; im < nm; im++) mode_im[im] = mode_re[im] = 0.0;
+  for (int ix = 0; ix < nx; ix++)
+    for (int im = 0; im < nm; im++) {
+      mode_im[im] += f->fourier_re[(size_t)ix * nm + im] * rho[ix]; /* :231 */
+      mode_re[im] += f->fourier_im[(size_t)ix * nm + im] * rho[ix]; /* :236 */
+    }
+  for (int im = 0; im < nm; im++) {
+    mode_im[im] = mode_im[im] * sc_im;          /* :234 */
+    mode_re[im] = mode_re[im] * sc_re;          /* :239 */
+    mode_re[im] = mode_re[im] * f->grad_inv[im]; /* :243 */
+    mode_im[im] = mode_im[im] * f->grad_inv[im]; /* :246 */
+  }
+  for (int ix = 0; ix < nx; ix++) {
+    double s = 0.0;
+    for (int im = 0; im < nm; im++) /* :251 */
+      s += f->fourier_re[(size_t)ix * nm + im] * mode_re[im];
+    for (int im = 0; im < nm; im++) /* :253 */
+      s += f->fourier_im[(size_t)ix * nm + im] * mode_im[im];
+    E[ix] = s * 2.0; /* :256 */
+  }
+}
+
+/* src/pic1dp_output.F90:120-124 (VecNorm NORM_2, then squared) */
+double orc_field_energy(const orc_input *in, const double *E) {
+  double s = 0.0;
+  for (int ix = 0; ix < in->nx; ix++) s += E[ix] * E[ix];
+  double nrm = sqrt(s);
+  return nrm * nrm * in->lx / (double)in->nx;
+}
+
+/* src/pic1dp_output.F90:126-172 for deltaf==1 (sums run over the whole
+ * local vector, not just particle_np) */
+void orc_energy_sums(int64_t nalloc, const double *v, const double *p,
+                     const double *w, int deltaf, double out[3]) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = 0; i < nalloc; i++) {
+    double v2 = v[i] * v[i];
+    s0 += v2;
+    s1 += v2 * p[i];
+    if (deltaf == 1) s2 += v2 * w[i];
+  }
+  out[0] = s0;
+  out[1] = s1;
+  out[2] = deltaf == 1 ? s2 : s1;
+}
+
+/* src/pic1dp_output.F90:239-315: raw (unscaled, unreduced) histograms */
+void orc_ptcldist(const orc_input *in, int64_t np, const double *x,
+                  const double *v, const double *p, const double *w,
+                  double *markr_xv, double *total_xv, double *pertb_xv,
+                  double *markr_v, double *total_v, double *pertb_v) {
+  const int nxo = in->nx_opd, nvo = in->nv_opd;
+  const double lx = in->lx, vmax = in->v_max;
+  for (int64_t ip = 0; ip < np; ip++) {
+    if (fabs(v[ip]) >= vmax) continue; /* :241 */
+    double sx = x[ip] / lx * (double)nxo;
+    int ix = (int)floor(sx);
+    sx = 1.0 - (sx - (double)ix);
+    double sv = (v[ip] + vmax) / (vmax * 2.0) * (double)(nvo - 1);
+    int iv = (int)floor(sv);
+    sv = 1.0 - (sv - (double)iv);
+    if (ix < 0 || ix >= nxo || iv < 0 || iv + 1 >= nvo) continue; /* safety */
+    double pp = p[ip], pw = w ? w[ip] : 0.0;
+    for (int pass = 0; pass < 2; pass++) {
+      int a = iv * nxo + ix, b = (iv + 1) * nxo + ix;
+      markr_xv[a] += sx * sv;
+      total_xv[a] += sx * sv * pp;
+      if (in->deltaf == 1) pertb_xv[a] += sx * sv * pw;
+      markr_xv[b] += sx * (1.0 - sv);
+      total_xv[b] += sx * (1.0 - sv) * pp;
+      if (in->deltaf == 1) pertb_xv[b] += sx * (1.0 - sv) * pw;
+      ix = ix + 1; /* :274-276 */
+      if (ix > nxo - 1) ix = 0;
+      sx = 1.0 - sx;
+    }
+    markr_v[iv] += sv;
+    total_v[iv] += sv * pp;
+    if (in->deltaf == 1) pertb_v[iv] += sv * pw;
+    markr_v[iv + 1] += (1.0 - sv);
+    total_v[iv + 1] += (1.0 - sv) * pp;
+    if (in->deltaf == 1) pertb_v[iv + 1] += (1.0 - sv) * pw;
+  }
+}
+
+/* ======================================================================
+ * driver -- src/pic1dp.F90:64-109 with npe virtual reference ranks
+ * ====================================================================== */
+struct orc_sim {
+  orc_input in;
+  int npe, nthreads;
+  orc_field *fld;
+  int64_t *nalloc;              /* [npe] */
+  int64_t *np;                  /* [npe][nspecies] */
+  double **arr;                 /* [npe][nspecies][7] */
+  double *charge_rank;          /* [npe][nx] per-rank charge2 */
+  double *charge1, *chargeden, *E, *mode_re, *mode_im;
+  int32_t itime;
+  double time;
+};
+
+#define SIM_ARR(s, r, isp, k) ((s)->arr[((size_t)(r) * (s)->in.nspecies + (isp)) * 7 + (k)])
+
+orc_sim *orc_sim_new(const orc_input *in, int npe) {
+  orc_sim *s = (orc_sim *)calloc(1, sizeof(orc_sim));
+  s->in = *in;
+  s->npe = npe;
+  s->nthreads = 1;
+  s->fld = orc_field_new(in);
+  s->nalloc = (int64_t *)calloc((size_t)npe, sizeof(int64_t));
+  s->np = (int64_t *)calloc((size_t)npe * in->nspecies, sizeof(int64_t));
+  s->arr = (double **)calloc((size_t)npe * in->nspecies * 7, sizeof(double *));
+  for (int r = 0; r < npe; r++) {
+    s->nalloc[r] = orc_local_size(in->nparticle_max, r, npe);
+    for (int isp = 0; isp < in->nspecies; isp++) {
+      s->np[(size_t)r * in->nspecies + isp] = orc_particle_np(in, isp, r, npe);
+      for (int k = 0; k < 7; k++)
+        SIM_ARR(s, r, isp, k) =
+            (double *)calloc((size_t)s->nalloc[r] + 1, sizeof(double));
+    }
+  }
+  s->charge_rank = (double *)calloc((size_t)npe * in->nx, sizeof(double));
+  s->charge1 = (double *)calloc((size_t)in->nx, sizeof(double));
+  s->chargeden = (double *)calloc((size_t)in->nx, sizeof(double));
+  s->E = (double *)calloc((size_t)in->nx, sizeof(double));
+  s->mode_re = (double *)calloc((size_t)in->nmode, sizeof(double));
+  s->mode_im = (double *)calloc((size_t)in->nmode, sizeof(double));
+  return s;
+}
+
+void orc_sim_free(orc_sim *s) {
+  if (!s) return;
+  for (size_t i = 0; i < (size_t)s->npe * s->in.nspecies * 7; i++) free(s->arr[i]);
+  free(s->arr);
+  free(s->nalloc);
+  free(s->np);
+  free(s->charge_rank);
+  free(s->charge1);
+  free(s->chargeden);
+  free(s->E);
+  free(s->mode_re);
+  free(s->mode_im);
+  orc_field_free(s->fld);
+  free(s);
+}
+
+void orc_sim_set_threads(orc_sim *s, int nthreads) {
+  s->nthreads = nthreads < 1 ? 1 : nthreads;
+}
+
+/* particle_load on every virtual rank, src/pic1dp_particle.F90:159-265 */
+int orc_sim_load(orc_sim *s) {
+  int rc_all = 0;
+#pragma omp parallel for num_threads(s->nthreads) schedule(static, 1)
+  for (int r = 0; r < s->npe; r++) {
+    orc_multirand *g = orc_multirand_new();
+    int rc = orc_multirand_init(g, s->in.multirand_al_int,
+                                s->in.multirand_seed_type, r,
+                                s->in.multirand_warmup, s->in.multirand_selftest);
+    if (rc) {
+#pragma omp critical
+      rc_all = rc;
+    }
+    if (rc != 2)
+      for (int isp = 0; isp < s->in.nspecies; isp++)
+        orc_particle_load_species(&s->in, isp, g, s->nalloc[r],
+                                  SIM_ARR(s, r, isp, 0), SIM_ARR(s, r, isp, 1),
+                                  SIM_ARR(s, r, isp, 2), SIM_ARR(s, r, isp, 3));
+    orc_multirand_free(g);
+  }
+  s->itime = 0;
+  s->time = 0.0;
+  return rc_all;
+}
+
+/* interaction_collect_charge, src/pic1dp_interaction.F90:79-151 */
+void orc_sim_collect_charge(orc_sim *s) {
+  const orc_input *in = &s->in;
+  const int nx = in->nx;
+#pragma omp parallel for num_threads(s->nthreads) schedule(static, 1)
+  for (int r = 0; r < s->npe; r++) {
+    double *c2 = s->charge_rank + (size_t)r * nx;
+    double *c1 = (double *)malloc(sizeof(double) * (size_t)nx);
+    for (int ix = 0; ix < nx; ix++) c2[ix] = 0.0; /* :81 */
+    for (int isp = 0; isp < in->nspecies; isp++) {
+      for (int ix = 0; ix < nx; ix++) c1[ix] = 0.0; /* :83 */
+      const double *q = in->deltaf == 1 ? SIM_ARR(s, r, isp, 3) : SIM_ARR(s, r, isp, 2);
+      orc_deposit_species(in, s->np[(size_t)r * in->nspecies + isp],
+                          SIM_ARR(s, r, isp, 0), q, c1);
+      for (int ix = 0; ix < nx; ix++) /* :126-127 */
+        c2[ix] = c2[ix] + c1[ix] * in->species_charge[isp];
+    }
+    free(c1);
+  }
+  /* MPI_Allreduce(SUM) :132 -- summed here in rank order */
+  for (int ix = 0; ix < nx; ix++) {
+    double t = s->charge_rank[ix];
+    for (int r = 1; r < s->npe; r++) t = t + s->charge_rank[(size_t)r * nx + ix];
+    s->charge1[ix] = t;
+  }
+  orc_chargeden_from_charge(in, s->charge1, s->chargeden);
+}
+
+void orc_sim_solve_field(orc_sim *s) {
+  orc_field_solve(&s->in, s->fld, s->chargeden, s->E, s->mode_re, s->mode_im);
+}
+
+/* interaction_push_particle, src/pic1dp_interaction.F90:161-370 */
+void orc_sim_push(orc_sim *s, int irk) {
+  const orc_input *in = &s->in;
+#pragma omp parallel for num_threads(s->nthreads) schedule(static, 1)
+  for (int r = 0; r < s->npe; r++)
+    for (int isp = 0; isp < in->nspecies; isp++) {
+      double *x = SIM_ARR(s, r, isp, 0), *v = SIM_ARR(s, r, isp, 1);
+      double *p = SIM_ARR(s, r, isp, 2), *w = SIM_ARR(s, r, isp, 3);
+      double *xb = SIM_ARR(s, r, isp, 4), *vb = SIM_ARR(s, r, isp, 5);
+      double *wb = SIM_ARR(s, r, isp, 6);
+      if (irk == 1) orc_push_backup(s->nalloc[r], x, v, w, xb, vb, wb, in->deltaf);
+      orc_push_species(in, isp, irk, s->E, s->np[(size_t)r * in->nspecies + isp],
+                       x, v, p, w, xb, vb, wb);
+    }
+}
+
+/* time loop body, src/pic1dp.F90:79-93 */
+void orc_sim_step(orc_sim *s, int nsteps) {
+  for (int it = 0; it < nsteps; it++) {
+    for (int irk = 1; irk <= 2; irk++) {
+      orc_sim_push(s, irk);
+      orc_sim_collect_charge(s);
+      orc_sim_solve_field(s);
+    }
+    s->itime += 1;
+    s->time = s->time + s->in.dt;
+  }
+}
+
+int32_t orc_sim_itime(const orc_sim *s) { return s->itime; }
+double orc_sim_time(const orc_sim *s) { return s->time; }
+double orc_sim_field_energy(const orc_sim *s) { return orc_field_energy(&s->in, s->E); }
+
+void orc_sim_get_field(const orc_sim *s, double *E, double *rho,
+                       double *mode_re, double *mode_im) {
+  if (E) memcpy(E, s->E, sizeof(double) * (size_t)s->in.nx);
+  if (rho) memcpy(rho, s->chargeden, sizeof(double) * (size_t)s->in.nx);
+  if (mode_re) memcpy(mode_re, s->mode_re, sizeof(double) * (size_t)s->in.nmode);
+  if (mode_im) memcpy(mode_im, s->mode_im, sizeof(double) * (size_t)s->in.nmode);
+}
+
+void orc_sim_set_field(orc_sim *s, const double *E) {
+  memcpy(s->E, E, sizeof(double) * (size_t)s->in.nx);
+}
+
+int64_t orc_sim_rank_np(const orc_sim *s, int rank, int isp) {
+  return s->np[(size_t)rank * s->in.nspecies + isp];
+}
+int64_t orc_sim_rank_nalloc(const orc_sim *s, int rank) { return s->nalloc[rank]; }
+double *orc_sim_array(orc_sim *s, int rank, int isp, int which) {
+  return SIM_ARR(s, rank, isp, which);
+}
+
+/* VecSum on each rank then the scalar all-reduce, rank order */
+void orc_sim_energy_sums(const orc_sim *s, int isp, double out[3]) {
+  out[0] = out[1] = out[2] = 0.0;
+  for (int r = 0; r < s->npe; r++) {
+    double t[3];
+    orc_energy_sums(s->nalloc[r], SIM_ARR(s, r, isp, 1), SIM_ARR(s, r, isp, 2),
+                    SIM_ARR(s, r, isp, 3), s->in.deltaf, t);
+    for (int k = 0; k < 3; k++) out[k] = out[k] + t[k];
+  }
+}
+
+/* src/pic1dp.F90:133-148 */
+int orc_check_termination(const orc_input *in, int32_t itime, double time) {
+  return (itime >= in->ntime_max || time + ORC_SQRT_EPS >= in->time_max) ? 1 : 0;
+}
+
+/* src/pic1dp.F90:98-106 */
+int orc_output_due(const orc_input *in, double time, int itermination) {
+  double a = fmod(time + ORC_SQRT_EPS, in->output_interval);
+  double b = fmod(time + ORC_SQRT_EPS - in->dt, in->output_interval);
+  return (a < b || itermination == 1) ? 1 : 0;
+}
