@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-updates/sec of the PIC1D time-step hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json): configs[2] = bump-on-tail, 10^8 markers, 1024 grid
+cells, the configuration the metric is quoted on; it fits one GPU.  For N > 1
+every GPU holds 10^8 markers (weak scaling; configs[4] is this at N = 8) and the
+per-GPU charge vector is summed by one RCCL all-reduce per sub-step.
+
+A "step" is one time step = two Runge-Kutta sub-steps of push+gather, deposit,
+(all-reduce,) field solve over all markers.  A particle-update is one marker
+through one sub-step: value = markers_total * 2 * K / wall time.  Markers are
+resident in HBM before the timed region (the native loader runs untimed).
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     : algorithmic bytes of the fused push+gather+deposit kernel
+                 (80 B per particle-update) / its mean launch
+                 duration from HIP events on the engine's stream, vs 8 TB/s
+  cpu_baseline : the CPU oracle (line-faithful restatement of the reference,
+                 "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import pic1dp_amd  # noqa: E402  (loads libpic1dp_hip.so first: one HIP runtime per process)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALG_BYTES_PER_UPDATE = 80.0    # fused push+gather(+deposit), delta-f FP64
+
+CONFIGS = {
+    # BASELINE.json configs[1] and configs[2]
+    "c2": dict(nparticle_max=10**7, nx=256),
+    "c3": dict(nparticle_max=10**8, nx=1024),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--particles", type=int, default=0, help="markers per GPU (override)")
+    ap.add_argument("--nx", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0, help="workgroup size of the particle kernels")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--unfused", action="store_true", help="time separate push / deposit kernels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-particles-per-core", type=int, default=2 * 10**6)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    return ap.parse_args()
+
+
+def host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 32))
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, per_core, steps):
+    """the oracle (CPU restatement of the reference path) on the host cores:
+    T threads, each owning one reference rank block with a private charge array
+    (= a T-rank reference run), plus the same on 1 thread (= 1 MPI rank)."""
+    import oracle  # test infrastructure, used here only as the timed CPU baseline
+    T = host_cores()
+    out = {}
+    for label, threads in (("all", T), ("one", 1)):
+        n = per_core * threads
+        inp = oracle.make_input(nparticle_max=n, nx=cfg["nx"])
+        sim = oracle.Sim(inp, npe=threads, nthreads=threads)
+        sim.load()
+        sim.collect_charge()
+        sim.solve_field()
+        sim.step(1)                      # warm-up
+        t0 = time.perf_counter()
+        sim.step(steps)
+        dt = time.perf_counter() - t0
+        out[label] = (n * 2 * steps / dt, n, dt)
+        del sim
+    v, n, dt = out["all"]
+    return {
+        "value": v, "unit": "updates/s", "cores": T, "kind": "port",
+        "sample": "oracle (oracle/pic1dp_oracle.c, gcc -O3 -ffp-contract=off), bump-on-tail nx=%d, "
+                  "%d markers (%d per core, one reference rank block per core), %d steps, %.1f s"
+                  % (cfg["nx"], n, per_core, steps, dt),
+        "value_1core": out["one"][0], "cpu_model": cpu_model(),
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "(one process per GPU); WORLD_SIZE is 1" % a.gpus)
+        a.gpus = world
+
+    cfg = dict(CONFIGS[a.config])
+    if a.particles:
+        cfg["nparticle_max"] = a.particles
+    if a.nx:
+        cfg["nx"] = a.nx
+    per_gpu = cfg["nparticle_max"]
+    total = per_gpu * world
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # control plane only (barrier, max over ranks, unique-id broadcast); the
+        # data-path all-reduce is RCCL inside libpic1dp_hip.so, on the engine's stream
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    # every rank owns one reference block of the global array (PETSC_DECIDE split)
+    inp = pic1dp_amd.make_input(nparticle_max=total, nx=cfg["nx"])
+    eng = pic1dp_amd.Pic1dp(inp, rank=rank, nranks=world, device=local_rank)
+    if a.threads or a.blocks_per_cu:
+        eng.set_launch(a.threads, a.blocks_per_cu)
+    pic1dp_amd.parallel.bootstrap_comm(eng, dist)
+    t0 = time.perf_counter()
+    eng.particle_load()
+    load_s = time.perf_counter() - t0
+    eng.interaction_collect_charge()
+    eng.field_solve_electric()
+    eng.sync()
+
+    def device_sync():
+        eng.sync()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(local_rank)
+                return "torch.cuda.synchronize"
+        except Exception:
+            pass
+        return "hipStreamSynchronize"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def run(nsteps):
+        if not a.unfused:
+            eng.step(nsteps)
+            return
+        for _ in range(nsteps):
+            for irk in (1, 2):
+                eng.interaction_push_particle(irk)
+                eng.interaction_collect_charge()
+                eng.field_solve_electric()
+
+    run(a.warmup)
+    sync_kind = device_sync()
+    eng.kernel_stats_enable(True)
+    eng.timers_reset()
+    barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    run(a.steps)
+    device_sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fused_ms, fused_n = eng.kernel_stats(0)
+    push_ms, push_n = eng.kernel_stats(1)
+    dep_ms, dep_n = eng.kernel_stats(2)
+    energy = eng.field_energy()
+    _, np_local = eng.local_sizes()
+
+    if rank == 0:
+        value = total * 2.0 * a.steps / elapsed
+        if a.unfused:
+            kname, kms, kn, kbytes = "k_push (separate)", push_ms, push_n, 80.0
+        else:
+            kname, kms, kn, kbytes = "k_push<fused push+gather+deposit>", fused_ms, fused_n, ALG_BYTES_PER_UPDATE
+        avg_ms = kms / max(kn, 1)
+        achieved = kbytes * np_local / (avg_ms * 1e-3) / 1e9 if kn else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("particles_per_gpu") == per_gpu and tj.get("nx") == cfg["nx"]:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                pass
+        out = {
+            "metric": "particle-updates/sec", "value": value, "unit": "updates/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "bump-on-tail delta-f, %g markers per GPU, nx=%d (BASELINE configs[%s]); "
+                            "multirand constant seeds (al_int=3, seed_type=1), one reference rank block per GPU"
+                            % (per_gpu, cfg["nx"], {"c2": "1", "c3": "2"}[a.config]),
+                "particles_total": total, "particles_per_gpu": per_gpu, "nx": cfg["nx"],
+                "nmode": 1, "dt": 0.05,
+                "parallelism": "particle shard x%d, replicated grid, RCCL all-reduce of the charge vector" % world,
+                "path": "separate push/deposit kernels" if a.unfused else "fused push+gather+deposit kernel",
+                "sync": sync_kind, "load_seconds": load_s,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": kname, "avg_launch_ms": avg_ms, "launches": kn,
+                "algorithmic_bytes_per_update": kbytes, "updates_per_launch": np_local,
+                "deposit_kernel_avg_ms": dep_ms / dep_n if dep_n else None,
+            },
+            "field_energy_end": energy,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_particles_per_core, a.cpu_steps)
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,287 @@
+/*
+ * pic1dp_hip.h -- C ABI of the MI355X-native PIC1D time-step engine.
+ *
+ * This is the drop-in boundary for the hot path of wenjundeng/pic1dp
+ * (PIC1D-PETSc): particle push + field gather, charge deposition (+ all-reduce)
+ * and the mode-filtered spectral field solve.  The reference has no FFI: the
+ * boundary there is three argument-less Fortran module procedures working on
+ * module-global PETSc Vecs.  Each entry point below
+ * names the reference procedure / call site it replaces (paths relative to the
+ * reference tree).  The Fortran side binds these through ISO_C_BINDING
+ * (pic1dp_amd/fortran/pic1dp_hip_mod.F90).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Every function returns int: 0 = success, non-zero = error (the reference's
+ *     PetscErrorCode / CHKERRQ convention, src/pic1dp_global.F90:59).
+ *     pic1dp_hip_last_error() gives the message of the calling thread's last
+ *     failure.
+ *   - All state lives in an opaque context created per process/GPU.  Compute
+ *     calls enqueue work on the context's HIP stream and return; calls that
+ *     hand data to the host (get_*, download, energy, timers) synchronise.
+ *   - Called from one host thread per context (the reference is single-threaded
+ *     per MPI rank, src/multirand.F90:43-44).
+ *   - FP64 everywhere (PetscReal/PetscScalar = real(8)); counts are int64.
+ *   - There is NO CPU fallback: without a usable HIP device create() fails.
+ */
+#ifndef PIC1DP_HIP_H
+#define PIC1DP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIC1DP_ABI_VERSION 1
+#define PIC1DP_MAX_SPECIES 8
+#define PIC1DP_MAX_MODES 64
+#define PIC1DP_MAX_INIT_MODES 16
+#define PIC1DP_COMM_ID_BYTES 128
+
+/* error codes */
+enum {
+  PIC1DP_OK = 0,
+  PIC1DP_ERR_ARG = 1,      /* bad argument / unsupported parameter value */
+  PIC1DP_ERR_HIP = 2,      /* HIP runtime failure (message has the HIP error) */
+  PIC1DP_ERR_NODEVICE = 3, /* no usable gfx950 device: no CPU fallback exists */
+  PIC1DP_ERR_STATE = 4,    /* call out of sequence (e.g. step before load) */
+  PIC1DP_ERR_COMM = 5,     /* RCCL failure / library not loadable */
+  PIC1DP_ERR_RNG = 6,      /* multirand self-test failed or would hang */
+  PIC1DP_ERR_NOMEM = 7
+};
+
+/* Run-time mirror of the compile-time parameters of src/pic1dp_input.F90:32-256.
+ * Field names are the reference names without the "input_" prefix. */
+typedef struct pic1dp_input {
+  int32_t abi_version;          /* must be PIC1DP_ABI_VERSION */
+  int32_t ntime_max;            /* :32 */
+  int32_t linear;               /* :43  0 nonlinear, 1 linear */
+  int32_t iptcldist;            /* :54  0 Maxwellian 1 two-stream1 2 two-stream2 3 bump-on-tail */
+  int32_t nspecies;             /* :57 */
+  int32_t nmode;                /* :75 */
+  int32_t init_nmode;           /* :87 */
+  int32_t deltaf;               /* :106 0 full-f, 1 delta-f */
+  int32_t imarker;              /* :122 1 physical, 2 uniform in v */
+  int32_t nx;                   /* :128 */
+  int32_t nv;                   /* :131 (header of pic1dp.out only) */
+  int32_t iptclshape;           /* :138 only 4 (on-the-fly linear shape) is built */
+  int32_t nx_opd;               /* :253 */
+  int32_t nv_opd;               /* :256 */
+  int32_t multirand_al_int;     /* :217 */
+  int32_t multirand_seed_type;  /* :223 */
+  int32_t multirand_warmup;     /* :226 */
+  int32_t multirand_selftest;   /* :233 */
+  int64_t nparticle_max;        /* :113 global allocation per species */
+  int64_t species_nparticle_init[PIC1DP_MAX_SPECIES]; /* :116 */
+  double time_max;              /* :35 */
+  double lx;                    /* :46 */
+  double dt;                    /* :109 */
+  double v_max;                 /* :125 */
+  double output_interval;       /* :250 */
+  double species_charge[PIC1DP_MAX_SPECIES];       /* :67 */
+  double species_mass[PIC1DP_MAX_SPECIES];         /* :68 */
+  double species_temperature[PIC1DP_MAX_SPECIES];  /* :69 */
+  double species_temperature2[PIC1DP_MAX_SPECIES]; /* :70 */
+  double species_density[PIC1DP_MAX_SPECIES];      /* :71 */
+  double species_v0[PIC1DP_MAX_SPECIES];           /* :72 */
+  int32_t modes[PIC1DP_MAX_MODES];                 /* :79 */
+  int32_t init_mode[PIC1DP_MAX_INIT_MODES];        /* :90 */
+  double init_mode_cos[PIC1DP_MAX_INIT_MODES];     /* :97 */
+  double init_mode_sin[PIC1DP_MAX_INIT_MODES];     /* :98 */
+} pic1dp_input;
+
+/* Placement of this process in the particle decomposition.
+ * The reference splits every particle Vec into `npe` contiguous PETSC_DECIDE
+ * blocks (src/pic1dp_particle.F90:89-94,129) and seeds one RNG stream per MPI
+ * rank (:159-160).  Here `npe` is the number of REFERENCE ranks being
+ * reproduced; this process (rank of nranks, one per GPU) owns the contiguous
+ * group of npe/nranks reference blocks starting at rank*npe/nranks, so a
+ * 1-GPU run can reproduce an 8-rank reference run ("virtual ranks").
+ * npe must be a multiple of nranks; npe = nranks gives the plain mapping. */
+typedef struct pic1dp_layout {
+  int32_t rank;    /* global_mype of this process, 0-based */
+  int32_t nranks;  /* processes = GPUs in the job */
+  int32_t npe;     /* reference ranks reproduced (global_npe); 0 -> nranks */
+  int32_t device;  /* HIP device ordinal; -1 -> rank % device count */
+} pic1dp_layout;
+
+typedef struct pic1dp_ctx pic1dp_ctx; /* opaque */
+
+/* wall-clock timer ids: the reference's ids, src/pic1dp_global.F90:38-50 */
+enum {
+  PIC1DP_IWT_TOTAL = 1,
+  PIC1DP_IWT_INIT = 2,
+  PIC1DP_IWT_PARTICLE_LOAD = 3,
+  PIC1DP_IWT_PUSH_PARTICLE = 4,
+  PIC1DP_IWT_PARTICLE_SHAPE = 5,
+  PIC1DP_IWT_COLLECT_CHARGE = 6,
+  PIC1DP_IWT_FIELD_ELECTRIC = 7,
+  PIC1DP_IWT_PARTICLE_OPTIMIZE = 8,
+  PIC1DP_IWT_OUTPUT = 9,
+  PIC1DP_IWT_FINAL = 10,
+  PIC1DP_IWT_MPIALLREDU = 21,
+  PIC1DP_IWT_SCATTER = 22
+};
+
+/* ---- library ---------------------------------------------------------- */
+int pic1dp_hip_abi_version(void);
+const char *pic1dp_hip_last_error(void);
+/* number of visible HIP devices (0 when none; never fails) */
+int pic1dp_hip_device_count(void);
+/* fill `in` with the values of the reference's input file
+ * (src/pic1dp_input.F90), except multirand_seed_type = 1 (reproducible) */
+int pic1dp_hip_input_defaults(pic1dp_input *in);
+
+/* sizeof(pic1dp_input) as the library was compiled: lets a binding in another
+ * language verify its struct layout before the first call */
+int pic1dp_hip_input_size(void);
+/* the two validity checks of input_init (src/pic1dp_input.F90:287-308) plus the
+ * range checks of this build, without touching a device */
+int pic1dp_hip_input_validate(const pic1dp_input *in, const pic1dp_layout *layout);
+
+/* ---- host-only helpers (no device needed) --------------------------------
+ * allocated slots / valid markers of reference block `mype` of `npe`
+ * (src/pic1dp_particle.F90:129, :240-248) */
+int pic1dp_hip_block_sizes(const pic1dp_input *in, int32_t ispecies, int32_t mype,
+                           int32_t npe, int64_t *nalloc, int64_t *np);
+/* particle_load of ONE reference block into HOST arrays: x, v, p, w each hold
+ * nspecies * nalloc doubles, species-major (species s at offset s*nalloc).
+ * This is the generator pic1dp_hip_particle_load uses before the upload. */
+int pic1dp_hip_host_particle_load(const pic1dp_input *in, int32_t mype, int32_t npe,
+                                  double *x, double *v, double *p, double *w,
+                                  int64_t nalloc);
+
+/* ---- life cycle -------------------------------------------------------
+ * create  <-> input_init + particle_init + field_init
+ *             (src/pic1dp.F90:57-59; src/pic1dp_particle.F90:66-139;
+ *              src/pic1dp_field.F90:55-212)
+ * destroy <-> particle_final + field_final (src/pic1dp.F90:113-114) */
+int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout,
+                      pic1dp_ctx **out);
+int pic1dp_hip_destroy(pic1dp_ctx *ctx);
+
+/* local sizes of this process: allocated slots (sum of its reference blocks'
+ * PETSC_DECIDE sizes) and valid markers particle_np (src/pic1dp_particle.F90:54,
+ * :240-248) of one species */
+int pic1dp_hip_local_sizes(pic1dp_ctx *ctx, int32_t ispecies, int64_t *nalloc,
+                           int64_t *np);
+
+/* ---- initial condition -------------------------------------------------
+ * particle_load (src/pic1dp_particle.F90:145-269) with multirand
+ * (src/multirand.F90): native host loader, one RNG stream per owned reference
+ * block (seeded with that block's mype), then H2D.  Uses the multirand_*
+ * fields of the input. */
+int pic1dp_hip_particle_load(pic1dp_ctx *ctx);
+/* alternative for a host that ran the reference's own particle_load:
+ * hand over HOST arrays of one species (n = allocated slots, np = valid) --
+ * the VecGetArrayF90 view of particle_x/v/p/w (src/pic1dp_particle.F90:34-36) */
+int pic1dp_hip_particles_upload(pic1dp_ctx *ctx, int32_t ispecies,
+                                const double *x, const double *v,
+                                const double *p, const double *w, int64_t n,
+                                int64_t np);
+/* copy the current particle_x/v/p/w of one species back to HOST arrays of
+ * n = allocated slots (any pointer may be NULL) */
+int pic1dp_hip_particles_download(pic1dp_ctx *ctx, int32_t ispecies, double *x,
+                                  double *v, double *p, double *w, int64_t n);
+/* RK backups particle_x_bak/v_bak/w_bak as the reference would hold them
+ * (valid between push(1) and the end of push(2)) */
+int pic1dp_hip_particles_download_bak(pic1dp_ctx *ctx, int32_t ispecies,
+                                      double *xb, double *vb, double *wb,
+                                      int64_t n);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* interaction_collect_charge, iptclshape 4 (src/pic1dp_interaction.F90:79-151,
+ * call sites src/pic1dp.F90:71,88): periodic wrap of x (stored back), linear
+ * deposit, species charge scaling, all-reduce over ranks (RCCL), normalisation
+ * into field_chargeden */
+int pic1dp_hip_collect_charge(pic1dp_ctx *ctx);
+/* field_solve_electric (src/pic1dp_field.F90:218-270, call sites
+ * src/pic1dp.F90:72,89): mode-filtered partial DFT solve of field_chargeden
+ * into field_electric, field_mode_re, field_mode_im */
+int pic1dp_hip_solve_field(pic1dp_ctx *ctx);
+/* interaction_push_particle (src/pic1dp_interaction.F90:161-370, call site
+ * src/pic1dp.F90:80); irk = global_irk = 1 or 2 */
+int pic1dp_hip_push(pic1dp_ctx *ctx, int32_t irk);
+/* one Runge-Kutta sub-step = push(irk); collect_charge; solve_field
+ * (src/pic1dp.F90:80-89) with push+wrap+deposit fused into one kernel */
+int pic1dp_hip_substep(pic1dp_ctx *ctx, int32_t irk);
+/* nsteps time steps: {substep(1); substep(2); itime += 1; time += dt}
+ * (src/pic1dp.F90:79-93).  The field energy int E^2 dx after every step is
+ * appended to a device-side history (see pic1dp_hip_energy_history). */
+int pic1dp_hip_step(pic1dp_ctx *ctx, int32_t nsteps);
+/* wait for everything enqueued on the context's stream */
+int pic1dp_hip_sync(pic1dp_ctx *ctx);
+
+/* global_itime / global_time (src/pic1dp_global.F90:62-63) */
+int pic1dp_hip_get_time(pic1dp_ctx *ctx, int32_t *itime, double *time);
+int pic1dp_hip_set_time(pic1dp_ctx *ctx, int32_t itime, double time);
+/* check_termination (src/pic1dp.F90:133-148): *flag = 1 to terminate */
+int pic1dp_hip_check_termination(pic1dp_ctx *ctx, int32_t *flag);
+/* output cadence test of src/pic1dp.F90:98-106 evaluated at the current time */
+int pic1dp_hip_output_due(pic1dp_ctx *ctx, int32_t itermination, int32_t *flag);
+
+/* ---- field access (what output_field reads, src/pic1dp_output.F90:173-186) */
+/* any pointer may be NULL; E, chargeden: [nx]; mode_re, mode_im: [nmode] */
+int pic1dp_hip_get_field(pic1dp_ctx *ctx, double *electric, double *chargeden,
+                         double *mode_re, double *mode_im);
+/* overwrite field_electric (testing the push against a prescribed field) */
+int pic1dp_hip_set_electric(pic1dp_ctx *ctx, const double *electric);
+/* overwrite field_chargeden (testing the solve; field_test of
+ * src/pic1dp_field.F90:276-309) */
+int pic1dp_hip_set_chargeden(pic1dp_ctx *ctx, const double *chargeden);
+/* int E^2 dx = ||E||_2^2 * lx / nx (src/pic1dp_output.F90:120-124) */
+int pic1dp_hip_field_energy(pic1dp_ctx *ctx, double *energy);
+/* energies recorded by step(): copies min(count, max) values, oldest first */
+int pic1dp_hip_energy_history(pic1dp_ctx *ctx, double *energy, int64_t max,
+                              int64_t *count);
+int pic1dp_hip_energy_history_reset(pic1dp_ctx *ctx);
+/* per-species sums of output_field (src/pic1dp_output.F90:126-172), local to
+ * this process: out[0]=sum v^2, out[1]=sum v^2 p, out[2]=sum v^2 w */
+int pic1dp_hip_energy_sums(pic1dp_ctx *ctx, int32_t ispecies, double out[3]);
+/* cell index ix of every valid marker of one species and the per-cell marker
+ * counts, as the deposit computes them (src/pic1dp_interaction.F90:106-107);
+ * ix: [np] int32, count: [nx] int64, either may be NULL */
+int pic1dp_hip_cell_indices(pic1dp_ctx *ctx, int32_t ispecies, int32_t *ix,
+                            int64_t *count);
+
+/* ---- split-phase deposit for a host that owns the reduction (MPI) ------
+ * charge_local: everything of collect_charge up to the all-reduce
+ *   (src/pic1dp_interaction.F90:81-128) -> this rank's charge2[nx] on the host
+ * charge_reduced: hand back the globally summed array; finishes :138-150 */
+int pic1dp_hip_charge_local(pic1dp_ctx *ctx, double *charge2);
+int pic1dp_hip_charge_reduced(pic1dp_ctx *ctx, const double *charge1);
+
+/* ---- multi-GPU: RCCL communicator (replaces MPI_Allreduce at
+ * src/pic1dp_interaction.F90:132) ------------------------------------------
+ * rank 0 obtains an id, the host distributes the 128 bytes to every rank
+ * (MPI_Bcast / torch.distributed), every rank calls comm_init. */
+int pic1dp_hip_comm_unique_id(unsigned char id[PIC1DP_COMM_ID_BYTES]);
+int pic1dp_hip_comm_init(pic1dp_ctx *ctx,
+                         const unsigned char id[PIC1DP_COMM_ID_BYTES]);
+
+/* ---- timers: accumulated milliseconds under the reference's timer ids
+ * (src/pic1dp_global.F90:38-50), measured with HIP events on the stream ---- */
+int pic1dp_hip_timers_enable(pic1dp_ctx *ctx, int32_t on);
+int pic1dp_hip_timer_ms(pic1dp_ctx *ctx, int32_t iwt, double *ms);
+int pic1dp_hip_timers_reset(pic1dp_ctx *ctx);
+
+/* ---- tuning knobs (performance only; results do not depend on them apart
+ * from floating-point summation order of the charge) ----------------------- */
+/* threads per workgroup (multiple of 64, <= 1024; 0 = auto) and workgroups per
+ * CU (0 = auto) of the particle kernels */
+int pic1dp_hip_set_launch(pic1dp_ctx *ctx, int32_t threads, int32_t blocks_per_cu);
+/* opaque HIP stream handle (hipStream_t) the context enqueues on */
+int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
+/* name and launch counters of the particle kernels, for bench.py's roofline:
+ * accumulated device milliseconds (HIP events on the context's stream) and
+ * launch count of the fused push+deposit kernel (which=0), the separate push
+ * kernel (1) and the separate deposit kernel (2) */
+int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
+                            int64_t *launches);
+int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIC1DP_HIP_H */

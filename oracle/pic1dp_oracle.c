@@ -9,6 +9,9 @@
  * "**" binds tighter than unary minus, integer operands are converted to
  * double where they meet a double).  Build: gcc -O2 -ffp-contract=off.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE 1 /* sincos */
+#endif
 #include "pic1dp_oracle.h"
 
 #include <math.h>
@@ -435,8 +438,15 @@ void orc_particle_load_species(const orc_input *in, int isp, orc_multirand *g,
   for (int im = 0; im < in->init_nmode; im++) {
     const double k = 2.0 * ORC_PI / lx * (double)in->init_mode[im];
     const double ac = in->init_mode_cos[im], as = in->init_mode_sin[im];
-    for (int64_t i = 0; i < n; i++)
-      w[i] = w[i] + ac * cos(k * x[i]) + as * sin(k * x[i]);
+    for (int64_t i = 0; i < n; i++) {
+      /* GCC's middle end (hence gfortran -O3, the reference build) turns the
+       * cos/sin pair of one argument into a single sincos call; glibc's sincos
+       * and sin()/cos() differ in the last bit for ~0.05% of arguments, so the
+       * call is made explicit here instead of being left to the optimiser */
+      double sn, cs;
+      sincos(k * x[i], &sn, &cs);
+      w[i] = w[i] + ac * cs + as * sn;
+    }
   }
   /* :234-237, input_pertb_shape == 1.0 (src/pic1dp_input.F90:271) */
   for (int64_t i = 0; i < n; i++) w[i] = w[i] * p[i] * 1.0;
@@ -568,6 +578,12 @@ void orc_push_species(const orc_input *in, int isp, int irk, const double *E,
  * field -- src/pic1dp_field.F90
  * ====================================================================== */
 
+/* cos / sin that the optimiser cannot pair into sincos */
+static double (*volatile orc_cos_ptr)(double) = cos;
+static double (*volatile orc_sin_ptr)(double) = sin;
+static double orc_cos_alone(double x) { return orc_cos_ptr(x); }
+static double orc_sin_alone(double x) { return orc_sin_ptr(x); }
+
 /* operators of field_init, :158-210 */
 orc_field *orc_field_new(const orc_input *in) {
   orc_field *f = (orc_field *)calloc(1, sizeof(orc_field));
@@ -579,11 +595,17 @@ orc_field *orc_field_new(const orc_input *in) {
   f->grad_inv = (double *)malloc(sizeof(double) * (size_t)nm);
   for (int im = 0; im < nm; im++) /* :165-166 */
     f->grad_inv[im] = 1.0 / (2.0 * ORC_PI / in->lx * (double)in->modes[im]);
+  /* the reference fills the two matrices in two separate loops (:186-189 and
+   * :194-197): plain cos() and plain sin(), never merged into sincos */
   for (int ix = 0; ix < nx; ix++)
-    for (int im = 0; im < nm; im++) { /* :187-188, :195-196 */
+    for (int im = 0; im < nm; im++) {
       double th = 2.0 * ORC_PI / (double)nx * (double)in->modes[im] * (double)ix;
-      f->fourier_re[(size_t)ix * nm + im] = cos(th);
-      f->fourier_im[(size_t)ix * nm + im] = -sin(th);
+      f->fourier_re[(size_t)ix * nm + im] = orc_cos_alone(th);
+    }
+  for (int ix = 0; ix < nx; ix++)
+    for (int im = 0; im < nm; im++) {
+      double th = 2.0 * ORC_PI / (double)nx * (double)in->modes[im] * (double)ix;
+      f->fourier_im[(size_t)ix * nm + im] = -orc_sin_alone(th);
     }
   return f;
 }

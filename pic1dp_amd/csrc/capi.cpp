@@ -1,0 +1,1048 @@
+// capi.cpp -- context, sequencing and the C ABI of include/pic1dp_hip.h.
+//
+// One context = one process = one GPU = one HIP stream.  Every compute entry
+// point only enqueues kernels (and at most one RCCL all-reduce) on that stream;
+// nothing in the time loop synchronises with the host.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pic1dp_hip.h"
+#include "kernels.hpp"
+#include "loader.hpp"
+#include "multirand.hpp"
+#include "rccl_dyn.hpp"
+
+using namespace pic1dp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(PIC1DP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+#define CHECK_CTX(c) \
+  if (!(c)) return fail(PIC1DP_ERR_ARG, "null context")
+
+constexpr double kPi = 3.14159265358979323846264;        // PETSC_PI
+constexpr double kSqrtEps = 1.490116119384766e-08;       // PETSC_SQRT_MACHINE_EPSILON
+constexpr int kTagFused = 100, kTagPush = 101, kTagDeposit = 102, kNumTags = 128;
+constexpr int64_t kHistCap = 1 << 20;
+constexpr int kEnergyBlocks = 1024;
+
+bool is_pow2(double c) {
+  if (!(c > 0.0) || !std::isfinite(c)) return false;
+  int e;
+  return std::frexp(c, &e) == 0.5;
+}
+
+struct Species {
+  int64_t nalloc = 0, np = 0;
+  PSet set[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  double *p = nullptr;
+  double *rho = nullptr;  // slice of rho_sp
+  SpeciesConst sc{};
+};
+
+struct EvPair {
+  hipEvent_t a, b;
+  int tag;
+};
+
+}  // namespace
+
+struct pic1dp_ctx {
+  pic1dp_input in{};
+  pic1dp_layout lay{};
+  int device = 0, num_cu = 256;
+  hipStream_t st = nullptr;
+  int cur = 0;  // which particle set is particle_x/v/w right now
+  std::vector<Species> sp;
+  int blk0 = 0, nblk = 1;  // owned reference blocks [blk0, blk0+nblk)
+  bool loaded = false;
+  bool charge_pending = false;  // charge_local ran, waiting for charge_reduced
+  // field
+  double *d_rho_sp = nullptr, *d_charge = nullptr, *d_chargeden = nullptr, *d_E = nullptr;
+  double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
+  double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr;
+  int64_t hist_count = 0;
+  int32_t itime = 0;
+  double time = 0.0;
+  GridConst grid{};
+  FieldArgs fa{};
+  // comm
+  ncclComm_t comm = nullptr;
+  // launch
+  int threads_req = 0, bpc_req = 0;
+  // timing
+  bool timers_on = false, stats_on = false;
+  std::vector<EvPair> evpool;
+  size_t ev_used = 0;
+  double acc_ms[kNumTags] = {0};
+  int64_t acc_n[kNumTags] = {0};
+};
+
+namespace {
+
+int ev_resolve(pic1dp_ctx *c) {
+  if (c->ev_used == 0) return 0;
+  HIP_TRY(hipStreamSynchronize(c->st));
+  for (size_t i = 0; i < c->ev_used; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->evpool[i].a, c->evpool[i].b));
+    c->acc_ms[c->evpool[i].tag] += ms;
+    c->acc_n[c->evpool[i].tag] += 1;
+  }
+  c->ev_used = 0;
+  return 0;
+}
+
+// bracket helper: records a start event on construction (if enabled) and the
+// stop event in end(); pairs are resolved to milliseconds lazily (ev_resolve)
+struct Span {
+  pic1dp_ctx *c;
+  long idx = -1;
+  int rc = 0;
+  Span(pic1dp_ctx *c_, int tag, bool on) : c(c_) {
+    if (!on) return;
+    if (c->ev_used == c->evpool.size()) {
+      if (c->evpool.size() >= (1u << 20)) {
+        rc = fail(PIC1DP_ERR_STATE, "event pool exhausted: read the timers / kernel stats more often");
+        return;
+      }
+      EvPair p{};
+      if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
+        rc = fail(PIC1DP_ERR_HIP, "hipEventCreate failed");
+        return;
+      }
+      c->evpool.push_back(p);
+    }
+    idx = static_cast<long>(c->ev_used++);
+    c->evpool[idx].tag = tag;
+    if (hipEventRecord(c->evpool[idx].a, c->st) != hipSuccess) rc = fail(PIC1DP_ERR_HIP, "hipEventRecord failed");
+  }
+  int end() {
+    if (idx >= 0 && hipEventRecord(c->evpool[idx].b, c->st) != hipSuccess)
+      return fail(PIC1DP_ERR_HIP, "hipEventRecord failed");
+    return rc;
+  }
+};
+
+LaunchCfg particle_launch(const pic1dp_ctx *c, int64_t np, bool with_E, bool with_rho) {
+  const int nx = c->in.nx;
+  LaunchCfg lc{};
+  lc.lds = sizeof(double) * ((with_E ? static_cast<size_t>((nx + 2) & ~1) : 0) + (with_rho ? nx : 0));
+  const size_t lds_cap = 160 * 1024;
+  int by_lds = lc.lds ? static_cast<int>(lds_cap / lc.lds) : 8;
+  if (by_lds < 1) by_lds = 1;
+  int threads = c->threads_req > 0 ? c->threads_req : 512;
+  if (c->threads_req <= 0 && by_lds * threads < 2048) threads = 1024;
+  int bpc = 2048 / threads;
+  if (bpc > by_lds) bpc = by_lds;
+  if (c->bpc_req > 0) bpc = c->bpc_req < by_lds ? c->bpc_req : by_lds;
+  if (bpc < 1) bpc = 1;
+  int64_t blocks = static_cast<int64_t>(c->num_cu) * bpc;
+  const int64_t need = ((np >> 1) + threads - 1) / threads;
+  if (blocks > need) blocks = need;
+  if (blocks < 1) blocks = 1;
+  lc.threads = threads;
+  lc.blocks = static_cast<int>(blocks);
+  return lc;
+}
+
+SpeciesConst make_species_const(const pic1dp_input &in, int s) {
+  SpeciesConst c{};
+  const double T = in.species_temperature[s], T2 = in.species_temperature2[s];
+  c.Z = in.species_charge[s];
+  c.m = in.species_mass[s];
+  c.den = in.species_density[s];
+  c.beam = 1.0 - c.den;
+  c.v0 = in.species_v0[s];
+  c.T = T;
+  c.tm = T / c.m;
+  c.tm2 = T2 / c.m;
+  c.two_tm = 2.0 * T / c.m;
+  c.two_tm2 = 2.0 * T2 / c.m;
+  c.stm = std::sqrt(c.tm);
+  c.stm2 = std::sqrt(c.tm2);
+  c.r_m = 1.0 / c.m;
+  c.r_T = 1.0 / T;
+  c.r_tm = 1.0 / c.tm;
+  c.r_tm2 = 1.0 / c.tm2;
+  c.r_two_tm = 1.0 / c.two_tm;
+  c.r_two_tm2 = 1.0 / c.two_tm2;
+  c.r_stm = 1.0 / c.stm;
+  c.r_stm2 = 1.0 / c.stm2;
+  c.pow2 = is_pow2(c.m) && is_pow2(T) && is_pow2(c.tm) && is_pow2(c.tm2) && is_pow2(c.two_tm) &&
+           is_pow2(c.two_tm2) && is_pow2(c.stm) && is_pow2(c.stm2);
+  return c;
+}
+
+int validate(const pic1dp_input &in, const pic1dp_layout &lay) {
+  if (in.abi_version != PIC1DP_ABI_VERSION)
+    return fail(PIC1DP_ERR_ARG, "abi_version %d != %d", in.abi_version, PIC1DP_ABI_VERSION);
+  if (in.nspecies < 1 || in.nspecies > PIC1DP_MAX_SPECIES) return fail(PIC1DP_ERR_ARG, "nspecies out of range");
+  if (in.nmode < 1 || in.nmode > PIC1DP_MAX_MODES) return fail(PIC1DP_ERR_ARG, "nmode out of range");
+  if (in.init_nmode < 0 || in.init_nmode > PIC1DP_MAX_INIT_MODES) return fail(PIC1DP_ERR_ARG, "init_nmode out of range");
+  if (in.nx < 2 || in.nx > 8192) return fail(PIC1DP_ERR_ARG, "nx must be in [2, 8192] (LDS-resident grid)");
+  if (in.iptclshape != 4)
+    return fail(PIC1DP_ERR_ARG, "only iptclshape = 4 is built (the PETSc shape-matrix variants 1-3 are out of scope)");
+  if (in.iptcldist < 0 || in.iptcldist > 3) return fail(PIC1DP_ERR_ARG, "iptcldist out of range");
+  if (in.deltaf != 0 && in.deltaf != 1) return fail(PIC1DP_ERR_ARG, "deltaf must be 0 or 1");
+  if (in.linear != 0 && in.linear != 1) return fail(PIC1DP_ERR_ARG, "linear must be 0 or 1");
+  // the two checks of input_init, src/pic1dp_input.F90:292-307
+  if (in.iptcldist >= 1 && in.imarker == 1)
+    return fail(PIC1DP_ERR_ARG, "case of input_iptcldist >= 1 and input_imarker = 1 not implemented yet");
+  if (in.linear == 1 && in.deltaf == 0)
+    return fail(PIC1DP_ERR_ARG, "case of input_linear = 1 and input_deltaf = 0 not implemented yet");
+  if (in.imarker != 1 && in.imarker != 2) return fail(PIC1DP_ERR_ARG, "imarker must be 1 or 2");
+  if (!(in.lx > 0.0) || !(in.dt > 0.0) || !(in.v_max > 0.0)) return fail(PIC1DP_ERR_ARG, "lx, dt, v_max must be positive");
+  if (in.nparticle_max < 1) return fail(PIC1DP_ERR_ARG, "nparticle_max must be positive");
+  for (int s = 0; s < in.nspecies; ++s) {
+    if (in.species_nparticle_init[s] < 1 || in.species_nparticle_init[s] > in.nparticle_max)
+      return fail(PIC1DP_ERR_ARG, "species_nparticle_init out of range");
+    if (!(in.species_mass[s] > 0.0)) return fail(PIC1DP_ERR_ARG, "species_mass must be positive");
+  }
+  for (int m = 0; m < in.nmode; ++m)
+    if (in.modes[m] < 1) return fail(PIC1DP_ERR_ARG, "modes must be >= 1");
+  if (lay.nranks < 1 || lay.rank < 0 || lay.rank >= lay.nranks) return fail(PIC1DP_ERR_ARG, "bad rank/nranks");
+  const int npe = lay.npe > 0 ? lay.npe : lay.nranks;
+  if (npe % lay.nranks) return fail(PIC1DP_ERR_ARG, "npe must be a multiple of nranks");
+  return 0;
+}
+
+// the all-reduce of src/pic1dp_interaction.F90:132 on the stream
+int allreduce_charge(pic1dp_ctx *c) {
+  if (c->lay.nranks == 1) return 0;
+  if (!c->comm)
+    return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: call pic1dp_hip_comm_init (or use charge_local/charge_reduced)");
+  Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
+  ncclResult_t r = rccl().AllReduce(c->d_charge, c->d_charge, static_cast<size_t>(c->in.nx), ncclDouble,
+                                    ncclSum, c->comm, c->st);
+  if (r != ncclSuccess) return fail(PIC1DP_ERR_COMM, "ncclAllReduce: %s", rccl().GetErrorString(r));
+  return sp.end();
+}
+
+PushArgs make_push_args(pic1dp_ctx *c, int isp, int irk) {
+  Species &S = c->sp[isp];
+  PushArgs a{};
+  a.src = S.set[c->cur];
+  a.base = irk == 2 ? S.set[1 - c->cur] : S.set[c->cur];
+  a.dst = S.set[1 - c->cur];
+  a.p = S.p;
+  a.E = c->d_E;
+  a.rho = S.rho;
+  a.np = S.np;
+  a.dt = irk == 1 ? 0.5 * c->in.dt : c->in.dt;  // src/pic1dp_interaction.F90:179,192
+  a.g = c->grid;
+  a.s = S.sc;
+  a.iptcldist = c->in.iptcldist;
+  a.deltaf = c->in.deltaf;
+  a.linear = c->in.linear;
+  a.irk = irk;
+  return a;
+}
+
+int enqueue_push(pic1dp_ctx *c, int irk, bool fused) {
+  for (int s = 0; s < c->in.nspecies; ++s) {
+    PushArgs a = make_push_args(c, s, irk);
+    if (a.np <= 0) continue;
+    LaunchCfg lc = particle_launch(c, a.np, true, fused);
+    Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
+    Span ks(c, fused ? kTagFused : kTagPush, c->stats_on);
+    HIP_TRY(launch_push(a, fused, lc, c->st));
+    if (int rc = ks.end()) return rc;
+    if (int rc = tm.end()) return rc;
+  }
+  c->cur = 1 - c->cur;
+  return 0;
+}
+
+int enqueue_deposit(pic1dp_ctx *c) {
+  for (int s = 0; s < c->in.nspecies; ++s) {
+    Species &S = c->sp[s];
+    if (S.np <= 0) continue;
+    double *x = S.set[c->cur].x;
+    const double *q = c->in.deltaf ? S.set[c->cur].w : S.p;  // :84-91
+    LaunchCfg lc = particle_launch(c, S.np, false, true);
+    Span ks(c, kTagDeposit, c->stats_on);
+    HIP_TRY(launch_deposit(x, q, S.rho, S.np, c->grid, lc, c->st));
+    if (int rc = ks.end()) return rc;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int pic1dp_hip_abi_version(void) { return PIC1DP_ABI_VERSION; }
+
+const char *pic1dp_hip_last_error(void) { return g_err.c_str(); }
+
+int pic1dp_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int pic1dp_hip_input_defaults(pic1dp_input *in) {
+  if (!in) return fail(PIC1DP_ERR_ARG, "null input");
+  std::memset(in, 0, sizeof *in);
+  in->abi_version = PIC1DP_ABI_VERSION;
+  in->ntime_max = 900000;
+  in->time_max = 500.0;
+  in->linear = 0;
+  in->lx = 2.0 * 3.1415926535897932384626 / 0.36;
+  in->iptcldist = 3;
+  in->nspecies = 1;
+  in->species_charge[0] = -1.0;
+  in->species_mass[0] = 1.0;
+  in->species_temperature[0] = 1.0;
+  in->species_temperature2[0] = 1.0;
+  in->species_density[0] = 0.9;
+  in->species_v0[0] = 5.0;
+  in->nmode = 1;
+  in->modes[0] = 1;
+  in->init_nmode = 1;
+  in->init_mode[0] = 1;
+  in->init_mode_cos[0] = 0.0;
+  in->init_mode_sin[0] = 1e-5;
+  in->deltaf = 1;
+  in->dt = 0.05;
+  in->nparticle_max = 6400000;
+  in->species_nparticle_init[0] = 6400000;
+  in->imarker = 2;
+  in->v_max = 8.0;
+  in->nx = 192;
+  in->nv = 128;
+  in->iptclshape = 4;
+  in->multirand_al_int = 3;
+  in->multirand_seed_type = 1;  // the shipped input uses 3 (/dev/urandom)
+  in->multirand_warmup = 5;
+  in->multirand_selftest = 1;
+  in->output_interval = 0.5;
+  in->nx_opd = 64;
+  in->nv_opd = 64;
+  return 0;
+}
+
+int pic1dp_hip_input_size(void) { return static_cast<int>(sizeof(pic1dp_input)); }
+
+int pic1dp_hip_input_validate(const pic1dp_input *in, const pic1dp_layout *layout) {
+  if (!in) return fail(PIC1DP_ERR_ARG, "null input");
+  pic1dp_layout one{0, 1, 1, -1};
+  return validate(*in, layout ? *layout : one);
+}
+
+int pic1dp_hip_block_sizes(const pic1dp_input *in, int32_t isp, int32_t mype, int32_t npe,
+                           int64_t *nalloc, int64_t *np) {
+  if (!in) return fail(PIC1DP_ERR_ARG, "null input");
+  if (npe < 1 || mype < 0 || mype >= npe || isp < 0 || isp >= in->nspecies)
+    return fail(PIC1DP_ERR_ARG, "bad block / species index");
+  if (nalloc) *nalloc = block_alloc(in->nparticle_max, mype, npe);
+  if (np) *np = block_np(*in, isp, mype, npe);
+  return 0;
+}
+
+static int init_block_rng(const pic1dp_input &in, int mype, Multirand &g) {
+  Multirand::Status st = g.init(in.multirand_al_int, in.multirand_seed_type, mype, in.multirand_warmup,
+                                in.multirand_selftest != 0);
+  if (st == Multirand::WOULD_HANG)
+    return fail(PIC1DP_ERR_RNG,
+                "multirand: al_int=3 with seed_type 1|2 needs selftest on (the reference spins forever at "
+                "src/multirand.F90:346-348)");
+  if (st == Multirand::SELFTEST_FAILED)
+    return fail(PIC1DP_ERR_RNG, "multirand self-test: generator gives an unexpected sequence");
+  if (st == Multirand::IO_ERROR) return fail(PIC1DP_ERR_RNG, "multirand: short read from /dev/urandom");
+  return 0;
+}
+
+static int load_threads() {
+  int nthreads = static_cast<int>(std::thread::hardware_concurrency());
+  if (const char *e = std::getenv("PIC1DP_LOAD_THREADS")) nthreads = std::atoi(e);
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 64) nthreads = 64;
+  return nthreads;
+}
+
+int pic1dp_hip_host_particle_load(const pic1dp_input *in, int32_t mype, int32_t npe, double *x,
+                                  double *v, double *p, double *w, int64_t nalloc) {
+  if (!in || !x || !v || !p || !w) return fail(PIC1DP_ERR_ARG, "null argument");
+  pic1dp_layout one{0, 1, 1, -1};
+  if (int rc = validate(*in, one)) return rc;
+  if (npe < 1 || mype < 0 || mype >= npe) return fail(PIC1DP_ERR_ARG, "bad block index");
+  if (nalloc != block_alloc(in->nparticle_max, mype, npe))
+    return fail(PIC1DP_ERR_ARG, "nalloc does not match the block's PETSC_DECIDE size");
+  Multirand g;
+  if (int rc = init_block_rng(*in, mype, g)) return rc;
+  const int nthreads = load_threads();
+  for (int s = 0; s < in->nspecies; ++s)
+    load_block_species(*in, s, g, nalloc, x + s * nalloc, v + s * nalloc, p + s * nalloc, w + s * nalloc,
+                       nthreads);
+  return 0;
+}
+
+int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1dp_ctx **out) {
+  if (!in || !layout || !out) return fail(PIC1DP_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (int rc = validate(*in, *layout)) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    (void)hipGetLastError();
+    return fail(PIC1DP_ERR_NODEVICE, "no HIP device visible: this engine has no CPU path");
+  }
+  pic1dp_ctx *c = new pic1dp_ctx();
+  c->in = *in;
+  c->lay = *layout;
+  if (c->lay.npe <= 0) c->lay.npe = c->lay.nranks;
+  c->device = layout->device >= 0 ? layout->device : layout->rank % ndev;
+  if (c->device >= ndev) {
+    delete c;
+    return fail(PIC1DP_ERR_ARG, "device %d not present (%d visible)", layout->device, ndev);
+  }
+#define HIP_TRY_C(expr)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      int rc_ = fail(PIC1DP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+      pic1dp_hip_destroy(c);                                                             \
+      return rc_;                                                                        \
+    }                                                                                    \
+  } while (0)
+  HIP_TRY_C(hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  HIP_TRY_C(hipGetDeviceProperties(&prop, c->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::string arch = prop.gcnArchName;
+    pic1dp_hip_destroy(c);
+    return fail(PIC1DP_ERR_NODEVICE, "device arch %s: the kernels are built for gfx950 only", arch.c_str());
+  }
+  c->num_cu = prop.multiProcessorCount;
+  HIP_TRY_C(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+
+  const int npe = c->lay.npe;
+  c->nblk = npe / c->lay.nranks;
+  c->blk0 = c->lay.rank * c->nblk;
+  const int nx = in->nx, nm = in->nmode, ns = in->nspecies;
+  c->grid.lx = in->lx;
+  c->grid.dnx = static_cast<double>(nx);
+  c->grid.dt_full = in->dt;
+  c->grid.nx = nx;
+
+  // particle storage: valid markers of the owned blocks packed first, block
+  // tails (allocated but unloaded slots) behind them
+  c->sp.resize(ns);
+  int64_t nalloc = 0;
+  for (int b = 0; b < c->nblk; ++b) nalloc += block_alloc(in->nparticle_max, c->blk0 + b, npe);
+  HIP_TRY_C(hipMalloc(&c->d_rho_sp, sizeof(double) * ns * nx));
+  HIP_TRY_C(hipMemsetAsync(c->d_rho_sp, 0, sizeof(double) * ns * nx, c->st));
+  for (int s = 0; s < ns; ++s) {
+    Species &S = c->sp[s];
+    S.nalloc = nalloc;
+    S.np = 0;
+    for (int b = 0; b < c->nblk; ++b) S.np += block_np(*in, s, c->blk0 + b, npe);
+    S.sc = make_species_const(*in, s);
+    S.rho = c->d_rho_sp + static_cast<size_t>(s) * nx;
+    const size_t bytes = sizeof(double) * static_cast<size_t>(nalloc + 2);
+    HIP_TRY_C(hipMalloc(&S.p, bytes));
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY_C(hipMalloc(&S.set[k].x, bytes));
+      if (k == 1 && in->linear == 1) {
+        S.set[1].v = S.set[0].v;  // v is never pushed in a linear run
+      } else {
+        HIP_TRY_C(hipMalloc(&S.set[k].v, bytes));
+      }
+      if (k == 1 && in->deltaf == 0) {
+        S.set[1].w = S.set[0].w;  // w is not evolved in a full-f run
+      } else {
+        HIP_TRY_C(hipMalloc(&S.set[k].w, bytes));
+      }
+    }
+  }
+
+  // field storage and the operators of field_init (src/pic1dp_field.F90:158-210),
+  // evaluated on the host with libm like the reference, stored mode-major
+  HIP_TRY_C(hipMalloc(&c->d_charge, sizeof(double) * nx));
+  HIP_TRY_C(hipMalloc(&c->d_chargeden, sizeof(double) * nx));
+  HIP_TRY_C(hipMalloc(&c->d_E, sizeof(double) * nx));
+  HIP_TRY_C(hipMalloc(&c->d_mode_re, sizeof(double) * nm));
+  HIP_TRY_C(hipMalloc(&c->d_mode_im, sizeof(double) * nm));
+  HIP_TRY_C(hipMalloc(&c->d_fre, sizeof(double) * nm * nx));
+  HIP_TRY_C(hipMalloc(&c->d_fim, sizeof(double) * nm * nx));
+  HIP_TRY_C(hipMalloc(&c->d_ginv, sizeof(double) * nm));
+  HIP_TRY_C(hipMalloc(&c->d_hist, sizeof(double) * kHistCap));
+  HIP_TRY_C(hipMalloc(&c->d_scratch, sizeof(double) * (kEnergyBlocks * 3 + 16)));
+  HIP_TRY_C(hipMemsetAsync(c->d_charge, 0, sizeof(double) * nx, c->st));
+  HIP_TRY_C(hipMemsetAsync(c->d_chargeden, 0, sizeof(double) * nx, c->st));
+  HIP_TRY_C(hipMemsetAsync(c->d_E, 0, sizeof(double) * nx, c->st));
+  HIP_TRY_C(hipMemsetAsync(c->d_mode_re, 0, sizeof(double) * nm, c->st));
+  HIP_TRY_C(hipMemsetAsync(c->d_mode_im, 0, sizeof(double) * nm, c->st));
+  {
+    std::vector<double> fre(static_cast<size_t>(nm) * nx), fim(static_cast<size_t>(nm) * nx), gi(nm);
+    for (int m = 0; m < nm; ++m) {
+      const double mode = static_cast<double>(in->modes[m]);
+      gi[m] = 1.0 / (2.0 * kPi / in->lx * mode);  // :166
+      // two loops, plain cos() and plain sin(), as the reference's two fills
+      // (:186-189, :194-197): a paired sincos can differ in the last bit
+      double (*volatile cos_fn)(double) = std::cos;
+      double (*volatile sin_fn)(double) = std::sin;
+      for (int ix = 0; ix < nx; ++ix) {
+        const double th = 2.0 * kPi / static_cast<double>(nx) * mode * static_cast<double>(ix);  // :188
+        fre[static_cast<size_t>(m) * nx + ix] = cos_fn(th);
+      }
+      for (int ix = 0; ix < nx; ++ix) {
+        const double th = 2.0 * kPi / static_cast<double>(nx) * mode * static_cast<double>(ix);  // :196
+        fim[static_cast<size_t>(m) * nx + ix] = -sin_fn(th);
+      }
+    }
+    HIP_TRY_C(hipMemcpy(c->d_fre, fre.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemcpy(c->d_fim, fim.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemcpy(c->d_ginv, gi.data(), sizeof(double) * nm, hipMemcpyHostToDevice));
+  }
+  FieldArgs &f = c->fa;
+  f.rho_sp = c->d_rho_sp;
+  f.charge = c->d_charge;
+  f.chargeden = c->d_chargeden;
+  f.E = c->d_E;
+  f.mode_re = c->d_mode_re;
+  f.mode_im = c->d_mode_im;
+  f.fre = c->d_fre;
+  f.fim = c->d_fim;
+  f.grad_inv = c->d_ginv;
+  f.history = nullptr;
+  f.nx = nx;
+  f.nmode = nm;
+  f.nspecies = ns;
+  f.deltaf = in->deltaf;
+  f.tab_lds = (static_cast<size_t>(2) * nm * nx * sizeof(double) <= 96 * 1024) ? 1 : 0;
+  f.lx = in->lx;
+  f.dnx = static_cast<double>(nx);
+  f.sc_re = 1.0 / static_cast<double>(nx);    // src/pic1dp_field.F90:239
+  f.sc_im = -1.0 / static_cast<double>(nx);   // :234
+  for (int s = 0; s < ns; ++s) {
+    f.Z[s] = in->species_charge[s];
+    f.n0[s] = in->species_density[s];
+  }
+  HIP_TRY_C(hipStreamSynchronize(c->st));
+#undef HIP_TRY_C
+  *out = c;
+  return 0;
+}
+
+int pic1dp_hip_destroy(pic1dp_ctx *c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  if (c->comm) {
+    rccl().CommDestroy(c->comm);
+    c->comm = nullptr;
+  }
+  for (auto &S : c->sp) {
+    (void)hipFree(S.p);
+    (void)hipFree(S.set[0].x);
+    (void)hipFree(S.set[0].v);
+    (void)hipFree(S.set[0].w);
+    (void)hipFree(S.set[1].x);
+    if (S.set[1].v != S.set[0].v) (void)hipFree(S.set[1].v);
+    if (S.set[1].w != S.set[0].w) (void)hipFree(S.set[1].w);
+  }
+  double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
+                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch};
+  for (double *b : bufs) (void)hipFree(b);
+  for (auto &e : c->evpool) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  if (c->st) (void)hipStreamDestroy(c->st);
+  delete c;
+  return 0;
+}
+
+int pic1dp_hip_local_sizes(pic1dp_ctx *c, int32_t isp, int64_t *nalloc, int64_t *np) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  if (nalloc) *nalloc = c->sp[isp].nalloc;
+  if (np) *np = c->sp[isp].np;
+  return 0;
+}
+
+int pic1dp_hip_particle_load(pic1dp_ctx *c) {
+  CHECK_CTX(c);
+  HIP_TRY(hipSetDevice(c->device));
+  const pic1dp_input &in = c->in;
+  const int npe = c->lay.npe, ns = in.nspecies;
+  const int nthreads = load_threads();
+  int64_t max_alloc = 0;
+  for (int b = 0; b < c->nblk; ++b)
+    max_alloc = std::max<int64_t>(max_alloc, block_alloc(in.nparticle_max, c->blk0 + b, npe));
+  double *stage = nullptr;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&stage), sizeof(double) * 4 * static_cast<size_t>(max_alloc), 0));
+  double *hx = stage, *hv = stage + max_alloc, *hp = stage + 2 * max_alloc, *hw = stage + 3 * max_alloc;
+  std::vector<int64_t> voff(ns, 0), toff(ns);
+  for (int s = 0; s < ns; ++s) toff[s] = c->sp[s].np;
+  int rc = 0;
+  for (int b = 0; b < c->nblk && !rc; ++b) {
+    const int mype = c->blk0 + b;
+    const int64_t n = block_alloc(in.nparticle_max, mype, npe);
+    Multirand g;
+    if ((rc = init_block_rng(in, mype, g)) != 0) break;
+    for (int s = 0; s < ns && !rc; ++s) {
+      Species &S = c->sp[s];
+      load_block_species(in, s, g, n, hx, hv, hp, hw, nthreads);
+      const int64_t np = block_np(in, s, mype, npe), nt = n - np;
+      struct {
+        double *d;
+        const double *h;
+      } arr[4] = {{S.set[0].x, hx}, {S.set[0].v, hv}, {S.p, hp}, {S.set[0].w, hw}};
+      for (auto &a : arr) {
+        hipError_t e = hipMemcpy(a.d + voff[s], a.h, sizeof(double) * np, hipMemcpyHostToDevice);
+        if (e == hipSuccess && nt > 0)
+          e = hipMemcpy(a.d + toff[s], a.h + np, sizeof(double) * nt, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+          rc = fail(PIC1DP_ERR_HIP, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
+          break;
+        }
+      }
+      voff[s] += np;
+      toff[s] += nt;
+    }
+  }
+  (void)hipHostFree(stage);
+  if (rc) return rc;
+  c->cur = 0;
+  c->loaded = true;
+  c->itime = 0;
+  c->time = 0.0;
+  c->hist_count = 0;
+  return 0;
+}
+
+int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, const double *v,
+                                const double *p, const double *w, int64_t n, int64_t np) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  Species &S = c->sp[isp];
+  if (!x || !v || !p || !w) return fail(PIC1DP_ERR_ARG, "null array");
+  if (n != S.nalloc) return fail(PIC1DP_ERR_ARG, "n = %lld but this process owns %lld slots", (long long)n, (long long)S.nalloc);
+  if (np < 0 || np > n) return fail(PIC1DP_ERR_ARG, "np out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  PSet &A = S.set[c->cur];
+  HIP_TRY(hipMemcpy(A.x, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(A.v, v, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(A.w, w, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.p, p, sizeof(double) * n, hipMemcpyHostToDevice));
+  S.np = np;
+  c->loaded = true;
+  return 0;
+}
+
+int pic1dp_hip_particles_download(pic1dp_ctx *c, int32_t isp, double *x, double *v, double *p,
+                                  double *w, int64_t n) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  Species &S = c->sp[isp];
+  if (n != S.nalloc) return fail(PIC1DP_ERR_ARG, "n = %lld but this process owns %lld slots", (long long)n, (long long)S.nalloc);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  const PSet &A = S.set[c->cur];
+  const int64_t np = S.np;
+  // slots beyond np are only defined in the set they were uploaded to (set 0)
+  auto pull = [&](double *h, const double *cur, const double *first) -> hipError_t {
+    if (!h) return hipSuccess;
+    hipError_t e = hipMemcpy(h, cur, sizeof(double) * np, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n > np)
+      e = hipMemcpy(h + np, first + np, sizeof(double) * (n - np), hipMemcpyDeviceToHost);
+    return e;
+  };
+  HIP_TRY(pull(x, A.x, S.set[0].x));
+  HIP_TRY(pull(v, A.v, S.set[0].v));
+  HIP_TRY(pull(w, A.w, S.set[0].w));
+  HIP_TRY(pull(p, S.p, S.p));
+  return 0;
+}
+
+int pic1dp_hip_particles_download_bak(pic1dp_ctx *c, int32_t isp, double *xb, double *vb, double *wb,
+                                      int64_t n) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  Species &S = c->sp[isp];
+  if (n != S.nalloc) return fail(PIC1DP_ERR_ARG, "n does not match the owned slots");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  const PSet &B = S.set[1 - c->cur];
+  if (xb) HIP_TRY(hipMemcpy(xb, B.x, sizeof(double) * S.np, hipMemcpyDeviceToHost));
+  if (vb) HIP_TRY(hipMemcpy(vb, B.v, sizeof(double) * S.np, hipMemcpyDeviceToHost));
+  if (wb) HIP_TRY(hipMemcpy(wb, B.w, sizeof(double) * S.np, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// hot path
+// ---------------------------------------------------------------------------
+static int require_loaded(pic1dp_ctx *c) {
+  if (!c->loaded) return fail(PIC1DP_ERR_STATE, "no particles: call particle_load or particles_upload first");
+  if (c->charge_pending) return fail(PIC1DP_ERR_STATE, "charge_local is waiting for charge_reduced");
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(PIC1DP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
+  CHECK_CTX(c);
+  if (int rc = require_loaded(c)) return rc;
+  Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
+  if (int rc = enqueue_deposit(c)) return rc;
+  const bool multi = c->lay.nranks > 1;
+  if (multi) {
+    HIP_TRY(launch_charge_local(c->fa, c->st));
+    if (int rc = allreduce_charge(c)) return rc;
+  }
+  HIP_TRY(launch_chargeden(c->fa, !multi, c->st));
+  return tm.end();
+}
+
+int pic1dp_hip_solve_field(pic1dp_ctx *c) {
+  CHECK_CTX(c);
+  HIP_TRY(hipSetDevice(c->device));
+  Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
+  FieldArgs f = c->fa;
+  HIP_TRY(launch_field_solve(f, false, true, c->st));
+  return tm.end();
+}
+
+int pic1dp_hip_push(pic1dp_ctx *c, int32_t irk) {
+  CHECK_CTX(c);
+  if (irk != 1 && irk != 2) return fail(PIC1DP_ERR_ARG, "irk must be 1 or 2");
+  if (int rc = require_loaded(c)) return rc;
+  return enqueue_push(c, irk, false);
+}
+
+static int substep_impl(pic1dp_ctx *c, int irk, bool record) {
+  if (int rc = enqueue_push(c, irk, true)) return rc;
+  const bool multi = c->lay.nranks > 1;
+  if (multi) {
+    HIP_TRY(launch_charge_local(c->fa, c->st));
+    if (int rc = allreduce_charge(c)) return rc;
+  }
+  Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
+  FieldArgs f = c->fa;
+  if (record && c->hist_count < kHistCap) f.history = c->d_hist + c->hist_count++;
+  HIP_TRY(launch_field_solve(f, !multi, false, c->st));
+  return tm.end();
+}
+
+int pic1dp_hip_substep(pic1dp_ctx *c, int32_t irk) {
+  CHECK_CTX(c);
+  if (irk != 1 && irk != 2) return fail(PIC1DP_ERR_ARG, "irk must be 1 or 2");
+  if (int rc = require_loaded(c)) return rc;
+  return substep_impl(c, irk, false);
+}
+
+int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
+  CHECK_CTX(c);
+  if (nsteps < 0) return fail(PIC1DP_ERR_ARG, "nsteps < 0");
+  if (int rc = require_loaded(c)) return rc;
+  for (int it = 0; it < nsteps; ++it) {
+    if (int rc = substep_impl(c, 1, false)) return rc;
+    if (int rc = substep_impl(c, 2, true)) return rc;
+    c->itime += 1;                  // src/pic1dp.F90:92
+    c->time = c->time + c->in.dt;   // :93
+  }
+  return 0;
+}
+
+int pic1dp_hip_sync(pic1dp_ctx *c) {
+  CHECK_CTX(c);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+int pic1dp_hip_get_time(pic1dp_ctx *c, int32_t *itime, double *time) {
+  CHECK_CTX(c);
+  if (itime) *itime = c->itime;
+  if (time) *time = c->time;
+  return 0;
+}
+
+int pic1dp_hip_set_time(pic1dp_ctx *c, int32_t itime, double time) {
+  CHECK_CTX(c);
+  c->itime = itime;
+  c->time = time;
+  return 0;
+}
+
+int pic1dp_hip_check_termination(pic1dp_ctx *c, int32_t *flag) {
+  CHECK_CTX(c);
+  if (!flag) return fail(PIC1DP_ERR_ARG, "null flag");
+  *flag = (c->itime >= c->in.ntime_max || c->time + kSqrtEps >= c->in.time_max) ? 1 : 0;
+  return 0;
+}
+
+int pic1dp_hip_output_due(pic1dp_ctx *c, int32_t itermination, int32_t *flag) {
+  CHECK_CTX(c);
+  if (!flag) return fail(PIC1DP_ERR_ARG, "null flag");
+  const double a = std::fmod(c->time + kSqrtEps, c->in.output_interval);
+  const double b = std::fmod(c->time + kSqrtEps - c->in.dt, c->in.output_interval);
+  *flag = (a < b || itermination == 1) ? 1 : 0;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// field access
+// ---------------------------------------------------------------------------
+int pic1dp_hip_get_field(pic1dp_ctx *c, double *E, double *cd, double *re, double *im) {
+  CHECK_CTX(c);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  const size_t nx = c->in.nx, nm = c->in.nmode;
+  if (E) HIP_TRY(hipMemcpy(E, c->d_E, sizeof(double) * nx, hipMemcpyDeviceToHost));
+  if (cd) HIP_TRY(hipMemcpy(cd, c->d_chargeden, sizeof(double) * nx, hipMemcpyDeviceToHost));
+  if (re) HIP_TRY(hipMemcpy(re, c->d_mode_re, sizeof(double) * nm, hipMemcpyDeviceToHost));
+  if (im) HIP_TRY(hipMemcpy(im, c->d_mode_im, sizeof(double) * nm, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pic1dp_hip_set_electric(pic1dp_ctx *c, const double *E) {
+  CHECK_CTX(c);
+  if (!E) return fail(PIC1DP_ERR_ARG, "null array");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  HIP_TRY(hipMemcpy(c->d_E, E, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int pic1dp_hip_set_chargeden(pic1dp_ctx *c, const double *cd) {
+  CHECK_CTX(c);
+  if (!cd) return fail(PIC1DP_ERR_ARG, "null array");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  HIP_TRY(hipMemcpy(c->d_chargeden, cd, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int pic1dp_hip_field_energy(pic1dp_ctx *c, double *energy) {
+  CHECK_CTX(c);
+  if (!energy) return fail(PIC1DP_ERR_ARG, "null output");
+  HIP_TRY(hipSetDevice(c->device));
+  double *slot = c->d_scratch + kEnergyBlocks * 3;
+  HIP_TRY(launch_field_energy(c->d_E, c->in.nx, c->in.lx, static_cast<double>(c->in.nx), slot, c->st));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  HIP_TRY(hipMemcpy(energy, slot, sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pic1dp_hip_energy_history(pic1dp_ctx *c, double *energy, int64_t max, int64_t *count) {
+  CHECK_CTX(c);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  int64_t n = c->hist_count < max ? c->hist_count : max;
+  if (n < 0) n = 0;
+  if (energy && n > 0) HIP_TRY(hipMemcpy(energy, c->d_hist, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (count) *count = c->hist_count;
+  return 0;
+}
+
+int pic1dp_hip_energy_history_reset(pic1dp_ctx *c) {
+  CHECK_CTX(c);
+  c->hist_count = 0;
+  return 0;
+}
+
+int pic1dp_hip_energy_sums(pic1dp_ctx *c, int32_t isp, double out[3]) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies || !out) return fail(PIC1DP_ERR_ARG, "bad argument");
+  if (int rc = require_loaded(c)) return rc;
+  Species &S = c->sp[isp];
+  const PSet &A = S.set[c->cur];
+  // the reference sums the whole local vector (VecSum); slots beyond np live in set 0
+  std::vector<double> part(kEnergyBlocks * 3);
+  out[0] = out[1] = out[2] = 0.0;
+  struct Seg {
+    const double *v, *p, *w;
+    int64_t n;
+  } segs[2] = {{A.v, S.p, c->in.deltaf ? A.w : nullptr, S.np},
+               {S.set[0].v + S.np, S.p + S.np, c->in.deltaf ? S.set[0].w + S.np : nullptr, S.nalloc - S.np}};
+  for (const Seg &g : segs) {
+    if (g.n <= 0) continue;
+    int blocks = static_cast<int>(std::min<int64_t>(kEnergyBlocks, (g.n + 255) / 256));
+    HIP_TRY(launch_energy_sums(g.v, g.p, g.w, g.n, c->d_scratch, blocks, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(part.data(), c->d_scratch, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
+    for (int b = 0; b < blocks; ++b)
+      for (int k = 0; k < 3; ++k) out[k] += part[b * 3 + k];
+  }
+  if (!c->in.deltaf) out[2] = out[1];
+  return 0;
+}
+
+int pic1dp_hip_cell_indices(pic1dp_ctx *c, int32_t isp, int32_t *ix, int64_t *count) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  if (int rc = require_loaded(c)) return rc;
+  Species &S = c->sp[isp];
+  int32_t *d_ix = nullptr;
+  unsigned long long *d_cnt = nullptr;
+  if (ix) HIP_TRY(hipMalloc(&d_ix, sizeof(int32_t) * static_cast<size_t>(S.np + 1)));
+  if (count) {
+    HIP_TRY(hipMalloc(&d_cnt, sizeof(unsigned long long) * c->in.nx));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * c->in.nx, c->st));
+  }
+  hipError_t e = launch_cell_indices(S.set[c->cur].x, S.np, c->grid, d_ix, d_cnt, c->st);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+  if (e == hipSuccess && ix) e = hipMemcpy(ix, d_ix, sizeof(int32_t) * S.np, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && count) e = hipMemcpy(count, d_cnt, sizeof(int64_t) * c->in.nx, hipMemcpyDeviceToHost);
+  (void)hipFree(d_ix);
+  (void)hipFree(d_cnt);
+  HIP_TRY(e);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// split-phase deposit
+// ---------------------------------------------------------------------------
+int pic1dp_hip_charge_local(pic1dp_ctx *c, double *charge2) {
+  CHECK_CTX(c);
+  if (!charge2) return fail(PIC1DP_ERR_ARG, "null array");
+  if (int rc = require_loaded(c)) return rc;
+  if (int rc = enqueue_deposit(c)) return rc;
+  HIP_TRY(launch_charge_local(c->fa, c->st));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  HIP_TRY(hipMemcpy(charge2, c->d_charge, sizeof(double) * c->in.nx, hipMemcpyDeviceToHost));
+  c->charge_pending = true;
+  return 0;
+}
+
+int pic1dp_hip_charge_reduced(pic1dp_ctx *c, const double *charge1) {
+  CHECK_CTX(c);
+  if (!charge1) return fail(PIC1DP_ERR_ARG, "null array");
+  if (!c->charge_pending) return fail(PIC1DP_ERR_STATE, "charge_reduced without charge_local");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(c->d_charge, charge1, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
+  c->charge_pending = false;
+  HIP_TRY(launch_chargeden(c->fa, false, c->st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// RCCL
+// ---------------------------------------------------------------------------
+int pic1dp_hip_comm_unique_id(unsigned char id[PIC1DP_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == PIC1DP_COMM_ID_BYTES, "unique id size");
+  if (!id) return fail(PIC1DP_ERR_ARG, "null id");
+  std::string err;
+  if (!rccl().load(err)) return fail(PIC1DP_ERR_COMM, "%s", err.c_str());
+  ncclUniqueId u;
+  ncclResult_t r = rccl().GetUniqueId(&u);
+  if (r != ncclSuccess) return fail(PIC1DP_ERR_COMM, "ncclGetUniqueId: %s", rccl().GetErrorString(r));
+  std::memcpy(id, u.internal, PIC1DP_COMM_ID_BYTES);
+  return 0;
+}
+
+int pic1dp_hip_comm_init(pic1dp_ctx *c, const unsigned char id[PIC1DP_COMM_ID_BYTES]) {
+  CHECK_CTX(c);
+  if (!id) return fail(PIC1DP_ERR_ARG, "null id");
+  if (c->lay.nranks == 1) return 0;
+  std::string err;
+  if (!rccl().load(err)) return fail(PIC1DP_ERR_COMM, "%s", err.c_str());
+  HIP_TRY(hipSetDevice(c->device));
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, PIC1DP_COMM_ID_BYTES);
+  ncclResult_t r = rccl().CommInitRank(&c->comm, c->lay.nranks, u, c->lay.rank);
+  if (r != ncclSuccess) {
+    c->comm = nullptr;
+    return fail(PIC1DP_ERR_COMM, "ncclCommInitRank: %s", rccl().GetErrorString(r));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// timers and knobs
+// ---------------------------------------------------------------------------
+int pic1dp_hip_timers_enable(pic1dp_ctx *c, int32_t on) {
+  CHECK_CTX(c);
+  c->timers_on = on != 0;
+  return 0;
+}
+
+int pic1dp_hip_timer_ms(pic1dp_ctx *c, int32_t iwt, double *ms) {
+  CHECK_CTX(c);
+  if (iwt < 0 || iwt >= 100 || !ms) return fail(PIC1DP_ERR_ARG, "bad timer id");
+  if (int rc = ev_resolve(c)) return rc;
+  *ms = c->acc_ms[iwt];
+  return 0;
+}
+
+int pic1dp_hip_timers_reset(pic1dp_ctx *c) {
+  CHECK_CTX(c);
+  if (int rc = ev_resolve(c)) return rc;
+  for (int i = 0; i < kNumTags; ++i) {
+    c->acc_ms[i] = 0.0;
+    c->acc_n[i] = 0;
+  }
+  return 0;
+}
+
+int pic1dp_hip_set_launch(pic1dp_ctx *c, int32_t threads, int32_t bpc) {
+  CHECK_CTX(c);
+  if (threads < 0 || threads > 1024 || (threads % 64)) return fail(PIC1DP_ERR_ARG, "threads must be a multiple of 64, <= 1024");
+  if (bpc < 0 || bpc > 32) return fail(PIC1DP_ERR_ARG, "blocks_per_cu out of range");
+  c->threads_req = threads;
+  c->bpc_req = bpc;
+  return 0;
+}
+
+int pic1dp_hip_get_stream(pic1dp_ctx *c, void **stream) {
+  CHECK_CTX(c);
+  if (!stream) return fail(PIC1DP_ERR_ARG, "null output");
+  *stream = reinterpret_cast<void *>(c->st);
+  return 0;
+}
+
+int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
+  CHECK_CTX(c);
+  c->stats_on = on != 0;
+  return 0;
+}
+
+int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
+  CHECK_CTX(c);
+  if (which < 0 || which > 2) return fail(PIC1DP_ERR_ARG, "which must be 0, 1 or 2");
+  if (int rc = ev_resolve(c)) return rc;
+  if (ms) *ms = c->acc_ms[kTagFused + which];
+  if (launches) *launches = c->acc_n[kTagFused + which];
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,569 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the PIC1D
+// time-step hot path.  Compiled with -ffp-contract=off: every product/sum that
+// the reference rounds separately is rounded separately here, so positions,
+// velocities and cell indices are bit-identical to the CPU arithmetic; only
+// exp() (OCML vs libm, <= 1 ulp) and the order of the charge sums differ.
+//
+// Design (DESIGN.md has the numbers):
+//  * All kernels are HBM-bound streaming passes over SoA FP64 particle arrays;
+//    there is no dense contraction, so no MFMA.  Loads/stores are 16 B per lane
+//    (double2), fully coalesced, grid-stride, >= 4 workgroups per CU.
+//  * The field E (nx doubles) is staged once per workgroup into LDS with a
+//    wrap-around guard cell, so the 2-point gather is two ds_read_b64.
+//  * Deposition accumulates into a per-workgroup LDS copy of rho with
+//    ds_add_f64, and is flushed with one global_atomic_add_f64 per cell per
+//    workgroup, start cell staggered by workgroup to spread contention.
+//  * RK2 uses two particle sets (ping-pong): sub-step 1 reads the step-start
+//    set and writes the half-step set; sub-step 2 reads both and overwrites
+//    the step-start set.  The reference's x_bak/v_bak/w_bak copies
+//    (src/pic1dp_interaction.F90:178-189) are never materialised.
+#include "kernels.hpp"
+
+namespace pic1dp {
+
+namespace {
+
+constexpr int MODE_DF_NL = 0;   // deltaf=1, linear=0
+constexpr int MODE_DF_LIN = 1;  // deltaf=1, linear=1
+constexpr int MODE_FULLF = 2;   // deltaf=0, linear=0
+
+__device__ __forceinline__ void lds_add(double *p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void glb_add(double *p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a / c, or a * (1/c) when c is a power of two (bit-identical, cheaper)
+template <bool POW2>
+__device__ __forceinline__ double divc(double a, double c, double rc) {
+  if constexpr (POW2) {
+    return a * rc;
+  } else {
+    return a / c;
+  }
+}
+
+// cell index and left weight of position x (already inside [0, lx]):
+// sx = x/lx*nx; ix = floor(sx); wl = 1 - (sx - ix)
+// src/pic1dp_interaction.F90:106-108 and :250-252
+__device__ __forceinline__ void locate(double x, const GridConst &g, int &ix, double &wl) {
+  const double s = x / g.lx * g.dnx;
+  const double fl = floor(s);
+  ix = static_cast<int>(fl);
+  wl = 1.0 - (s - fl);
+  // memory safety only (x + lx may round to lx; NaN): fold to cell 0
+  if (static_cast<unsigned>(ix) >= static_cast<unsigned>(g.nx)) ix = 0;
+}
+
+// periodic wrap: x = mod(x, lx); if (x < 0) x = x + lx
+// src/pic1dp_interaction.F90:102-104.  fmod is exact; the common cases are
+// resolved without the general routine, with identical results:
+//   0 <= x < lx          -> x
+//   lx <= x < 2 lx       -> x - lx       (exact, Sterbenz)
+//   -lx < x < 0          -> fmod = x, then x + lx (one rounding, as the reference)
+__device__ __forceinline__ double wrap(double x, double lx) {
+  if (x >= 0.0 && x < lx) return x;
+  if (x >= lx && x < 2.0 * lx) return x - lx;
+  if (x < 0.0 && x > -lx) return x + lx;
+  double r = fmod(x, lx);
+  if (r < 0.0) r = r + lx;
+  return r;
+}
+
+// -(d f0/dv)/f0 at v, src/pic1dp_interaction.F90:274-326
+template <int DIST, bool POW2>
+__device__ __forceinline__ double dlnf0(double v, const SpeciesConst &c) {
+  if constexpr (DIST == 1) {  // two-stream1 :276
+    return v - 2.0 / v;
+  } else if constexpr (DIST == 2) {  // two-stream2 :278-292
+    const double vp = v + c.v0, vm = v - c.v0;
+    const double ep = exp(-divc<POW2>(vp * vp, c.two_tm, c.r_two_tm));
+    const double em = exp(-divc<POW2>(vm * vm, c.two_tm, c.r_two_tm));
+    const double q = (vp * ep + vm * em) / (ep + em);
+    return divc<POW2>(q * c.m, c.T, c.r_T);
+  } else if constexpr (DIST == 3) {  // bump-on-tail :294-321
+    const double vm = v - c.v0;
+    const double e1 = exp(-divc<POW2>(v * v, c.two_tm, c.r_two_tm));
+    const double e2 = exp(-divc<POW2>(vm * vm, c.two_tm2, c.r_two_tm2));
+    const double a = divc<POW2>(divc<POW2>(c.den * v, c.tm, c.r_tm) * e1, c.stm, c.r_stm);
+    const double b = divc<POW2>(divc<POW2>(c.beam * vm, c.tm2, c.r_tm2) * e2, c.stm2, c.r_stm2);
+    const double cc = divc<POW2>(c.den * e1, c.stm, c.r_stm);
+    const double d = divc<POW2>(c.beam * e2, c.stm2, c.r_stm2);
+    return (a + b) / (cc + d);
+  } else {  // (shifted) Maxwellian :323-325
+    return divc<POW2>(v - c.v0, c.tm, c.r_tm);
+  }
+}
+
+struct One {
+  double x, v, w;
+};
+
+// gather + push of one marker, src/pic1dp_interaction.F90:246-338
+template <int DIST, int MODE, bool POW2>
+__device__ __forceinline__ One push_one(double x, double v, double w, double p, double xb,
+                                        double vb, double wb, const double *sE,
+                                        const PushArgs &a) {
+  int ix;
+  double wl;
+  locate(x, a.g, ix, wl);
+  double e = sE[ix] * wl;                // :254
+  e = e + sE[ix + 1] * (1.0 - wl);       // :257 (sE[nx] holds E[0])
+  One o;
+  o.x = xb + a.dt * v;                   // :261
+  o.w = w;
+  if constexpr (MODE != MODE_FULLF) {
+    const double tmp1 = (MODE == MODE_DF_LIN) ? p * e : (p - w) * e;   // :268-272
+    const double tmp2 = dlnf0<DIST, POW2>(v, a.s);
+    o.w = wb + divc<POW2>(a.dt * tmp1 * tmp2 * a.s.Z, a.s.m, a.s.r_m);  // :329
+  }
+  if constexpr (MODE == MODE_DF_LIN) {
+    o.v = v;
+  } else {
+    o.v = vb + divc<POW2>(a.dt * e * a.s.Z, a.s.m, a.s.r_m);  // :336
+  }
+  return o;
+}
+
+// wrap + linear deposit of one marker into the LDS copy of rho,
+// src/pic1dp_interaction.F90:102-113; returns the wrapped position
+__device__ __forceinline__ double deposit_one(double x, double q, double *sR, const GridConst &g) {
+  const double px = wrap(x, g.lx);
+  int ix;
+  double wl;
+  locate(px, g, ix, wl);
+  lds_add(&sR[ix], wl * q);              // :110
+  ix = ix + 1;
+  if (ix > g.nx - 1) ix = 0;
+  lds_add(&sR[ix], (1.0 - wl) * q);      // :113
+  return px;
+}
+
+__device__ __forceinline__ void flush_rho(const double *sR, double *rho, int nx) {
+  // one global atomic per cell per workgroup; start cell rotated by workgroup
+  const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    int j = i + rot;
+    if (j >= nx) j -= nx;
+    const double val = sR[j];
+    if (val != 0.0) glb_add(&rho[j], val);
+  }
+}
+
+template <int DIST, int MODE, bool POW2, bool IRK2, bool FUSED>
+__global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sE = reinterpret_cast<double *>(smem);
+  const int nx = a.g.nx;
+  double *sR = sE + ((nx + 2) & ~1);
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    sE[i] = a.E[i];
+    if constexpr (FUSED) sR[i] = 0.0;
+  }
+  if (threadIdx.x == 0) sE[nx] = a.E[0];
+  __syncthreads();
+
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
+  const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const double2 *sx2 = reinterpret_cast<const double2 *>(a.src.x);
+  const double2 *sv2 = reinterpret_cast<const double2 *>(a.src.v);
+  const double2 *sw2 = reinterpret_cast<const double2 *>(a.src.w);
+  const double2 *bx2 = reinterpret_cast<const double2 *>(a.base.x);
+  const double2 *bv2 = reinterpret_cast<const double2 *>(a.base.v);
+  const double2 *bw2 = reinterpret_cast<const double2 *>(a.base.w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+  double2 *dx2 = reinterpret_cast<double2 *>(a.dst.x);
+  double2 *dv2 = reinterpret_cast<double2 *>(a.dst.v);
+  double2 *dw2 = reinterpret_cast<double2 *>(a.dst.w);
+
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair;
+       j += stride) {
+    const double2 X = sx2[j], V = sv2[j];
+    double2 W = make_double2(0.0, 0.0), P = make_double2(0.0, 0.0);
+    if constexpr (HAS_W) W = sw2[j];
+    if constexpr (MODE != MODE_FULLF || FUSED) P = p2[j];
+    double2 XB = X, VB = V, WB = W;
+    if constexpr (IRK2) {
+      XB = bx2[j];
+      if constexpr (PUSH_V) VB = bv2[j];
+      if constexpr (HAS_W) WB = bw2[j];
+    }
+    One o0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, XB.x, VB.x, WB.x, sE, a);
+    One o1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, XB.y, VB.y, WB.y, sE, a);
+    if constexpr (FUSED) {
+      o0.x = deposit_one(o0.x, HAS_W ? o0.w : P.x, sR, a.g);
+      o1.x = deposit_one(o1.x, HAS_W ? o1.w : P.y, sR, a.g);
+    }
+    dx2[j] = make_double2(o0.x, o1.x);
+    if constexpr (PUSH_V) dv2[j] = make_double2(o0.v, o1.v);
+    if constexpr (HAS_W) dw2[j] = make_double2(o0.w, o1.w);
+  }
+  // odd tail marker
+  if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = a.np - 1;
+    const double x = a.src.x[i], v = a.src.v[i];
+    const double w = HAS_W ? a.src.w[i] : 0.0;
+    const double p = a.p[i];
+    double xb = x, vb = v, wb = w;
+    if constexpr (IRK2) {
+      xb = a.base.x[i];
+      if constexpr (PUSH_V) vb = a.base.v[i];
+      if constexpr (HAS_W) wb = a.base.w[i];
+    }
+    One o = push_one<DIST, MODE, POW2>(x, v, w, p, xb, vb, wb, sE, a);
+    if constexpr (FUSED) o.x = deposit_one(o.x, HAS_W ? o.w : p, sR, a.g);
+    a.dst.x[i] = o.x;
+    if constexpr (PUSH_V) a.dst.v[i] = o.v;
+    if constexpr (HAS_W) a.dst.w[i] = o.w;
+  }
+  if constexpr (FUSED) {
+    __syncthreads();
+    flush_rho(sR, a.rho, nx);
+  }
+}
+
+// stand-alone wrap + deposit (interaction_collect_charge loop :96-114)
+__global__ void __launch_bounds__(1024)
+k_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sR = reinterpret_cast<double *>(smem);
+  for (int i = threadIdx.x; i < g.nx; i += blockDim.x) sR[i] = 0.0;
+  __syncthreads();
+  const int64_t npair = np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double2 *x2 = reinterpret_cast<double2 *>(x);
+  const double2 *q2 = reinterpret_cast<const double2 *>(q);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair;
+       j += stride) {
+    double2 X = x2[j];
+    const double2 Q = q2[j];
+    X.x = deposit_one(X.x, Q.x, sR, g);
+    X.y = deposit_one(X.y, Q.y, sR, g);
+    x2[j] = X;
+  }
+  if ((np & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+    x[np - 1] = deposit_one(x[np - 1], q[np - 1], sR, g);
+  __syncthreads();
+  flush_rho(sR, rho, g.nx);
+}
+
+template <int DIST, int MODE, bool POW2, bool IRK2, bool FUSED>
+hipError_t launch_push_t(const PushArgs &a, const LaunchCfg &lc, hipStream_t st) {
+  auto kern = k_push<DIST, MODE, POW2, IRK2, FUSED>;
+  static bool big_lds_ok = false;  // opt in once to > 64 KiB of dynamic LDS (nx >= 4096)
+  if (lc.lds > 64 * 1024 && !big_lds_ok) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    big_lds_ok = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(lc.blocks), dim3(lc.threads), lc.lds, st, a);
+  return hipGetLastError();
+}
+
+template <int DIST, int MODE, bool POW2>
+hipError_t launch_push_dm(const PushArgs &a, bool fused, const LaunchCfg &lc, hipStream_t st) {
+  const bool irk2 = a.irk == 2;
+  if (irk2) {
+    return fused ? launch_push_t<DIST, MODE, POW2, true, true>(a, lc, st)
+                 : launch_push_t<DIST, MODE, POW2, true, false>(a, lc, st);
+  }
+  return fused ? launch_push_t<DIST, MODE, POW2, false, true>(a, lc, st)
+               : launch_push_t<DIST, MODE, POW2, false, false>(a, lc, st);
+}
+
+template <int DIST>
+hipError_t launch_push_d(const PushArgs &a, bool fused, const LaunchCfg &lc, hipStream_t st) {
+  const int mode = a.deltaf ? (a.linear ? MODE_DF_LIN : MODE_DF_NL) : MODE_FULLF;
+  const bool pow2 = a.s.pow2 != 0;
+  switch (mode) {
+    case MODE_DF_NL:
+      return pow2 ? launch_push_dm<DIST, MODE_DF_NL, true>(a, fused, lc, st)
+                  : launch_push_dm<DIST, MODE_DF_NL, false>(a, fused, lc, st);
+    case MODE_DF_LIN:
+      return pow2 ? launch_push_dm<DIST, MODE_DF_LIN, true>(a, fused, lc, st)
+                  : launch_push_dm<DIST, MODE_DF_LIN, false>(a, fused, lc, st);
+    default:
+      // full-f evaluates no f0 derivative: one instantiation serves all DIST
+      return launch_push_dm<0, MODE_FULLF, true>(a, fused, lc, st);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_push(const PushArgs &a, bool fused_deposit, const LaunchCfg &lc,
+                       hipStream_t st) {
+  switch (a.iptcldist) {
+    case 1: return launch_push_d<1>(a, fused_deposit, lc, st);
+    case 2: return launch_push_d<2>(a, fused_deposit, lc, st);
+    case 3: return launch_push_d<3>(a, fused_deposit, lc, st);
+    default: return launch_push_d<0>(a, fused_deposit, lc, st);
+  }
+}
+
+hipError_t launch_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst &g,
+                          const LaunchCfg &lc, hipStream_t st) {
+  static bool big_lds_ok = false;
+  if (lc.lds > 64 * 1024 && !big_lds_ok) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_deposit),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    big_lds_ok = true;
+  }
+  hipLaunchKernelGGL(k_deposit, dim3(lc.blocks), dim3(lc.threads), lc.lds, st, x, q, rho, np, g);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// field kernels (nx <= a few thousand: one workgroup, latency-bound, tiny)
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int FIELD_THREADS = 256;
+
+// charge2(:) = charge2(:) + charge1(:)*Z over species, from 0
+// (src/pic1dp_interaction.F90:81,126-127); accumulators are re-zeroed
+__device__ __forceinline__ void charge_local_body(const FieldArgs &f) {
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) {
+    double c2 = 0.0;
+    for (int s = 0; s < f.nspecies; ++s) {
+      double *r = f.rho_sp + static_cast<size_t>(s) * f.nx + ix;
+      c2 = c2 + *r * f.Z[s];
+      *r = 0.0;
+    }
+    f.charge[ix] = c2;
+  }
+}
+
+__global__ void __launch_bounds__(FIELD_THREADS) k_charge_local(const FieldArgs f) {
+  charge_local_body(f);
+}
+
+// chargeden = charge1*nx/lx (- Z*n0 per species for full-f)
+// src/pic1dp_interaction.F90:138-148
+__device__ __forceinline__ double chargeden_of(const FieldArgs &f, int ix) {
+  double cd = f.charge[ix] * f.dnx / f.lx;
+  if (!f.deltaf)
+    for (int s = 0; s < f.nspecies; ++s) cd = cd - f.Z[s] * f.n0[s];
+  return cd;
+}
+
+template <bool WITH_LOCAL>
+__global__ void __launch_bounds__(FIELD_THREADS) k_chargeden(const FieldArgs f) {
+  if constexpr (WITH_LOCAL) {
+    charge_local_body(f);
+    __syncthreads();
+  }
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) f.chargeden[ix] = chargeden_of(f, ix);
+}
+
+// sum of squares reduced over the workgroup (tree order)
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (blockDim.x >> 6); ++w) t += scratch[w];
+  return t;  // valid on thread 0
+}
+
+// field_solve_electric, src/pic1dp_field.F90:231-257, with the one-rank PETSc
+// summation order: forward sums run over ascending ix in ONE thread per
+// (mode, re/im) so the result is bit-identical to the sequential CPU loop.
+template <bool WITH_LOCAL, bool FROM_CD>
+__global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sCD = reinterpret_cast<double *>(smem);       // [nx]
+  double *sMode = sCD + f.nx;                           // [2*nmode]: re then im
+  double *sScr = sMode + 2 * f.nmode;                   // [16]
+  double *sTab = sScr + 16;                             // [2][nmode][nx] when tab_lds
+  const int nx = f.nx, nm = f.nmode;
+  if (f.tab_lds) {  // stage the cos / -sin tables (coalesced) for the serial sums
+    const int n = nm * nx;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      sTab[i] = f.fre[i];
+      sTab[n + i] = f.fim[i];
+    }
+  }
+
+  if constexpr (WITH_LOCAL) {
+    charge_local_body(f);
+    __syncthreads();
+  }
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+    double cd;
+    if constexpr (FROM_CD) {
+      cd = f.chargeden[ix];
+    } else {
+      cd = chargeden_of(f, ix);
+      f.chargeden[ix] = cd;
+    }
+    sCD[ix] = cd;
+  }
+  __syncthreads();
+
+  // forward partial DFT: thread t -> mode t>>1, (t&1 ? cos-table : -sin-table)
+  if (threadIdx.x < 2 * nm) {
+    const int m = threadIdx.x >> 1;
+    const bool use_cos = threadIdx.x & 1;
+    const double *tab = f.tab_lds
+                            ? sTab + (use_cos ? 0 : nm * nx) + m * nx
+                            : (use_cos ? f.fre : f.fim) + static_cast<size_t>(m) * nx;
+    double acc = 0.0;
+    int ix = 0;
+    for (; ix + 8 <= nx; ix += 8) {
+      double t[8], r[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        t[k] = tab[ix + k];
+        r[k] = sCD[ix + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = acc + t[k] * r[k];
+    }
+    for (; ix < nx; ++ix) acc = acc + tab[ix] * sCD[ix];
+    // :234/:239 VecScale by -1/nx resp. 1/nx, then :243-247 times 1/k
+    if (use_cos) {
+      const double im = acc * f.sc_im * f.grad_inv[m];
+      sMode[nm + m] = im;
+      f.mode_im[m] = im;
+    } else {
+      const double re = acc * f.sc_re * f.grad_inv[m];
+      sMode[m] = re;
+      f.mode_re[m] = re;
+    }
+  }
+  __syncthreads();
+
+  // inverse: E = 2*(Fre*mode_re + Fim*mode_im), ascending mode order :251-256
+  double e2 = 0.0;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+    double s = 0.0;
+    for (int m = 0; m < nm; ++m) s = s + f.fre[static_cast<size_t>(m) * nx + ix] * sMode[m];
+    for (int m = 0; m < nm; ++m) s = s + f.fim[static_cast<size_t>(m) * nx + ix] * sMode[nm + m];
+    const double e = s * 2.0;
+    f.E[ix] = e;
+    e2 += e * e;
+  }
+  if (f.history) {  // int E^2 dx, src/pic1dp_output.F90:120-124
+    const double tot = block_sum(e2, sScr);
+    if (threadIdx.x == 0) {
+      const double nrm = sqrt(tot);
+      *f.history = nrm * nrm * f.lx / f.dnx;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(FIELD_THREADS)
+k_field_energy(const double *E, int nx, double lx, double dnx, double *out) {
+  __shared__ double scr[16];
+  double e2 = 0.0;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) e2 += E[ix] * E[ix];
+  const double tot = block_sum(e2, scr);
+  if (threadIdx.x == 0) {
+    const double nrm = sqrt(tot);
+    *out = nrm * nrm * lx / dnx;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_charge_local(const FieldArgs &f, hipStream_t st) {
+  hipLaunchKernelGGL(k_charge_local, dim3(1), dim3(FIELD_THREADS), 0, st, f);
+  return hipGetLastError();
+}
+
+hipError_t launch_chargeden(const FieldArgs &f, bool with_local, hipStream_t st) {
+  if (with_local) {
+    hipLaunchKernelGGL(k_chargeden<true>, dim3(1), dim3(FIELD_THREADS), 0, st, f);
+  } else {
+    hipLaunchKernelGGL(k_chargeden<false>, dim3(1), dim3(FIELD_THREADS), 0, st, f);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_field_solve(const FieldArgs &f, bool with_local, bool from_chargeden,
+                              hipStream_t st) {
+  const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
+                                       (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
+  if (from_chargeden) {
+    hipLaunchKernelGGL((k_field_solve<false, true>), dim3(1), dim3(FIELD_THREADS), lds, st, f);
+  } else if (with_local) {
+    hipLaunchKernelGGL((k_field_solve<true, false>), dim3(1), dim3(FIELD_THREADS), lds, st, f);
+  } else {
+    hipLaunchKernelGGL((k_field_solve<false, false>), dim3(1), dim3(FIELD_THREADS), lds, st, f);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_field_energy(const double *E, int nx, double lx, double dnx, double *out,
+                               hipStream_t st) {
+  hipLaunchKernelGGL(k_field_energy, dim3(1), dim3(FIELD_THREADS), 0, st, E, nx, lx, dnx, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// diagnostics
+// ---------------------------------------------------------------------------
+namespace {
+
+// sum v^2, v^2 p, v^2 w (src/pic1dp_output.F90:126-151): per-workgroup partials,
+// the host adds them in workgroup order
+__global__ void __launch_bounds__(256)
+k_energy_sums(const double *v, const double *p, const double *w, int64_t n, double *partial) {
+  __shared__ double scr[16];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double v2 = v[i] * v[i];
+    s0 += v2;
+    s1 += v2 * p[i];
+    if (w) s2 += v2 * w[i];
+  }
+  const double t0 = block_sum(s0, scr);
+  const double t1 = block_sum(s1, scr);
+  const double t2 = block_sum(s2, scr);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 3 + 0] = t0;
+    partial[blockIdx.x * 3 + 1] = t1;
+    partial[blockIdx.x * 3 + 2] = t2;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_cell_indices(const double *x, int64_t np, const GridConst g, int32_t *ixo,
+               unsigned long long *count) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < np; i += stride) {
+    int ix;
+    double wl;
+    locate(x[i], g, ix, wl);
+    if (ixo) ixo[i] = ix;
+    if (count) atomicAdd(&count[ix], 1ULL);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t n,
+                              double *partial, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(k_energy_sums, dim3(blocks), dim3(256), 0, st, v, p, w, n, partial);
+  return hipGetLastError();
+}
+
+hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
+                               unsigned long long *count, hipStream_t st) {
+  int blocks = static_cast<int>((np + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_cell_indices, dim3(blocks), dim3(256), 0, st, x, np, g, ix, count);
+  return hipGetLastError();
+}
+
+}  // namespace pic1dp

@@ -1,0 +1,94 @@
+// kernels.hpp -- launch interface of the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pic1dp {
+
+// Constants of one species' push, pre-formed on the host exactly as the
+// reference's compile-time folding would form them (src/pic1dp_input.F90
+// parameters; expressions at src/pic1dp_interaction.F90:274-337).
+struct SpeciesConst {
+  double Z, m;          // charge, mass
+  double den, beam;     // density, 1 - density
+  double v0, T;
+  double tm, tm2;       // T/m, T2/m
+  double two_tm, two_tm2;  // 2*T/m, 2*T2/m
+  double stm, stm2;     // sqrt(T/m), sqrt(T2/m)
+  // reciprocals, used only when every divisor is a power of two (exact)
+  double r_m, r_T, r_tm, r_tm2, r_two_tm, r_two_tm2, r_stm, r_stm2;
+  int pow2;             // 1: all divisors above are powers of two
+};
+
+struct GridConst {
+  double lx, dnx, dt_full;
+  int nx;
+};
+
+// One particle set = the three pushed arrays of a species.
+struct PSet {
+  double *x, *v, *w;
+};
+
+struct PushArgs {
+  PSet src;       // state the derivatives are evaluated at (particle_x/v/w)
+  PSet base;      // RK base (particle_*_bak); == src for irk 1
+  PSet dst;       // where the pushed state goes
+  const double *p;
+  const double *E;  // [nx] field_electric
+  double *rho;      // [nx] this species' charge accumulator (fused deposit)
+  int64_t np;
+  double dt;        // 0.5*dt (irk 1) or dt (irk 2)
+  GridConst g;
+  SpeciesConst s;
+  int iptcldist, deltaf, linear, irk;
+};
+
+struct LaunchCfg {
+  int threads;   // per workgroup
+  int blocks;    // grid size
+  size_t lds;    // dynamic LDS bytes
+};
+
+// push (+gather) with or without the fused wrap+deposit
+hipError_t launch_push(const PushArgs &a, bool fused_deposit, const LaunchCfg &lc, hipStream_t st);
+// wrap + deposit of q (= w or p) at x, x stored back
+hipError_t launch_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst &g,
+                          const LaunchCfg &lc, hipStream_t st);
+
+struct FieldArgs {
+  double *rho_sp;        // [nspecies][nx] raw per-species deposits (zeroed after use)
+  double *charge;        // [nx] charge2 / charge1 (local sum, all-reduced in place)
+  double *chargeden;     // [nx]
+  double *E;             // [nx]
+  double *mode_re, *mode_im;   // [nmode]
+  const double *fre, *fim;     // [nmode][nx] cos / -sin tables
+  const double *grad_inv;      // [nmode]
+  double *history;       // energy slot to write, or nullptr
+  int nx, nmode, nspecies, deltaf;
+  int tab_lds;           // 1: stage the tables in LDS (they fit)
+  double lx, dnx, sc_re, sc_im;
+  double Z[8], n0[8];
+};
+
+// charge2 = sum_s rho_sp[s]*Z_s ; rho_sp = 0      (src/pic1dp_interaction.F90:81-128)
+hipError_t launch_charge_local(const FieldArgs &f, hipStream_t st);
+// chargeden from charge (:138-148) only; with_local folds launch_charge_local in
+hipError_t launch_chargeden(const FieldArgs &f, bool with_local, hipStream_t st);
+// chargeden from charge (:138-148) then field_solve_electric; with_local runs
+// launch_charge_local's work first in the same kernel (single-rank path)
+hipError_t launch_field_solve(const FieldArgs &f, bool with_local, bool from_chargeden,
+                              hipStream_t st);
+// int E^2 dx into *out (device)
+hipError_t launch_field_energy(const double *E, int nx, double lx, double dnx, double *out,
+                               hipStream_t st);
+
+// per-block partial sums of v^2, v^2 p, v^2 w -> partial[blocks][3]
+hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t n,
+                              double *partial, int blocks, hipStream_t st);
+// cell index per marker and per-cell counts from (wrapped) x
+hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
+                               unsigned long long *count, hipStream_t st);
+
+}  // namespace pic1dp

@@ -1,0 +1,286 @@
+"""Host-side mirror of the reference's module procedures for the time-step hot
+path, on top of the C ABI (include/pic1dp_hip.h).
+
+Method names are the reference's procedure names so that a parity test reads
+like the reference driver (src/pic1dp.F90:64-109):
+
+    sim = Pic1dp(make_input(nparticle_max=10**7, nx=256))
+    sim.particle_load()
+    sim.interaction_collect_charge(); sim.field_solve_electric()
+    for irk in (1, 2):
+        sim.interaction_push_particle(irk)
+        sim.interaction_collect_charge(); sim.field_solve_electric()
+
+All compute runs in hand-written HIP kernels on one MI355X; nothing here
+computes, and there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Input, Layout, Pic1dpError, check  # noqa: F401
+
+
+def make_input(**kw):
+    """pic1dp_input with the reference's default input file
+    (src/pic1dp_input.F90) except multirand_seed_type=1; keyword names are the
+    reference names without the input_ prefix.  Array-valued parameters take
+    sequences."""
+    L = _lib.load()
+    inp = Input()
+    check(L.pic1dp_hip_input_defaults(C.byref(inp)))
+    names = {n for n, _ in Input._fields_}
+    explicit_init = "species_nparticle_init" in kw
+    for k, val in kw.items():
+        if k not in names or k == "abi_version":
+            raise KeyError("unknown input parameter %r" % k)
+        cur = getattr(inp, k)
+        if hasattr(cur, "__len__"):
+            if len(val) > len(cur):
+                raise ValueError("%s: at most %d entries" % (k, len(cur)))
+            for i, x in enumerate(val):
+                cur[i] = x
+        else:
+            setattr(inp, k, val)
+    if not explicit_init:
+        # input_species_nparticle_init = input_nparticle_max (src/pic1dp_input.F90:117)
+        for s in range(inp.nspecies):
+            inp.species_nparticle_init[s] = inp.nparticle_max
+    return inp
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Pic1dp:
+    """one process = one GPU = one context"""
+
+    def __init__(self, inp, rank=0, nranks=1, npe=0, device=-1):
+        self.L = _lib.load()
+        self.inp = inp
+        self.rank, self.nranks = rank, nranks
+        self.npe = npe or nranks
+        self._ctx = C.c_void_p()
+        lay = Layout(rank, nranks, self.npe, device)
+        check(self.L.pic1dp_hip_create(C.byref(inp), C.byref(lay), C.byref(self._ctx)))
+
+    # -- life cycle (particle_final / field_final) ---------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.L.pic1dp_hip_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- sizes -----------------------------------------------------------------
+    def local_sizes(self, ispecies=0):
+        na, npv = C.c_int64(), C.c_int64()
+        check(self.L.pic1dp_hip_local_sizes(self._ctx, ispecies, C.byref(na), C.byref(npv)))
+        return na.value, npv.value
+
+    # -- particle_load (src/pic1dp_particle.F90:145-269) -----------------------
+    def particle_load(self):
+        check(self.L.pic1dp_hip_particle_load(self._ctx))
+
+    def particles_upload(self, x, v, p, w, ispecies=0, np_valid=None):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, v, p, w)]
+        n = arrs[0].size
+        if any(a.size != n for a in arrs):
+            raise ValueError("x, v, p, w must have one length")
+        check(self.L.pic1dp_hip_particles_upload(
+            self._ctx, ispecies, *[_ptr(a) for a in arrs], n, n if np_valid is None else np_valid))
+
+    def particles_download(self, ispecies=0):
+        n, _ = self.local_sizes(ispecies)
+        out = [np.empty(n) for _ in range(4)]
+        check(self.L.pic1dp_hip_particles_download(self._ctx, ispecies, *[_ptr(a) for a in out], n))
+        return dict(zip("xvpw", out))
+
+    def particles_download_bak(self, ispecies=0):
+        n, npv = self.local_sizes(ispecies)
+        out = [np.zeros(n) for _ in range(3)]
+        check(self.L.pic1dp_hip_particles_download_bak(self._ctx, ispecies, *[_ptr(a) for a in out], n))
+        return dict(zip(("xb", "vb", "wb"), [a[:npv] for a in out]))
+
+    # -- the hot path, under the reference's names -----------------------------
+    def interaction_collect_charge(self):
+        check(self.L.pic1dp_hip_collect_charge(self._ctx))
+
+    def field_solve_electric(self):
+        check(self.L.pic1dp_hip_solve_field(self._ctx))
+
+    def interaction_push_particle(self, irk):
+        check(self.L.pic1dp_hip_push(self._ctx, irk))
+
+    def substep(self, irk):
+        """push(irk) + collect_charge + solve_field, push and deposit fused"""
+        check(self.L.pic1dp_hip_substep(self._ctx, irk))
+
+    def step(self, nsteps=1):
+        check(self.L.pic1dp_hip_step(self._ctx, nsteps))
+
+    def sync(self):
+        check(self.L.pic1dp_hip_sync(self._ctx))
+
+    # -- driver scalars (global_itime, global_time) -----------------------------
+    @property
+    def itime(self):
+        it, t = C.c_int32(), C.c_double()
+        check(self.L.pic1dp_hip_get_time(self._ctx, C.byref(it), C.byref(t)))
+        return it.value
+
+    @property
+    def time(self):
+        it, t = C.c_int32(), C.c_double()
+        check(self.L.pic1dp_hip_get_time(self._ctx, C.byref(it), C.byref(t)))
+        return t.value
+
+    def set_time(self, itime, time):
+        check(self.L.pic1dp_hip_set_time(self._ctx, itime, time))
+
+    def check_termination(self):
+        f = C.c_int32()
+        check(self.L.pic1dp_hip_check_termination(self._ctx, C.byref(f)))
+        return f.value
+
+    def output_due(self, itermination=0):
+        f = C.c_int32()
+        check(self.L.pic1dp_hip_output_due(self._ctx, itermination, C.byref(f)))
+        return f.value
+
+    # -- field access -------------------------------------------------------------
+    def get_field(self):
+        nx, nm = self.inp.nx, self.inp.nmode
+        E, cd, re, im = np.empty(nx), np.empty(nx), np.empty(nm), np.empty(nm)
+        check(self.L.pic1dp_hip_get_field(self._ctx, _ptr(E), _ptr(cd), _ptr(re), _ptr(im)))
+        return dict(electric=E, chargeden=cd, mode_re=re, mode_im=im)
+
+    def set_electric(self, E):
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        if E.size != self.inp.nx:
+            raise ValueError("E must have nx entries")
+        check(self.L.pic1dp_hip_set_electric(self._ctx, _ptr(E)))
+
+    def set_chargeden(self, cd):
+        cd = np.ascontiguousarray(cd, dtype=np.float64)
+        if cd.size != self.inp.nx:
+            raise ValueError("chargeden must have nx entries")
+        check(self.L.pic1dp_hip_set_chargeden(self._ctx, _ptr(cd)))
+
+    def field_energy(self):
+        e = C.c_double()
+        check(self.L.pic1dp_hip_field_energy(self._ctx, C.byref(e)))
+        return e.value
+
+    def energy_history(self):
+        cnt = C.c_int64()
+        check(self.L.pic1dp_hip_energy_history(self._ctx, None, 0, C.byref(cnt)))
+        out = np.empty(cnt.value)
+        if cnt.value:
+            check(self.L.pic1dp_hip_energy_history(self._ctx, _ptr(out), cnt.value, C.byref(cnt)))
+        return out
+
+    def energy_history_reset(self):
+        check(self.L.pic1dp_hip_energy_history_reset(self._ctx))
+
+    def energy_sums(self, ispecies=0):
+        out = np.empty(3)
+        check(self.L.pic1dp_hip_energy_sums(self._ctx, ispecies, _ptr(out)))
+        return out
+
+    def cell_indices(self, ispecies=0):
+        _, npv = self.local_sizes(ispecies)
+        ix = np.empty(npv, dtype=np.int32)
+        cnt = np.empty(self.inp.nx, dtype=np.int64)
+        check(self.L.pic1dp_hip_cell_indices(self._ctx, ispecies, _ptr(ix), _ptr(cnt)))
+        return ix, cnt
+
+    # -- split-phase deposit -------------------------------------------------------
+    def charge_local(self):
+        out = np.empty(self.inp.nx)
+        check(self.L.pic1dp_hip_charge_local(self._ctx, _ptr(out)))
+        return out
+
+    def charge_reduced(self, charge1):
+        a = np.ascontiguousarray(charge1, dtype=np.float64)
+        if a.size != self.inp.nx:
+            raise ValueError("charge must have nx entries")
+        check(self.L.pic1dp_hip_charge_reduced(self._ctx, _ptr(a)))
+
+    # -- RCCL ------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+        check(self.L.pic1dp_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, uid):
+        if len(uid) != _lib.COMM_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % _lib.COMM_ID_BYTES)
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(uid)
+        check(self.L.pic1dp_hip_comm_init(self._ctx, buf))
+
+    # -- timers / knobs -----------------------------------------------------------------
+    def timers_enable(self, on=True):
+        check(self.L.pic1dp_hip_timers_enable(self._ctx, int(on)))
+
+    def timer_ms(self, iwt):
+        ms = C.c_double()
+        check(self.L.pic1dp_hip_timer_ms(self._ctx, iwt, C.byref(ms)))
+        return ms.value
+
+    def timers_reset(self):
+        check(self.L.pic1dp_hip_timers_reset(self._ctx))
+
+    def set_launch(self, threads=0, blocks_per_cu=0):
+        check(self.L.pic1dp_hip_set_launch(self._ctx, threads, blocks_per_cu))
+
+    def kernel_stats_enable(self, on=True):
+        check(self.L.pic1dp_hip_kernel_stats_enable(self._ctx, int(on)))
+
+    def kernel_stats(self, which=0):
+        ms, n = C.c_double(), C.c_int64()
+        check(self.L.pic1dp_hip_kernel_stats(self._ctx, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- the reference driver, src/pic1dp.F90:64-109 ---------------------------------------
+    def run(self, on_output=None, max_steps=None, fused=True):
+        """particle_load must have been called.  Runs the initial deposit+solve
+        and the RK2 time loop until check_termination, calling
+        on_output(self) at step 0 and whenever the reference would call
+        output_all.  Returns the number of steps taken."""
+        self.interaction_collect_charge()
+        self.field_solve_electric()
+        if on_output:
+            on_output(self)
+        steps = 0
+        term = self.check_termination()
+        while term == 0 and (max_steps is None or steps < max_steps):
+            if fused:
+                self.step(1)
+            else:
+                for irk in (1, 2):
+                    self.interaction_push_particle(irk)
+                    self.interaction_collect_charge()
+                    self.field_solve_electric()
+                self.set_time(self.itime + 1, self.time + self.inp.dt)
+            steps += 1
+            term = self.check_termination()
+            if on_output and self.output_due(term):
+                on_output(self)
+        return steps
+
+
+def device_count():
+    return _lib.load().pic1dp_hip_device_count()

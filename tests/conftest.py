@@ -1,0 +1,44 @@
+"""pytest configuration: the `gpu` marker, import paths and shared helpers."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    """the CPU oracle (test infrastructure); built on demand with gcc"""
+    import oracle
+    oracle.build()
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def amd():
+    """the product package; importing it loads libpic1dp_hip.so or fails loudly"""
+    import pic1dp_amd
+    return pic1dp_amd
+
+
+# input keyword sets shared by CPU and GPU tests: (id, kwargs)
+DIST_CASES = [
+    ("bump_on_tail", dict()),
+    ("maxwellian", dict(iptcldist=0, species_density=[1.0], species_v0=[0.0])),
+    ("two_stream1", dict(iptcldist=1, species_density=[1.0])),
+    ("two_stream2", dict(iptcldist=2, species_density=[1.0], species_v0=[3.0])),
+    ("bump_nonpow2", dict(iptcldist=3, species_temperature=[1.3], species_temperature2=[0.7],
+                          species_mass=[1.1], species_density=[0.85], species_v0=[4.5])),
+    ("two_stream2_nonpow2", dict(iptcldist=2, species_density=[1.0], species_v0=[3.0],
+                                 species_temperature=[0.9], species_mass=[1.2])),
+    ("maxwellian_nonpow2", dict(iptcldist=0, species_density=[1.0], species_v0=[0.3],
+                                species_temperature=[1.7], species_mass=[0.9])),
+]
