@@ -44,7 +44,9 @@ def assert_w_close(w_gpu, w_orc, wb_orc, exact):
         return
     scale = np.abs(w_orc) + np.abs(wb_orc)
     err = np.abs(w_gpu - w_orc)
-    bad = err > 16 * EPS * scale + 1e-300
+    # exp() differs by <= 1 ulp (OCML vs libm) and the bump-on-tail / two-stream
+    # numerators cancel partially, so allow a few hundred ulp of the update scale
+    bad = err > 512 * EPS * scale + 1e-300
     assert not bad.any(), "w off by %g (scale %g) at %d" % (
         err[bad].max(), scale[bad][np.argmax(err[bad])], np.flatnonzero(bad)[0])
 
@@ -256,15 +258,15 @@ def test_fused_substep_equals_separate_calls(amd):
         e.interaction_collect_charge()
         e.field_solve_electric()
     for it in range(4):
-        a.step(1)
         for irk in (1, 2):
+            a.substep(irk)
             b.interaction_push_particle(irk)
             b.interaction_collect_charge()
             b.field_solve_electric()
-        # charge sums differ in order only; resynchronise the field so that the
-        # particle comparison stays bit-exact
-        assert relerr(a.get_field()["electric"], b.get_field()["electric"]) < 1e-11
-        b.set_electric(a.get_field()["electric"])
+            # charge sums differ in order only; resynchronise the field so that
+            # the particle comparison stays bit-exact
+            assert relerr(a.get_field()["electric"], b.get_field()["electric"]) < 1e-11
+            b.set_electric(a.get_field()["electric"])
     ga, gb = a.particles_download(), b.particles_download()
     for k in "xvw":
         assert np.array_equal(ga[k], gb[k]), k
