@@ -152,6 +152,14 @@ int pic1dp_hip_host_particle_load(const pic1dp_input *in, int32_t mype, int32_t 
                                   double *x, double *v, double *p, double *w,
                                   int64_t nalloc);
 
+/* n raw 64-bit draws (multirand_int64, as two's-complement int64) of the
+ * loader's generator after multirand_init(al_int, seed_type, mype, warmup,
+ * selftest) -- src/multirand.F90:132-383; lets a host or a test check the
+ * stream against the reference's */
+int pic1dp_hip_host_multirand_int64(int32_t al_int, int32_t seed_type, int32_t mype,
+                                    int32_t warmup, int32_t selftest, int64_t *out,
+                                    int64_t n);
+
 /* ---- life cycle -------------------------------------------------------
  * create  <-> input_init + particle_init + field_init
  *             (src/pic1dp.F90:57-59; src/pic1dp_particle.F90:66-139;

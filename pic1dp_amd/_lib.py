@@ -72,6 +72,7 @@ SIGNATURES = {
     "pic1dp_hip_block_sizes": [_INP, C.c_int32, C.c_int32, C.c_int32,
                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "pic1dp_hip_host_particle_load": [_INP, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64],
+    "pic1dp_hip_host_multirand_int64": [C.c_int32] * 5 + [_P, C.c_int64],
     "pic1dp_hip_create": [_INP, C.POINTER(Layout), C.POINTER(_P)],
     "pic1dp_hip_destroy": [_P],
     "pic1dp_hip_local_sizes": [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],

@@ -412,6 +412,20 @@ int pic1dp_hip_host_particle_load(const pic1dp_input *in, int32_t mype, int32_t 
   return 0;
 }
 
+int pic1dp_hip_host_multirand_int64(int32_t al_int, int32_t seed_type, int32_t mype, int32_t warmup,
+                                    int32_t selftest, int64_t *out, int64_t n) {
+  if (!out || n < 0) return fail(PIC1DP_ERR_ARG, "bad output buffer");
+  pic1dp_input in{};
+  in.multirand_al_int = al_int;
+  in.multirand_seed_type = seed_type;
+  in.multirand_warmup = warmup;
+  in.multirand_selftest = selftest;
+  Multirand g;
+  if (int rc = init_block_rng(in, mype, g)) return rc;
+  for (int64_t i = 0; i < n; ++i) out[i] = static_cast<int64_t>(g.next());
+  return 0;
+}
+
 int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1dp_ctx **out) {
   if (!in || !layout || !out) return fail(PIC1DP_ERR_ARG, "null argument");
   *out = nullptr;

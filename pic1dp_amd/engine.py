@@ -45,7 +45,7 @@ def make_input(**kw):
             setattr(inp, k, val)
     if not explicit_init:
         # input_species_nparticle_init = input_nparticle_max (src/pic1dp_input.F90:117)
-        for s in range(inp.nspecies):
+        for s in range(max(0, min(inp.nspecies, _lib.MAX_SPECIES))):
             inp.species_nparticle_init[s] = inp.nparticle_max
     return inp
 

@@ -1,0 +1,247 @@
+"""The oracle's push / deposit / field solve / driver restatement, checked by
+what the reference offers for them (no golden vectors):
+the analytic identity of its field_test, conservation properties, independent
+numpy re-evaluations of the cited formulas, and the linear growth rate against
+the Vlasov dispersion root (BASELINE.md physics anchors).  CPU only."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DIST_CASES
+
+PI = 3.14159265358979323846264
+
+
+def test_field_solve_analytic_identity(oracle_mod):
+    """field_test (src/pic1dp_field.F90:276-309): rho = cos(2 pi ix/nx), mode 1
+    kept  ->  E = lx/(2 pi) sin(2 pi ix/nx)"""
+    for nx in (64, 192, 1000):
+        inp = oracle_mod.make_input(nx=nx)
+        ix = np.arange(nx)
+        E, re, im = oracle_mod.Field(inp).solve(np.cos(2 * np.pi * ix / nx))
+        assert np.max(np.abs(E - inp.lx / (2 * np.pi) * np.sin(2 * np.pi * ix / nx))) < 1e-13 * inp.lx
+        # E_k = -i rho_k / k with rho_k = 1/2: mode_im = -1/(2k), mode_re = 0
+        k = 2 * np.pi / inp.lx
+        assert abs(im[0] + 0.5 / k) < 1e-13 and abs(re[0]) < 1e-13
+
+
+def test_field_solve_filters_unkept_modes(oracle_mod):
+    nx = 128
+    inp = oracle_mod.make_input(nx=nx, nmode=2, modes=[1, 3])
+    ix = np.arange(nx)
+    rho = np.cos(2 * np.pi * 2 * ix / nx) + 0.5 * np.sin(2 * np.pi * 5 * ix / nx)   # modes 2 and 5 only
+    E, _, _ = oracle_mod.Field(inp).solve(rho)
+    assert np.max(np.abs(E)) < 1e-13
+    rho = np.sin(2 * np.pi * 3 * ix / nx)
+    E, _, _ = oracle_mod.Field(inp).solve(rho)
+    k3 = 2 * np.pi * 3 / inp.lx
+    assert np.max(np.abs(E + np.cos(2 * np.pi * 3 * ix / nx) / k3)) < 1e-13 / k3 * 10
+
+
+def test_field_solve_matches_numpy_fft(oracle_mod):
+    nx = 192
+    inp = oracle_mod.make_input(nx=nx, nmode=4, modes=[1, 2, 3, 7])
+    rng = np.random.default_rng(5)
+    rho = rng.standard_normal(nx)
+    E, _, _ = oracle_mod.Field(inp).solve(rho)
+    rk = np.fft.fft(rho)
+    Ek = np.zeros(nx, dtype=complex)
+    for m in (1, 2, 3, 7):
+        k = 2 * np.pi * m / inp.lx
+        Ek[m] = -1j * rk[m] / k
+        Ek[nx - m] = np.conj(Ek[m])
+    assert np.max(np.abs(E - np.fft.ifft(Ek).real)) < 1e-12 * np.max(np.abs(E))
+
+
+def test_deposit_conserves_charge_and_wraps(oracle_mod):
+    inp = oracle_mod.make_input(nx=50)
+    rng = np.random.default_rng(2)
+    n = 20001
+    x = rng.uniform(-3 * inp.lx, 4 * inp.lx, n)
+    q = rng.standard_normal(n)
+    x0 = x.copy()
+    c1 = np.zeros(50)
+    ix = np.empty(n, dtype=np.int32)
+    cnt = np.zeros(50, dtype=np.int64)
+    oracle_mod.lib().orc_deposit_species_idx(C.byref(inp), n, x, q, c1, ix, cnt)
+    assert x.min() >= 0.0 and x.max() < inp.lx
+    # same point modulo the period
+    d = (x - x0) / inp.lx
+    assert np.max(np.abs(d - np.round(d))) < 1e-12
+    assert abs(c1.sum() - q.sum()) < 1e-11
+    assert cnt.sum() == n and np.array_equal(np.bincount(ix, minlength=50), cnt)
+    assert np.array_equal(ix, np.floor(x / inp.lx * 50).astype(np.int32))
+    # linearity: deposit(a q1 + b q2) = a deposit(q1) + b deposit(q2)
+    q2 = rng.standard_normal(n)
+    ca, cb, cc = np.zeros(50), np.zeros(50), np.zeros(50)
+    L = oracle_mod.lib()
+    L.orc_deposit_species(C.byref(inp), n, x.copy(), q, ca)
+    L.orc_deposit_species(C.byref(inp), n, x.copy(), q2, cb)
+    L.orc_deposit_species(C.byref(inp), n, x.copy(), 2.0 * q - 3.0 * q2, cc)
+    assert np.max(np.abs(cc - (2.0 * ca - 3.0 * cb))) < 1e-11
+
+
+def numpy_dlnf0(inp, v):
+    T, T2, m = inp.species_temperature[0], inp.species_temperature2[0], inp.species_mass[0]
+    n, v0 = inp.species_density[0], inp.species_v0[0]
+    d = inp.iptcldist
+    if d == 1:
+        return v - 2.0 / v
+    if d == 2:
+        ep = np.exp(-(v + v0) ** 2 / (2 * T / m))
+        em = np.exp(-(v - v0) ** 2 / (2 * T / m))
+        return ((v + v0) * ep + (v - v0) * em) / (ep + em) * m / T
+    if d == 3:
+        e1 = np.exp(-v ** 2 / (2 * T / m)) / np.sqrt(T / m)
+        e2 = np.exp(-(v - v0) ** 2 / (2 * T2 / m)) / np.sqrt(T2 / m)
+        return (n * v / (T / m) * e1 + (1 - n) * (v - v0) / (T2 / m) * e2) / (n * e1 + (1 - n) * e2)
+    return (v - v0) / (T / m)
+
+
+@pytest.mark.parametrize("name,kw", DIST_CASES, ids=lambda v: v if isinstance(v, str) else "")
+@pytest.mark.parametrize("linear", [0, 1])
+def test_push_against_numpy(oracle_mod, name, kw, linear):
+    """orc_push_species vs a vectorised numpy evaluation of
+    src/pic1dp_interaction.F90:250-337 (independent code, same formulas)"""
+    inp = oracle_mod.make_input(nx=40, linear=linear, **kw)
+    rng = np.random.default_rng(7)
+    n = 5000
+    x = rng.uniform(0, inp.lx, n)
+    v = rng.uniform(-8, 8, n)
+    v[np.abs(v) < 1e-3] = 0.5
+    p = rng.uniform(0.5, 1.5, n)
+    w = rng.uniform(-0.1, 0.1, n)
+    E = rng.standard_normal(40)
+    xb, vb, wb = x + 0.01, v - 0.02, w + 0.003
+    for irk in (1, 2):
+        dt = 0.5 * inp.dt if irk == 1 else inp.dt
+        s = x / inp.lx * 40
+        ix = np.floor(s).astype(int)
+        wl = 1.0 - (s - ix)
+        e = E[ix] * wl + E[(ix + 1) % 40] * (1.0 - wl)
+        Z, m = inp.species_charge[0], inp.species_mass[0]
+        x_want = xb + dt * v
+        w_want = wb + dt * ((p if linear else (p - w)) * e) * numpy_dlnf0(inp, v) * Z / m
+        v_want = v.copy() if linear else vb + dt * e * Z / m
+        xo, vo, wo = x.copy(), v.copy(), w.copy()
+        oracle_mod.lib().orc_push_species(C.byref(inp), 0, irk, E, n, xo, vo, p, wo, xb, vb, wb)
+        assert np.array_equal(xo, x_want)
+        assert np.array_equal(vo, v_want)
+        assert np.max(np.abs(wo - w_want)) <= 1e-13 * np.max(np.abs(w_want))
+
+
+def test_ownership_and_unload(oracle_mod):
+    L = oracle_mod.lib()
+    for n, size in ((10, 3), (6400000, 4), (100, 7), (5, 8)):
+        sizes = [L.orc_local_size(n, r, size) for r in range(size)]
+        assert sum(sizes) == n and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    inp = oracle_mod.make_input(nparticle_max=1000, species_nparticle_init=[900])
+    nps = [L.orc_particle_np(C.byref(inp), 0, r, 3) for r in range(3)]
+    # 100 spare slots: 33 per rank, remainder 1 on rank 0 (src/pic1dp_particle.F90:240-248)
+    assert nps == [334 - 34, 333 - 33, 333 - 33] and sum(nps) == 900
+
+
+def test_driver_termination_and_output_cadence(oracle_mod):
+    """check_termination and the output test of src/pic1dp.F90:98-106,133-148"""
+    inp = oracle_mod.make_input(time_max=500.0, ntime_max=900000)
+    L = oracle_mod.lib()
+    t, outs = 0.0, []
+    for it in range(1, 101):
+        t = t + inp.dt
+        if L.orc_output_due(C.byref(inp), t, 0):
+            outs.append(it)
+    assert outs == list(range(10, 101, 10))          # every 0.5 / 0.05 = 10 steps
+    assert L.orc_check_termination(C.byref(inp), 10, 499.9) == 0
+    assert L.orc_check_termination(C.byref(inp), 10, 500.0 - 1e-9) == 1   # within sqrt(eps)
+    assert L.orc_check_termination(C.byref(inp), 900000, 1.0) == 1
+    assert L.orc_output_due(C.byref(inp), 0.123, 1) == 1                  # final step always writes
+
+
+def test_loader_statistics_and_weights(oracle_mod):
+    inp = oracle_mod.make_input(nparticle_max=200000)
+    sim = oracle_mod.Sim(inp)
+    assert sim.load() == 0
+    x, v, p, w = (sim.gather(k) for k in "xvpw")
+    assert 0.0 <= x.min() and x.max() <= inp.lx and abs(x.mean() / inp.lx - 0.5) < 5e-3
+    assert -8.0 <= v.min() and v.max() <= 8.0
+    # sum of p approximates lx * integral f0 dv = lx (f0 normalised to 1)
+    assert abs(p.sum() / inp.lx - 1.0) < 1e-2
+    # w = 1e-5 sin(k x) * f0/g, and the nonlinear p includes it
+    k = 2 * PI / inp.lx
+    assert np.max(np.abs(w / (p - w) - 1e-5 * np.sin(k * x))) < 1e-15
+
+
+def test_two_rank_sim_equals_manual_blocks(oracle_mod):
+    """npe virtual ranks: block r is drawn from stream mype=r; the summed
+    charge equals the sum of per-block deposits"""
+    inp = oracle_mod.make_input(nparticle_max=30001, nx=32)
+    sim = oracle_mod.Sim(inp, npe=3)
+    sim.load()
+    L = oracle_mod.lib()
+    tot = np.zeros(32)
+    for r in range(3):
+        n = L.orc_local_size(30001, r, 3)
+        g = oracle_mod.Multirand()
+        g.init(3, 1, r, 5, True)
+        x, v, p, w = (np.empty(n) for _ in range(4))
+        L.orc_particle_load_species(C.byref(inp), 0, g.g, n, x, v, p, w)
+        assert np.array_equal(x, sim.array(r, 0, "x"))
+        c1 = np.zeros(32)
+        L.orc_deposit_species(C.byref(inp), n, x, w, c1)
+        tot = tot + c1 * -1.0
+    sim.collect_charge()
+    assert np.max(np.abs(sim.get_field()[1] - tot * 32 / inp.lx)) < 1e-18 + 1e-13 * np.max(np.abs(tot))
+
+
+def test_threads_do_not_change_results(oracle_mod):
+    inp = oracle_mod.make_input(nparticle_max=40000, nx=32)
+    a = oracle_mod.Sim(inp, npe=4, nthreads=1)
+    b = oracle_mod.Sim(inp, npe=4, nthreads=4)
+    for s in (a, b):
+        s.load()
+        s.collect_charge()
+        s.solve_field()
+        s.step(5)
+    assert a.field_energy() == b.field_energy()
+    assert np.array_equal(a.gather("w"), b.gather("w"))
+
+
+def test_growth_rate_against_vlasov_dispersion(oracle_mod):
+    """default bump-on-tail: d ln(int E^2 dx)/dt = 2 gamma = 0.16766 (BASELINE.md,
+    root of the reference's tools/dispersion.py); finite-N run within 3 %"""
+    inp = oracle_mod.make_input(nparticle_max=100000, nx=64)
+    sim = oracle_mod.Sim(inp, npe=4, nthreads=4)
+    sim.load()
+    sim.collect_charge()
+    sim.solve_field()
+    t, e = [0.0], [sim.field_energy()]
+    for _ in range(70):
+        sim.step(10)
+        t.append(sim.time)
+        e.append(sim.field_energy())
+    g2 = oracle_mod.growthrate_energy_fit(t, e, 18.0, 34.0)
+    assert abs(g2 / 0.16766 - 1.0) < 0.03
+
+
+def test_oracle_series_fixture(oracle_mod):
+    """regression pin of the oracle itself (generated by the oracle, committed
+    by tests/golden/gen_oracle_series.py): NOT a reference output"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_series.json")
+    with open(path) as f:
+        fx = json.load(f)
+    for case in fx["cases"]:
+        inp = oracle_mod.make_input(**case["input"])
+        sim = oracle_mod.Sim(inp, npe=case["npe"])
+        sim.load()
+        sim.collect_charge()
+        sim.solve_field()
+        e = [sim.field_energy()]
+        for _ in range(case["steps"]):
+            sim.step(1)
+            e.append(sim.field_energy())
+        want = np.array([float.fromhex(h) for h in case["energy_hex"]])
+        # libm may differ between images in the last bit of exp/sin: allow 1e-12
+        assert np.max(np.abs(np.array(e) / want - 1.0)) < 1e-12
