@@ -253,6 +253,24 @@ int pic1dp_hip_energy_sums(pic1dp_ctx *ctx, int32_t ispecies, double out[3]);
 int pic1dp_hip_cell_indices(pic1dp_ctx *ctx, int32_t ispecies, int32_t *ix,
                             int64_t *count);
 
+/* ---- diagnostics of output_all (called every output_interval, not timed) --
+ * realbuf of output_field (src/pic1dp_output.F90:117-175): out[0] = time,
+ * out[1] = int E^2 dx, then per species s: out[2+3s] = sum v^2,
+ * out[3+3s] = total kinetic sum, out[4+3s] = perturbed kinetic sum (the linear /
+ * full-f adjustments of :152-170 applied).  n must be 2 + 3*nspecies.  Sums are
+ * all-reduced over ranks when a communicator exists. */
+int pic1dp_hip_output_scalars(pic1dp_ctx *ctx, double *out, int32_t n);
+/* (x,v) and v distributions of output_ptcldist (src/pic1dp_output.F90:196-477)
+ * of one species, computed on the GPU: markr/total/pertb_xv hold
+ * nx_opd*nv_opd doubles (index iv*nx_opd+ix), markr/total/pertb_v hold nv_opd.
+ * finish = 0: this rank's raw sums (:239-315).
+ * finish = 1: what the reference writes: summed over ranks (when a communicator
+ *             exists), linear total += pertb (:328-331), scaled by the grid
+ *             sizes (:361-369) and, for full-f, pertb = total - f0 (:370-453). */
+int pic1dp_hip_ptcldist(pic1dp_ctx *ctx, int32_t ispecies, int32_t finish,
+                        double *markr_xv, double *total_xv, double *pertb_xv,
+                        double *markr_v, double *total_v, double *pertb_v);
+
 /* ---- split-phase deposit for a host that owns the reduction (MPI) ------
  * charge_local: everything of collect_charge up to the all-reduce
  *   (src/pic1dp_interaction.F90:81-128) -> this rank's charge2[nx] on the host
@@ -263,7 +281,10 @@ int pic1dp_hip_charge_reduced(pic1dp_ctx *ctx, const double *charge1);
 /* ---- multi-GPU: RCCL communicator (replaces MPI_Allreduce at
  * src/pic1dp_interaction.F90:132) ------------------------------------------
  * rank 0 obtains an id, the host distributes the 128 bytes to every rank
- * (MPI_Bcast / torch.distributed), every rank calls comm_init. */
+ * (MPI_Bcast / torch.distributed), every rank calls comm_init.  A context with
+ * nranks = 1 needs no communicator; if comm_init is called on it anyway a
+ * 1-rank communicator is created and the all-reduce path is taken (used to
+ * exercise that path on a single GPU). */
 int pic1dp_hip_comm_unique_id(unsigned char id[PIC1DP_COMM_ID_BYTES]);
 int pic1dp_hip_comm_init(pic1dp_ctx *ctx,
                          const unsigned char id[PIC1DP_COMM_ID_BYTES]);

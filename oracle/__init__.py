@@ -150,6 +150,9 @@ def lib():
         "orc_sim_rank_nalloc": (C.c_int64, [P, C.c_int]),
         "orc_sim_array": (C.POINTER(C.c_double), [P, C.c_int, C.c_int, C.c_int]),
         "orc_sim_energy_sums": (None, [P, C.c_int, _dp]),
+        "orc_ptcldist_finish": (None, [IN, C.c_int] + [_dp] * 6),
+        "orc_sim_ptcldist": (None, [P, C.c_int, C.c_int] + [_dp] * 6),
+        "orc_sim_output_scalars": (None, [P, _dp]),
         "orc_check_termination": (C.c_int, [IN, C.c_int32, C.c_double]),
         "orc_output_due": (C.c_int, [IN, C.c_double, C.c_int]),
     }
@@ -335,6 +338,18 @@ class Sim:
         out = np.empty(3)
         lib().orc_sim_energy_sums(self.s, isp, out)
         return out
+
+    def output_scalars(self):
+        out = np.empty(2 + 3 * self.inp.nspecies)
+        lib().orc_sim_output_scalars(self.s, out)
+        return out
+
+    def ptcldist(self, isp=0, finish=True):
+        nxo, nvo = self.inp.nx_opd, self.inp.nv_opd
+        names = ("markr_xv", "total_xv", "pertb_xv", "markr_v", "total_v", "pertb_v")
+        out = [np.zeros(nxo * nvo) for _ in range(3)] + [np.zeros(nvo) for _ in range(3)]
+        lib().orc_sim_ptcldist(self.s, isp, int(finish), *out)
+        return dict(zip(names, out))
 
 
 def growthrate_energy_fit(t, energy, time1, time2):

@@ -712,6 +712,61 @@ void orc_ptcldist(const orc_input *in, int64_t np, const double *x,
   }
 }
 
+/* equilibrium f0(v) of the full-f branch, src/pic1dp_output.F90:375-451
+ * (the reference normalises by T/m where sqrt(T/m) would be expected) */
+static double output_f0(const orc_input *in, int isp, double sv) {
+  const double T = in->species_temperature[isp], T2 = in->species_temperature2[isp];
+  const double m = in->species_mass[isp], den = in->species_density[isp];
+  const double v0 = in->species_v0[isp];
+  if (in->iptcldist == 1) /* :380-381 */
+    return den * (sv * sv) * exp(-(sv * sv) / 2.0) / sqrt(2.0 * ORC_PI);
+  if (in->iptcldist == 2) /* :390-396 */
+    return den * (exp(-((sv + v0) * (sv + v0)) / (2.0 * T / m)) +
+                  exp(-((sv - v0) * (sv - v0)) / (2.0 * T / m))) /
+           (sqrt(8.0 * ORC_PI) * T / m);
+  if (in->iptcldist == 3) /* :410-419 */
+    return den * exp(-(sv * sv) / (2.0 * T / m)) / (sqrt(2.0 * ORC_PI) * T / m) +
+           (1.0 - den) * exp(-((sv - v0) * (sv - v0)) / (2.0 * T2 / m)) /
+               (sqrt(2.0 * ORC_PI) * T2 / m);
+  return den * exp(-((sv - v0) * (sv - v0)) / (2.0 * T / m)) /
+         (sqrt(2.0 * ORC_PI) * T / m); /* :438-443 */
+}
+
+/* root-rank post-processing of output_ptcldist, src/pic1dp_output.F90:328-454,
+ * applied to the rank-summed histograms */
+void orc_ptcldist_finish(const orc_input *in, int isp, double *markr_xv,
+                         double *total_xv, double *pertb_xv, double *markr_v,
+                         double *total_v, double *pertb_v) {
+  const int nxo = in->nx_opd, nvo = in->nv_opd;
+  const int nxv = nxo * nvo;
+  const double delv_inv = (double)(nvo - 1) / (2.0 * in->v_max); /* :203-205 */
+  const double delx_inv = (double)nxo / in->lx;
+  if (in->linear == 1) { /* :328-331 */
+    for (int i = 0; i < nxv; i++) total_xv[i] = total_xv[i] + pertb_xv[i];
+    for (int i = 0; i < nvo; i++) total_v[i] = total_v[i] + pertb_v[i];
+  }
+  for (int i = 0; i < nxv; i++) { /* :362-363 */
+    markr_xv[i] = markr_xv[i] * delx_inv * delv_inv;
+    total_xv[i] = total_xv[i] * delx_inv * delv_inv;
+  }
+  for (int i = 0; i < nvo; i++) { /* :364-365 */
+    markr_v[i] = markr_v[i] * delv_inv;
+    total_v[i] = total_v[i] * delv_inv;
+  }
+  if (in->deltaf == 1) { /* :366-369 */
+    for (int i = 0; i < nxv; i++) pertb_xv[i] = pertb_xv[i] * delx_inv * delv_inv;
+    for (int i = 0; i < nvo; i++) pertb_v[i] = pertb_v[i] * delv_inv;
+  } else { /* :371-452 */
+    for (int iv = 0; iv < nvo; iv++) {
+      double sv = ((double)iv / (double)(nvo - 1) * 2.0 - 1.0) * in->v_max;
+      double f0 = output_f0(in, isp, sv);
+      for (int ix = 0; ix < nxo; ix++)
+        pertb_xv[iv * nxo + ix] = total_xv[iv * nxo + ix] - f0;
+      pertb_v[iv] = total_v[iv] - in->lx * f0;
+    }
+  }
+}
+
 /* ======================================================================
  * driver -- src/pic1dp.F90:64-109 with npe virtual reference ranks
  * ====================================================================== */
@@ -895,6 +950,63 @@ void orc_sim_energy_sums(const orc_sim *s, int isp, double out[3]) {
     orc_energy_sums(s->nalloc[r], SIM_ARR(s, r, isp, 1), SIM_ARR(s, r, isp, 2),
                     SIM_ARR(s, r, isp, 3), s->in.deltaf, t);
     for (int k = 0; k < 3; k++) out[k] = out[k] + t[k];
+  }
+}
+
+/* output_ptcldist over all virtual ranks: per-rank histograms, MPI_Reduce in
+ * rank order (src/pic1dp_output.F90:333-358), then the root's finish */
+void orc_sim_ptcldist(const orc_sim *s, int isp, int finish, double *markr_xv,
+                      double *total_xv, double *pertb_xv, double *markr_v,
+                      double *total_v, double *pertb_v) {
+  const orc_input *in = &s->in;
+  const int nxv = in->nx_opd * in->nv_opd, nvo = in->nv_opd;
+  const size_t ntot = (size_t)3 * nxv + 3 * nvo;
+  double *acc = (double *)calloc(ntot, sizeof(double));
+  double *loc = (double *)malloc(ntot * sizeof(double));
+  for (int r = 0; r < s->npe; r++) {
+    memset(loc, 0, ntot * sizeof(double));
+    orc_ptcldist(in, s->np[(size_t)r * in->nspecies + isp], SIM_ARR(s, r, isp, 0),
+                 SIM_ARR(s, r, isp, 1), SIM_ARR(s, r, isp, 2), SIM_ARR(s, r, isp, 3),
+                 loc, loc + nxv, loc + 2 * nxv, loc + 3 * nxv, loc + 3 * nxv + nvo,
+                 loc + 3 * nxv + 2 * nvo);
+    for (size_t i = 0; i < ntot; i++) acc[i] = r == 0 ? loc[i] : acc[i] + loc[i];
+  }
+  if (finish)
+    orc_ptcldist_finish(in, isp, acc, acc + nxv, acc + 2 * nxv, acc + 3 * nxv,
+                        acc + 3 * nxv + nvo, acc + 3 * nxv + 2 * nvo);
+  memcpy(markr_xv, acc, sizeof(double) * nxv);
+  memcpy(total_xv, acc + nxv, sizeof(double) * nxv);
+  memcpy(pertb_xv, acc + 2 * nxv, sizeof(double) * nxv);
+  memcpy(markr_v, acc + 3 * nxv, sizeof(double) * nvo);
+  memcpy(total_v, acc + 3 * nxv + nvo, sizeof(double) * nvo);
+  memcpy(pertb_v, acc + 3 * nxv + 2 * nvo, sizeof(double) * nvo);
+  free(acc);
+  free(loc);
+}
+
+/* realbuf of output_field, src/pic1dp_output.F90:117-172 */
+void orc_sim_output_scalars(const orc_sim *s, double *out) {
+  const orc_input *in = &s->in;
+  out[0] = s->time;
+  out[1] = orc_field_energy(in, s->E);
+  for (int isp = 0; isp < in->nspecies; isp++) {
+    double t[3];
+    orc_sim_energy_sums(s, isp, t);
+    double total = t[1], pert;
+    if (in->deltaf == 1) {
+      pert = t[2];
+      if (in->linear == 1) total = total + pert; /* :152-155 */
+    } else {                                      /* :156-170 */
+      pert = total;
+      if (in->iptcldist == 1)
+        pert = pert - 3.0 * in->species_density[isp] * in->lx;
+      else if (in->iptcldist == 0)
+        pert = pert - in->species_temperature[isp] / in->species_mass[isp] *
+                          in->species_density[isp] * in->lx;
+    }
+    out[2 + 3 * isp] = t[0];
+    out[3 + 3 * isp] = total;
+    out[4 + 3 * isp] = pert;
   }
 }
 

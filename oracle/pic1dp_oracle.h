@@ -155,6 +155,11 @@ void orc_ptcldist(const orc_input *in, int64_t np, const double *x,
                   double *markr_xv, double *total_xv, double *pertb_xv,
                   double *markr_v, double *total_v, double *pertb_v);
 
+/* root-rank post-processing of output_ptcldist (src/pic1dp_output.F90:328-454) */
+void orc_ptcldist_finish(const orc_input *in, int isp, double *markr_xv,
+                         double *total_xv, double *pertb_xv, double *markr_v,
+                         double *total_v, double *pertb_v);
+
 /* ---- whole simulation with npe virtual reference ranks (driver of
  * src/pic1dp.F90:64-109).  nthreads>1 runs the rank blocks on OpenMP threads
  * (private charge per rank, summed in rank order = the npe-rank reference). */
@@ -178,6 +183,10 @@ int64_t orc_sim_rank_nalloc(const orc_sim *s, int rank);
 /* pointers into rank-owned arrays: which = 0..6 -> x v p w xb vb wb */
 double *orc_sim_array(orc_sim *s, int rank, int isp, int which);
 void orc_sim_energy_sums(const orc_sim *s, int isp, double out[3]);
+void orc_sim_ptcldist(const orc_sim *s, int isp, int finish, double *markr_xv,
+                      double *total_xv, double *pertb_xv, double *markr_v,
+                      double *total_v, double *pertb_v);
+void orc_sim_output_scalars(const orc_sim *s, double *out);
 /* termination / output cadence of src/pic1dp.F90:98-108,133-148 */
 int orc_check_termination(const orc_input *in, int32_t itime, double time);
 int orc_output_due(const orc_input *in, double time, int itermination);

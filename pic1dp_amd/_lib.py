@@ -98,6 +98,8 @@ SIGNATURES = {
     "pic1dp_hip_energy_history_reset": [_P],
     "pic1dp_hip_energy_sums": [_P, C.c_int32, _P],
     "pic1dp_hip_cell_indices": [_P, C.c_int32, _P, _P],
+    "pic1dp_hip_output_scalars": [_P, _P, C.c_int32],
+    "pic1dp_hip_ptcldist": [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P],
     "pic1dp_hip_charge_local": [_P, _P],
     "pic1dp_hip_charge_reduced": [_P, _P],
     "pic1dp_hip_comm_unique_id": [_P],

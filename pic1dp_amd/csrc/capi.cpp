@@ -87,7 +87,7 @@ struct pic1dp_ctx {
   // field
   double *d_rho_sp = nullptr, *d_charge = nullptr, *d_chargeden = nullptr, *d_E = nullptr;
   double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
-  double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr;
+  double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
   int64_t hist_count = 0;
   int32_t itime = 0;
   double time = 0.0;
@@ -236,7 +236,7 @@ int validate(const pic1dp_input &in, const pic1dp_layout &lay) {
 
 // the all-reduce of src/pic1dp_interaction.F90:132 on the stream
 int allreduce_charge(pic1dp_ctx *c) {
-  if (c->lay.nranks == 1) return 0;
+  if (c->lay.nranks == 1 && !c->comm) return 0;
   if (!c->comm)
     return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: call pic1dp_hip_comm_init (or use charge_local/charge_reduced)");
   Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
@@ -591,7 +591,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     if (S.set[1].w != S.set[0].w) (void)hipFree(S.set[1].w);
   }
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
-                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch};
+                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist};
   for (double *b : bufs) (void)hipFree(b);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);
@@ -737,7 +737,7 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   if (int rc = require_loaded(c)) return rc;
   Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
   if (int rc = enqueue_deposit(c)) return rc;
-  const bool multi = c->lay.nranks > 1;
+  const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (multi) {
     HIP_TRY(launch_charge_local(c->fa, c->st));
     if (int rc = allreduce_charge(c)) return rc;
@@ -764,7 +764,7 @@ int pic1dp_hip_push(pic1dp_ctx *c, int32_t irk) {
 
 static int substep_impl(pic1dp_ctx *c, int irk, bool record) {
   if (int rc = enqueue_push(c, irk, true)) return rc;
-  const bool multi = c->lay.nranks > 1;
+  const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (multi) {
     HIP_TRY(launch_charge_local(c->fa, c->st));
     if (int rc = allreduce_charge(c)) return rc;
@@ -944,6 +944,133 @@ int pic1dp_hip_cell_indices(pic1dp_ctx *c, int32_t isp, int32_t *ix, int64_t *co
 }
 
 // ---------------------------------------------------------------------------
+// diagnostics of output_all
+// ---------------------------------------------------------------------------
+static int allreduce_doubles(pic1dp_ctx *c, double *d, size_t n) {
+  if (!c->comm) {
+    if (c->lay.nranks > 1)
+      return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: reduce the local sums on the host instead");
+    return 0;
+  }
+  ncclResult_t r = rccl().AllReduce(d, d, n, ncclDouble, ncclSum, c->comm, c->st);
+  if (r != ncclSuccess) return fail(PIC1DP_ERR_COMM, "ncclAllReduce: %s", rccl().GetErrorString(r));
+  return 0;
+}
+
+int pic1dp_hip_output_scalars(pic1dp_ctx *c, double *out, int32_t n) {
+  CHECK_CTX(c);
+  const int ns = c->in.nspecies;
+  if (!out || n != 2 + 3 * ns) return fail(PIC1DP_ERR_ARG, "out must hold 2 + 3*nspecies doubles");
+  std::vector<double> sums(3 * ns);
+  for (int s = 0; s < ns; ++s)
+    if (int rc = pic1dp_hip_energy_sums(c, s, &sums[3 * s])) return rc;
+  if (c->comm) {  // VecSum's scalar all-reduce
+    double *d = c->d_scratch;
+    HIP_TRY(hipMemcpyAsync(d, sums.data(), sizeof(double) * 3 * ns, hipMemcpyHostToDevice, c->st));
+    if (int rc = allreduce_doubles(c, d, 3 * ns)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(sums.data(), d, sizeof(double) * 3 * ns, hipMemcpyDeviceToHost));
+  }
+  out[0] = c->time;
+  if (int rc = pic1dp_hip_field_energy(c, &out[1])) return rc;
+  const pic1dp_input &in = c->in;
+  for (int s = 0; s < ns; ++s) {
+    double marker = sums[3 * s], total = sums[3 * s + 1], pert;
+    if (in.deltaf == 1) {
+      pert = sums[3 * s + 2];
+      if (in.linear == 1) total = total + pert;  // :152-155
+    } else {                                      // :156-170
+      pert = total;
+      if (in.iptcldist == 1) {
+        pert = pert - 3.0 * in.species_density[s] * in.lx;
+      } else if (in.iptcldist == 0) {
+        pert = pert - in.species_temperature[s] / in.species_mass[s] * in.species_density[s] * in.lx;
+      }
+    }
+    out[2 + 3 * s] = marker;
+    out[3 + 3 * s] = total;
+    out[4 + 3 * s] = pert;
+  }
+  return 0;
+}
+
+// equilibrium f0(v) as the full-f branch of output_ptcldist normalises it
+// (src/pic1dp_output.F90:375-451; note the reference divides by T/m, not sqrt(T/m))
+static double output_f0(const pic1dp_input &in, int s, double sv) {
+  const double T = in.species_temperature[s], T2 = in.species_temperature2[s], m = in.species_mass[s];
+  const double den = in.species_density[s], v0 = in.species_v0[s];
+  if (in.iptcldist == 1) return den * (sv * sv) * std::exp(-(sv * sv) / 2.0) / std::sqrt(2.0 * kPi);
+  if (in.iptcldist == 2)
+    return den * (std::exp(-((sv + v0) * (sv + v0)) / (2.0 * T / m)) + std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T / m))) /
+           (std::sqrt(8.0 * kPi) * T / m);
+  if (in.iptcldist == 3)
+    return den * std::exp(-(sv * sv) / (2.0 * T / m)) / (std::sqrt(2.0 * kPi) * T / m) +
+           (1.0 - den) * std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T2 / m)) / (std::sqrt(2.0 * kPi) * T2 / m);
+  return den * std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T / m)) / (std::sqrt(2.0 * kPi) * T / m);
+}
+
+int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *markr_xv, double *total_xv,
+                        double *pertb_xv, double *markr_v, double *total_v, double *pertb_v) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  if (int rc = require_loaded(c)) return rc;
+  const pic1dp_input &in = c->in;
+  const int nxo = in.nx_opd, nvo = in.nv_opd;
+  if (nxo < 1 || nvo < 2) return fail(PIC1DP_ERR_ARG, "nx_opd >= 1 and nv_opd >= 2 required");
+  const size_t nxv = static_cast<size_t>(nxo) * nvo, ntot = 3 * nxv + 3 * nvo;
+  if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * ntot));
+  HIP_TRY(hipMemsetAsync(c->d_dist, 0, sizeof(double) * ntot, c->st));
+  Species &S = c->sp[isp];
+  const PSet &A = S.set[c->cur];
+  if (S.np > 0)
+    HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, in.lx, in.v_max, nxo, nvo, in.deltaf == 1, c->d_dist,
+                            c->num_cu, c->st));
+  if (finish)
+    if (int rc = allreduce_doubles(c, c->d_dist, ntot)) return rc;
+  std::vector<double> h(ntot);
+  HIP_TRY(hipStreamSynchronize(c->st));
+  HIP_TRY(hipMemcpy(h.data(), c->d_dist, sizeof(double) * ntot, hipMemcpyDeviceToHost));
+  double *mxv = h.data(), *txv = mxv + nxv, *pxv = txv + nxv, *mv = pxv + nxv, *tv = mv + nvo, *pv = tv + nvo;
+  if (finish) {
+    if (in.linear == 1) {  // :328-331
+      for (size_t i = 0; i < nxv; ++i) txv[i] = txv[i] + pxv[i];
+      for (int i = 0; i < nvo; ++i) tv[i] = tv[i] + pv[i];
+    }
+    const double delv_inv = static_cast<double>(nvo - 1) / (2.0 * in.v_max);  // :203-205
+    const double delx_inv = static_cast<double>(nxo) / in.lx;
+    for (size_t i = 0; i < nxv; ++i) {
+      mxv[i] = mxv[i] * delx_inv * delv_inv;
+      txv[i] = txv[i] * delx_inv * delv_inv;
+    }
+    for (int i = 0; i < nvo; ++i) {
+      mv[i] = mv[i] * delv_inv;
+      tv[i] = tv[i] * delv_inv;
+    }
+    if (in.deltaf == 1) {
+      for (size_t i = 0; i < nxv; ++i) pxv[i] = pxv[i] * delx_inv * delv_inv;
+      for (int i = 0; i < nvo; ++i) pv[i] = pv[i] * delv_inv;
+    } else {  // :370-453
+      for (int iv = 0; iv < nvo; ++iv) {
+        const double sv = (static_cast<double>(iv) / static_cast<double>(nvo - 1) * 2.0 - 1.0) * in.v_max;
+        const double f0 = output_f0(in, isp, sv);
+        for (int ix = 0; ix < nxo; ++ix) pxv[static_cast<size_t>(iv) * nxo + ix] = txv[static_cast<size_t>(iv) * nxo + ix] - f0;
+        pv[iv] = tv[iv] - in.lx * f0;
+      }
+    }
+  }
+  auto give = [&](double *dst, const double *src, size_t n) {
+    if (dst) std::memcpy(dst, src, sizeof(double) * n);
+  };
+  give(markr_xv, mxv, nxv);
+  give(total_xv, txv, nxv);
+  give(pertb_xv, pxv, nxv);
+  give(markr_v, mv, nvo);
+  give(total_v, tv, nvo);
+  give(pertb_v, pv, nvo);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // split-phase deposit
 // ---------------------------------------------------------------------------
 int pic1dp_hip_charge_local(pic1dp_ctx *c, double *charge2) {
@@ -987,7 +1114,7 @@ int pic1dp_hip_comm_unique_id(unsigned char id[PIC1DP_COMM_ID_BYTES]) {
 int pic1dp_hip_comm_init(pic1dp_ctx *c, const unsigned char id[PIC1DP_COMM_ID_BYTES]) {
   CHECK_CTX(c);
   if (!id) return fail(PIC1DP_ERR_ARG, "null id");
-  if (c->lay.nranks == 1) return 0;
+  if (c->comm) return fail(PIC1DP_ERR_STATE, "communicator already initialised");
   std::string err;
   if (!rccl().load(err)) return fail(PIC1DP_ERR_COMM, "%s", err.c_str());
   HIP_TRY(hipSetDevice(c->device));

@@ -551,6 +551,117 @@ k_cell_indices(const double *x, int64_t np, const GridConst g, int32_t *ixo,
 
 }  // namespace
 
+namespace {
+
+struct DistBins {
+  double *h;       // base of [markr_xv | total_xv | pertb_xv | markr_v | total_v | pertb_v]
+  int nxv, nv;     // nx_opd*nv_opd, nv_opd
+  __device__ __forceinline__ double *xv(int k) const { return h + static_cast<size_t>(k) * nxv; }
+  __device__ __forceinline__ double *vv(int k) const { return h + static_cast<size_t>(3) * nxv + k * nv; }
+};
+
+template <bool LDS>
+__device__ __forceinline__ void bin_add(double *p, double v) {
+  if constexpr (LDS) {
+    lds_add(p, v);
+  } else {
+    glb_add(p, v);
+  }
+}
+
+// (x,v) and v histograms of output_ptcldist, src/pic1dp_output.F90:239-315:
+// 4-point bilinear weights on an nx_opd x nv_opd grid, markers with
+// |v| >= v_max skipped (:241).  LDS = true keeps a private copy of all six
+// histograms per workgroup (3*(nxo*nvo)+3*nvo doubles) and flushes it with
+// global atomics; LDS = false (grids too large for 160 KiB) adds straight to
+// global memory.
+template <bool LDS, bool DELTAF>
+__global__ void __launch_bounds__(1024)
+k_ptcldist(const double *x, const double *v, const double *p, const double *w, int64_t np, double lx,
+           double vmax, int nxo, int nvo, double *out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nxv = nxo * nvo;
+  const int ntot = 3 * nxv + 3 * nvo;
+  DistBins b{LDS ? reinterpret_cast<double *>(smem) : out, nxv, nvo};
+  if constexpr (LDS) {
+    for (int i = threadIdx.x; i < ntot; i += blockDim.x) b.h[i] = 0.0;
+    __syncthreads();
+  }
+  const double dnxo = static_cast<double>(nxo), dnv1 = static_cast<double>(nvo - 1);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < np; i += stride) {
+    const double pv = v[i];
+    if (fabs(pv) >= vmax) continue;                       // :241
+    const double px = x[i], pp = p[i];
+    const double pw = DELTAF ? w[i] : 0.0;
+    double sx = px / lx * dnxo;                           // :243
+    const double fx = floor(sx);
+    int ix = static_cast<int>(fx);
+    sx = 1.0 - (sx - fx);
+    double sv = (pv + vmax) / (vmax * 2.0) * dnv1;        // :247
+    const double fv = floor(sv);
+    const int iv = static_cast<int>(fv);
+    sv = 1.0 - (sv - fv);
+    // memory safety only (the reference would write out of bounds)
+    if (static_cast<unsigned>(ix) >= static_cast<unsigned>(nxo) || iv < 0 || iv + 1 >= nvo) continue;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int a = iv * nxo + ix, c = (iv + 1) * nxo + ix;
+      bin_add<LDS>(&b.xv(0)[a], sx * sv);
+      bin_add<LDS>(&b.xv(1)[a], sx * sv * pp);
+      if constexpr (DELTAF) bin_add<LDS>(&b.xv(2)[a], sx * sv * pw);
+      bin_add<LDS>(&b.xv(0)[c], sx * (1.0 - sv));
+      bin_add<LDS>(&b.xv(1)[c], sx * (1.0 - sv) * pp);
+      if constexpr (DELTAF) bin_add<LDS>(&b.xv(2)[c], sx * (1.0 - sv) * pw);
+      ix = ix + 1;                                        // :274-276
+      if (ix > nxo - 1) ix = 0;
+      sx = 1.0 - sx;
+    }
+    bin_add<LDS>(&b.vv(0)[iv], sv);                       // :300-314
+    bin_add<LDS>(&b.vv(1)[iv], sv * pp);
+    if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv], sv * pw);
+    bin_add<LDS>(&b.vv(0)[iv + 1], 1.0 - sv);
+    bin_add<LDS>(&b.vv(1)[iv + 1], (1.0 - sv) * pp);
+    if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv + 1], (1.0 - sv) * pw);
+  }
+  if constexpr (LDS) {
+    __syncthreads();
+    const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * ntot) / gridDim.x);
+    for (int i = threadIdx.x; i < ntot; i += blockDim.x) {
+      int j = i + rot;
+      if (j >= ntot) j -= ntot;
+      const double val = b.h[j];
+      if (val != 0.0) glb_add(&out[j], val);
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
+                           int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
+                           double *out, int num_cu, hipStream_t st) {
+  const size_t bytes = sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo));
+  const bool lds = bytes <= 150 * 1024;
+  const int threads = 1024;
+  int64_t blocks = lds ? num_cu : static_cast<int64_t>(num_cu) * 2;
+  const int64_t need = (np + threads - 1) / threads;
+  if (blocks > need) blocks = need;
+  if (blocks < 1) blocks = 1;
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds && bytes > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), lds ? bytes : 0, st, x, v,
+                       p, w, np, lx, vmax, nxo, nvo, out);
+    return hipGetLastError();
+  };
+  if (lds) return deltaf ? go(k_ptcldist<true, true>) : go(k_ptcldist<true, false>);
+  return deltaf ? go(k_ptcldist<false, true>) : go(k_ptcldist<false, false>);
+}
+
 hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t n,
                               double *partial, int blocks, hipStream_t st) {
   hipLaunchKernelGGL(k_energy_sums, dim3(blocks), dim3(256), 0, st, v, p, w, n, partial);

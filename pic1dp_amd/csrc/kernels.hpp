@@ -87,6 +87,11 @@ hipError_t launch_field_energy(const double *E, int nx, double lx, double dnx, d
 // per-block partial sums of v^2, v^2 p, v^2 w -> partial[blocks][3]
 hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t n,
                               double *partial, int blocks, hipStream_t st);
+// raw (x,v) and v histograms of output_ptcldist into out =
+// [markr_xv | total_xv | pertb_xv | markr_v | total_v | pertb_v] (accumulated)
+hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
+                           int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
+                           double *out, int num_cu, hipStream_t st);
 // cell index per marker and per-cell counts from (wrapped) x
 hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
                                unsigned long long *count, hipStream_t st);

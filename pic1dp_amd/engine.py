@@ -207,6 +207,22 @@ class Pic1dp:
         check(self.L.pic1dp_hip_cell_indices(self._ctx, ispecies, _ptr(ix), _ptr(cnt)))
         return ix, cnt
 
+    # -- diagnostics of output_all (src/pic1dp_output.F90) ------------------------
+    def output_scalars(self):
+        """realbuf of output_field: time, int E^2 dx, then 3 sums per species"""
+        n = 2 + 3 * self.inp.nspecies
+        out = np.empty(n)
+        check(self.L.pic1dp_hip_output_scalars(self._ctx, _ptr(out), n))
+        return out
+
+    def ptcldist(self, ispecies=0, finish=True):
+        """(x,v) and v distributions of output_ptcldist, computed on the GPU"""
+        nxo, nvo = self.inp.nx_opd, self.inp.nv_opd
+        names = ("markr_xv", "total_xv", "pertb_xv", "markr_v", "total_v", "pertb_v")
+        out = [np.empty(nxo * nvo) for _ in range(3)] + [np.empty(nvo) for _ in range(3)]
+        check(self.L.pic1dp_hip_ptcldist(self._ctx, ispecies, int(finish), *[_ptr(a) for a in out]))
+        return dict(zip(names, out))
+
     # -- split-phase deposit -------------------------------------------------------
     def charge_local(self):
         out = np.empty(self.inp.nx)

@@ -1,0 +1,77 @@
+! host_output.F90 -- pic1dp.out in the reference's byte layout (PETSc binary
+! viewer: big-endian, int32 / float64; src/pic1dp_output.F90:74-92,173-186,
+! 457-474) and the stdout progress lines (:510-526), fed by the GPU engine.
+module pic1dp_host_output
+use iso_c_binding
+use pic1dp_hip
+implicit none
+
+integer, parameter :: output_unit_out = 71
+integer(c_int32_t), parameter :: vec_file_classid = 1211214
+
+contains
+
+subroutine output_init(inp)
+  type(pic1dp_input_t), intent(in) :: inp
+  open (output_unit_out, file='pic1dp.out', access='stream', form='unformatted', &
+    status='replace', convert='big_endian')
+  write (output_unit_out) inp%nspecies, inp%nmode, inp%nx, inp%nv, inp%nx_opd, inp%nv_opd, &
+    inp%modes(1 : inp%nmode)
+  write (output_unit_out) inp%lx, inp%v_max
+end subroutine output_init
+
+subroutine output_vec(a)
+  real(c_double), intent(in) :: a(:)
+  write (output_unit_out) vec_file_classid, int(size(a), c_int32_t)
+  write (output_unit_out) a
+end subroutine output_vec
+
+! output_field + output_ptcldist + output_progress(1)
+subroutine output_all(ctx, inp, verbosity)
+  type(c_ptr), intent(in) :: ctx
+  type(pic1dp_input_t), intent(in) :: inp
+  integer(c_int32_t), intent(in) :: verbosity
+  real(c_double) :: scal(2 + 3 * inp%nspecies)
+  real(c_double) :: e(inp%nx), cd(inp%nx), re(inp%nmode), im(inp%nmode)
+  real(c_double), allocatable :: mxv(:), txv(:), pxv(:), mv(:), tv(:), pv(:)
+  integer(c_int32_t) :: s, itime
+  real(c_double) :: time, progress(2)
+  character :: cprogress
+  integer :: nxv
+
+  call pic1dp_hip_check(pic1dp_hip_output_scalars(ctx, scal, int(size(scal), c_int32_t)), 'output_scalars')
+  write (output_unit_out) scal
+  call pic1dp_hip_check(pic1dp_hip_get_field(ctx, e, cd, re, im), 'get_field')
+  call output_vec(re)
+  call output_vec(im)
+  call output_vec(e)
+  call output_vec(cd)
+  nxv = inp%nx_opd * inp%nv_opd
+  allocate (mxv(nxv), txv(nxv), pxv(nxv), mv(inp%nv_opd), tv(inp%nv_opd), pv(inp%nv_opd))
+  do s = 0, inp%nspecies - 1
+    call pic1dp_hip_check(pic1dp_hip_ptcldist(ctx, s, 1_c_int32_t, mxv, txv, pxv, mv, tv, pv), 'ptcldist')
+    write (output_unit_out) mxv
+    write (output_unit_out) txv
+    write (output_unit_out) pxv
+    write (output_unit_out) mv
+    write (output_unit_out) tv
+    write (output_unit_out) pv
+  end do
+  if (verbosity == 1) then
+    call pic1dp_hip_check(pic1dp_hip_get_time(ctx, itime, time), 'get_time')
+    progress(1) = 1e2_c_double * real(itime, c_double) / inp%ntime_max
+    progress(2) = 1e2_c_double * time / inp%time_max
+    if (maxloc(progress, 1) == 1) then
+      cprogress = 'i'
+    else
+      cprogress = 't'
+    end if
+    write (*, '(a, f5.1, a, i7, f9.3, es12.3e3)') cprogress, maxval(progress), '%', itime, time, scal(2)
+  end if
+end subroutine output_all
+
+subroutine output_final
+  close (output_unit_out)
+end subroutine output_final
+
+end module pic1dp_host_output

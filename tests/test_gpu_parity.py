@@ -257,6 +257,7 @@ def test_fused_substep_equals_separate_calls(amd):
         e.particle_load()
         e.interaction_collect_charge()
         e.field_solve_electric()
+    b.set_electric(a.get_field()["electric"])   # atomics order: E may differ in the last bit
     for it in range(4):
         for irk in (1, 2):
             a.substep(irk)
@@ -373,6 +374,23 @@ def test_split_phase_charge(amd):
     b.charge_reduced(c2)
     assert relerr(b.get_field()["chargeden"], a.get_field()["chargeden"]) < CHARGE_RTOL
     assert np.array_equal(a.particles_download()["x"], b.particles_download()["x"])
+
+
+def test_rccl_allreduce_path_single_rank(oracle_mod, amd):
+    """a 1-rank RCCL communicator: exercises the run-time RCCL binding, the
+    unique-id hand-off and the split kernels (charge_local -> ncclAllReduce on
+    the engine's stream -> field solve) that N > 1 uses"""
+    sim, eng = pair(oracle_mod, amd, nparticle_max=100000, nx=64)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(uid)
+    with pytest.raises(amd.Pic1dpError):
+        eng.comm_init(uid)                   # only once
+    t, eo, eg = run_both(sim, eng, 40)
+    assert np.max(np.abs(eg / eo - 1.0)) < ENERGY_RTOL
+    eng.interaction_collect_charge()
+    sim.collect_charge()
+    assert relerr(eng.get_field()["chargeden"], sim.get_field()[1]) < CHARGE_RTOL
 
 
 def test_error_behaviour(amd):
