@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--threads", type=int, default=0, help="workgroup size of the particle kernels")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--unfused", action="store_true", help="time separate push / deposit kernels")
+    ap.add_argument("--step-mode", type=int, default=0, choices=[0, 1],
+                    help="0: whole-step kernels (half-step state recomputed); 1: two fused sub-steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles-per-core", type=int, default=2 * 10**6)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -142,6 +144,7 @@ def main():
     eng = pic1dp_amd.Pic1dp(inp, rank=rank, nranks=world, device=local_rank)
     if a.threads or a.blocks_per_cu:
         eng.set_launch(a.threads, a.blocks_per_cu)
+    eng.set_step_mode(a.step_mode)
     pic1dp_amd.parallel.bootstrap_comm(eng, dist)
     t0 = time.perf_counter()
     eng.particle_load()
@@ -195,15 +198,23 @@ def main():
     fused_ms, fused_n = eng.kernel_stats(0)
     push_ms, push_n = eng.kernel_stats(1)
     dep_ms, dep_n = eng.kernel_stats(2)
+    half_ms, half_n = eng.kernel_stats(3)
+    full_ms, full_n = eng.kernel_stats(4)
     energy = eng.field_energy()
     _, np_local = eng.local_sizes()
 
     if rank == 0:
         value = total * 2.0 * a.steps / elapsed
+        # dominant kernel of the path that ran; one launch = np_local particle-updates,
+        # algorithmic bytes 80 B per update whatever the kernel really moves
         if a.unfused:
-            kname, kms, kn, kbytes = "k_push (separate)", push_ms, push_n, 80.0
+            kname, kms, kn, path = "k_push (separate gather+push)", push_ms, push_n, "separate push / deposit kernels"
+        elif full_n:
+            kname, kms, kn = "k_step_full (2nd sub-step: recompute half-step state, push+gather, deposit)", full_ms, full_n
+            path = "whole-step kernels k_step_half + k_step_full (half-step state recomputed, not stored)"
         else:
-            kname, kms, kn, kbytes = "k_push<fused push+gather+deposit>", fused_ms, fused_n, ALG_BYTES_PER_UPDATE
+            kname, kms, kn, path = "k_push<fused push+gather+deposit>", fused_ms, fused_n, "two fused push+gather+deposit sub-steps"
+        kbytes = ALG_BYTES_PER_UPDATE
         avg_ms = kms / max(kn, 1)
         achieved = kbytes * np_local / (avg_ms * 1e-3) / 1e9 if kn else 0.0
         traffic = None
@@ -228,7 +239,7 @@ def main():
                 "particles_total": total, "particles_per_gpu": per_gpu, "nx": cfg["nx"],
                 "nmode": 1, "dt": 0.05,
                 "parallelism": "particle shard x%d, replicated grid, RCCL all-reduce of the charge vector" % world,
-                "path": "separate push/deposit kernels" if a.unfused else "fused push+gather+deposit kernel",
+                "path": path,
                 "sync": sync_kind, "load_seconds": load_s,
             },
             "roofline": {
@@ -237,6 +248,8 @@ def main():
                 "kernel": kname, "avg_launch_ms": avg_ms, "launches": kn,
                 "algorithmic_bytes_per_update": kbytes, "updates_per_launch": np_local,
                 "deposit_kernel_avg_ms": dep_ms / dep_n if dep_n else None,
+                "step_half_kernel_avg_ms": half_ms / half_n if half_n else None,
+                "step_half_kernel_algorithmic_GBs": (kbytes * np_local / (half_ms / half_n * 1e-3) / 1e9) if half_n else None,
             },
             "field_energy_end": energy,
         }

@@ -218,6 +218,17 @@ int pic1dp_hip_substep(pic1dp_ctx *ctx, int32_t irk);
  * (src/pic1dp.F90:79-93).  The field energy int E^2 dx after every step is
  * appended to a device-side history (see pic1dp_hip_energy_history). */
 int pic1dp_hip_step(pic1dp_ctx *ctx, int32_t nsteps);
+/* how pic1dp_hip_step advances a time step (results are bit-identical given
+ * identical fields; only the memory traffic differs):
+ *   0 (default) whole-step kernels: the half-step state is recomputed in the
+ *     second sub-step instead of being stored and re-read, state updated in place
+ *     (88 B per marker per step); falls back to mode 1 when nx is too large
+ *     for three grid tiles in LDS
+ *   1 two fused sub-steps through the RK ping-pong sets (136 B per marker) */
+int pic1dp_hip_set_step_mode(pic1dp_ctx *ctx, int32_t mode);
+/* field_electric as it was between the two sub-steps of the last time step
+ * taken by pic1dp_hip_step ([nx]) */
+int pic1dp_hip_get_field_half(pic1dp_ctx *ctx, double *electric_half);
 /* wait for everything enqueued on the context's stream */
 int pic1dp_hip_sync(pic1dp_ctx *ctx);
 
@@ -305,7 +316,8 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
 /* name and launch counters of the particle kernels, for bench.py's roofline:
  * accumulated device milliseconds (HIP events on the context's stream) and
  * launch count of the fused push+deposit kernel (which=0), the separate push
- * kernel (1) and the separate deposit kernel (2) */
+ * kernel (1), the separate deposit kernel (2), and the whole-step kernels:
+ * first sub-step k_step_half (3), second sub-step k_step_full (4) */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

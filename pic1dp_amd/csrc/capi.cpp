@@ -49,7 +49,8 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr double kPi = 3.14159265358979323846264;        // PETSC_PI
 constexpr double kSqrtEps = 1.490116119384766e-08;       // PETSC_SQRT_MACHINE_EPSILON
-constexpr int kTagFused = 100, kTagPush = 101, kTagDeposit = 102, kNumTags = 128;
+constexpr int kTagFused = 100, kTagPush = 101, kTagDeposit = 102, kTagStepHalf = 103, kTagStepFull = 104,
+              kNumTags = 128;
 constexpr int64_t kHistCap = 1 << 20;
 constexpr int kEnergyBlocks = 1024;
 
@@ -88,6 +89,8 @@ struct pic1dp_ctx {
   double *d_rho_sp = nullptr, *d_charge = nullptr, *d_chargeden = nullptr, *d_E = nullptr;
   double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
   double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
+  double *d_Eh = nullptr;  // field after the first sub-step of the last whole-step call
+  int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
   int64_t hist_count = 0;
   int32_t itime = 0;
   double time = 0.0;
@@ -509,6 +512,8 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMalloc(&c->d_charge, sizeof(double) * nx));
   HIP_TRY_C(hipMalloc(&c->d_chargeden, sizeof(double) * nx));
   HIP_TRY_C(hipMalloc(&c->d_E, sizeof(double) * nx));
+  HIP_TRY_C(hipMalloc(&c->d_Eh, sizeof(double) * nx));
+  HIP_TRY_C(hipMemsetAsync(c->d_Eh, 0, sizeof(double) * nx, c->st));
   HIP_TRY_C(hipMalloc(&c->d_mode_re, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_mode_im, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_fre, sizeof(double) * nm * nx));
@@ -591,7 +596,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     if (S.set[1].w != S.set[0].w) (void)hipFree(S.set[1].w);
   }
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
-                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist};
+                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh};
   for (double *b : bufs) (void)hipFree(b);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);
@@ -783,16 +788,111 @@ int pic1dp_hip_substep(pic1dp_ctx *c, int32_t irk) {
   return substep_impl(c, irk, false);
 }
 
+// LDS bytes of the whole-step kernels: E0 tile, Eh tile (full only), rho tile
+static size_t step_lds_bytes(int nx, bool full) {
+  const size_t ne = static_cast<size_t>((nx + 2) & ~1);
+  return sizeof(double) * ((full ? 2 : 1) * ne + nx);
+}
+
+static bool step_recompute_ok(const pic1dp_ctx *c) {
+  return c->step_mode == 0 && step_lds_bytes(c->in.nx, true) <= 160 * 1024;
+}
+
+static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
+  LaunchCfg lc{};
+  lc.lds = step_lds_bytes(c->in.nx, full);
+  int by_lds = static_cast<int>((160 * 1024) / lc.lds);
+  if (by_lds < 1) by_lds = 1;
+  int threads = c->threads_req > 0 ? c->threads_req : 512;
+  if (c->threads_req <= 0 && by_lds * threads < 2048) threads = 1024;
+  int bpc = 2048 / threads;
+  if (bpc > by_lds) bpc = by_lds;
+  if (c->bpc_req > 0) bpc = c->bpc_req < by_lds ? c->bpc_req : by_lds;
+  if (bpc < 1) bpc = 1;
+  int64_t blocks = static_cast<int64_t>(c->num_cu) * bpc;
+  const int64_t need = ((np >> 1) + threads - 1) / threads;
+  if (blocks > need) blocks = need;
+  if (blocks < 1) blocks = 1;
+  lc.threads = threads;
+  lc.blocks = static_cast<int>(blocks);
+  return lc;
+}
+
+// sub-step of the whole-step path: particle kernel(s), charge, field into Eout
+static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
+  for (int s = 0; s < c->in.nspecies; ++s) {
+    Species &S = c->sp[s];
+    if (S.np <= 0) continue;
+    StepArgs a{};
+    a.x = S.set[c->cur].x;
+    a.v = S.set[c->cur].v;
+    a.w = S.set[c->cur].w;
+    a.p = S.p;
+    a.E0 = c->d_E;
+    a.Eh = c->d_Eh;
+    a.rho = S.rho;
+    a.np = S.np;
+    a.dt_half = 0.5 * c->in.dt;  // src/pic1dp_interaction.F90:179
+    a.dt_full = c->in.dt;        // :192
+    a.g = c->grid;
+    a.s = S.sc;
+    a.iptcldist = c->in.iptcldist;
+    a.deltaf = c->in.deltaf;
+    a.linear = c->in.linear;
+    LaunchCfg lc = step_launch(c, S.np, full);
+    Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
+    Span ks(c, full ? kTagStepFull : kTagStepHalf, c->stats_on);
+    HIP_TRY(launch_step(a, full, lc, c->st));
+    if (int rc = ks.end()) return rc;
+    if (int rc = tm.end()) return rc;
+  }
+  const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
+  if (multi) {
+    HIP_TRY(launch_charge_local(c->fa, c->st));
+    if (int rc = allreduce_charge(c)) return rc;
+  }
+  Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
+  FieldArgs f = c->fa;
+  f.E = Eout;
+  if (record && c->hist_count < kHistCap) f.history = c->d_hist + c->hist_count++;
+  HIP_TRY(launch_field_solve(f, !multi, false, c->st));
+  return tm.end();
+}
+
 int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
   CHECK_CTX(c);
   if (nsteps < 0) return fail(PIC1DP_ERR_ARG, "nsteps < 0");
   if (int rc = require_loaded(c)) return rc;
+  const bool recompute = step_recompute_ok(c);
   for (int it = 0; it < nsteps; ++it) {
-    if (int rc = substep_impl(c, 1, false)) return rc;
-    if (int rc = substep_impl(c, 2, true)) return rc;
+    if (recompute) {
+      // E0 = d_E stays untouched until the second solve overwrites it
+      if (int rc = step_phase(c, false, c->d_Eh, false)) return rc;
+      if (int rc = step_phase(c, true, c->d_E, true)) return rc;
+    } else {
+      if (int rc = substep_impl(c, 1, false)) return rc;
+      HIP_TRY(hipMemcpyAsync(c->d_Eh, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
+      if (int rc = substep_impl(c, 2, true)) return rc;
+    }
     c->itime += 1;                  // src/pic1dp.F90:92
     c->time = c->time + c->in.dt;   // :93
   }
+  return 0;
+}
+
+int pic1dp_hip_set_step_mode(pic1dp_ctx *c, int32_t mode) {
+  CHECK_CTX(c);
+  if (mode != 0 && mode != 1) return fail(PIC1DP_ERR_ARG, "step mode must be 0 or 1");
+  c->step_mode = mode;
+  return 0;
+}
+
+int pic1dp_hip_get_field_half(pic1dp_ctx *c, double *electric_half) {
+  CHECK_CTX(c);
+  if (!electric_half) return fail(PIC1DP_ERR_ARG, "null array");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  HIP_TRY(hipMemcpy(electric_half, c->d_Eh, sizeof(double) * c->in.nx, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1179,7 +1279,7 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 2) return fail(PIC1DP_ERR_ARG, "which must be 0, 1 or 2");
+  if (which < 0 || which > 4) return fail(PIC1DP_ERR_ARG, "which must be 0..4");
   if (int rc = ev_resolve(c)) return rc;
   if (ms) *ms = c->acc_ms[kTagFused + which];
   if (launches) *launches = c->acc_n[kTagFused + which];

@@ -100,28 +100,29 @@ struct One {
   double x, v, w;
 };
 
-// gather + push of one marker, src/pic1dp_interaction.F90:246-338
+// gather + push of one marker, src/pic1dp_interaction.F90:246-338:
+// derivatives at (x, v, w), base (xb, vb, wb), field tile sE, step dt
 template <int DIST, int MODE, bool POW2>
 __device__ __forceinline__ One push_one(double x, double v, double w, double p, double xb,
-                                        double vb, double wb, const double *sE,
-                                        const PushArgs &a) {
+                                        double vb, double wb, const double *sE, double dt,
+                                        const GridConst &g, const SpeciesConst &s) {
   int ix;
   double wl;
-  locate(x, a.g, ix, wl);
+  locate(x, g, ix, wl);
   double e = sE[ix] * wl;                // :254
   e = e + sE[ix + 1] * (1.0 - wl);       // :257 (sE[nx] holds E[0])
   One o;
-  o.x = xb + a.dt * v;                   // :261
+  o.x = xb + dt * v;                     // :261
   o.w = w;
   if constexpr (MODE != MODE_FULLF) {
     const double tmp1 = (MODE == MODE_DF_LIN) ? p * e : (p - w) * e;   // :268-272
-    const double tmp2 = dlnf0<DIST, POW2>(v, a.s);
-    o.w = wb + divc<POW2>(a.dt * tmp1 * tmp2 * a.s.Z, a.s.m, a.s.r_m);  // :329
+    const double tmp2 = dlnf0<DIST, POW2>(v, s);
+    o.w = wb + divc<POW2>(dt * tmp1 * tmp2 * s.Z, s.m, s.r_m);  // :329
   }
   if constexpr (MODE == MODE_DF_LIN) {
     o.v = v;
   } else {
-    o.v = vb + divc<POW2>(a.dt * e * a.s.Z, a.s.m, a.s.r_m);  // :336
+    o.v = vb + divc<POW2>(dt * e * s.Z, s.m, s.r_m);  // :336
   }
   return o;
 }
@@ -191,8 +192,8 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
       if constexpr (PUSH_V) VB = bv2[j];
       if constexpr (HAS_W) WB = bw2[j];
     }
-    One o0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, XB.x, VB.x, WB.x, sE, a);
-    One o1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, XB.y, VB.y, WB.y, sE, a);
+    One o0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, XB.x, VB.x, WB.x, sE, a.dt, a.g, a.s);
+    One o1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, XB.y, VB.y, WB.y, sE, a.dt, a.g, a.s);
     if constexpr (FUSED) {
       o0.x = deposit_one(o0.x, HAS_W ? o0.w : P.x, sR, a.g);
       o1.x = deposit_one(o1.x, HAS_W ? o1.w : P.y, sR, a.g);
@@ -213,7 +214,7 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
       if constexpr (PUSH_V) vb = a.base.v[i];
       if constexpr (HAS_W) wb = a.base.w[i];
     }
-    One o = push_one<DIST, MODE, POW2>(x, v, w, p, xb, vb, wb, sE, a);
+    One o = push_one<DIST, MODE, POW2>(x, v, w, p, xb, vb, wb, sE, a.dt, a.g, a.s);
     if constexpr (FUSED) o.x = deposit_one(o.x, HAS_W ? o.w : p, sR, a.g);
     a.dst.x[i] = o.x;
     if constexpr (PUSH_V) a.dst.v[i] = o.v;
@@ -223,6 +224,161 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
     __syncthreads();
     flush_rho(sR, a.rho, nx);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Whole-time-step kernels (pic1dp_hip_step): the half-step state is never
+// written to memory.  RK2 (midpoint) needs, for the second sub-step, the state
+// after the first one; instead of storing it (24 B) and loading it back (24 B)
+// it is recomputed from the step-start state and the step-start field E0 with
+// the very same instruction sequence, hence bit-identical:
+//   k_step_half : x0,v0,w0,p (32 B in, 0 B out) -> half-step x', w' -> deposit
+//   k_step_full : x0,v0,w0,p (32 B in)          -> recompute x',v',w' from E0,
+//                 push from the base with the half-step field Eh, wrap, deposit,
+//                 store x,v,w in place (24 B out)
+// 88 B per marker per time step instead of 136 B (ping-pong) or the reference's
+// 256 B data flow; arithmetic per marker roughly doubles (still under the
+// FP64 rate at the HBM-bound pace).
+// ---------------------------------------------------------------------------
+struct StepArgsDev {
+  double *x, *v, *w;
+  const double *p;
+  const double *E0, *Eh;
+  double *rho;
+  int64_t np;
+  double dt_half, dt_full;
+  GridConst g;
+  SpeciesConst s;
+};
+
+template <int DIST, int MODE, bool POW2>
+__global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sE = reinterpret_cast<double *>(smem);
+  const int nx = a.g.nx;
+  double *sR = sE + ((nx + 2) & ~1);
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    sE[i] = a.E0[i];
+    sR[i] = 0.0;
+  }
+  if (threadIdx.x == 0) sE[nx] = a.E0[0];
+  __syncthreads();
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const double2 *x2 = reinterpret_cast<const double2 *>(a.x);
+  const double2 *v2 = reinterpret_cast<const double2 *>(a.v);
+  const double2 *w2 = reinterpret_cast<const double2 *>(a.w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+    const double2 X = x2[j], V = v2[j], P = p2[j];
+    double2 W = make_double2(0.0, 0.0);
+    if constexpr (HAS_W) W = w2[j];
+    const One h0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, X.x, V.x, W.x, sE, a.dt_half, a.g, a.s);
+    const One h1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, X.y, V.y, W.y, sE, a.dt_half, a.g, a.s);
+    deposit_one(h0.x, HAS_W ? h0.w : P.x, sR, a.g);
+    deposit_one(h1.x, HAS_W ? h1.w : P.y, sR, a.g);
+  }
+  if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = a.np - 1;
+    const double x = a.x[i], v = a.v[i], p = a.p[i];
+    const double w = HAS_W ? a.w[i] : 0.0;
+    const One h = push_one<DIST, MODE, POW2>(x, v, w, p, x, v, w, sE, a.dt_half, a.g, a.s);
+    deposit_one(h.x, HAS_W ? h.w : p, sR, a.g);
+  }
+  __syncthreads();
+  flush_rho(sR, a.rho, nx);
+}
+
+// one marker through the second half of the time step
+template <int DIST, int MODE, bool POW2>
+__device__ __forceinline__ One step_full_one(double x, double v, double w, double p, const double *sE0,
+                                             const double *sEh, double *sR, const StepArgsDev &a) {
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  // sub-step 1 again (identical arithmetic), with the wrap the deposit applied
+  One h = push_one<DIST, MODE, POW2>(x, v, w, p, x, v, w, sE0, a.dt_half, a.g, a.s);
+  h.x = wrap(h.x, a.g.lx);
+  // sub-step 2: derivatives at the half-step state, base = step-start state
+  One n = push_one<DIST, MODE, POW2>(h.x, h.v, h.w, p, x, v, w, sEh, a.dt_full, a.g, a.s);
+  n.x = deposit_one(n.x, HAS_W ? n.w : p, sR, a.g);
+  return n;
+}
+
+template <int DIST, int MODE, bool POW2>
+__global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nx = a.g.nx;
+  const int ne = (nx + 2) & ~1;
+  double *sE0 = reinterpret_cast<double *>(smem);
+  double *sEh = sE0 + ne;
+  double *sR = sEh + ne;
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    sE0[i] = a.E0[i];
+    sEh[i] = a.Eh[i];
+    sR[i] = 0.0;
+  }
+  if (threadIdx.x == 0) {
+    sE0[nx] = a.E0[0];
+    sEh[nx] = a.Eh[0];
+  }
+  __syncthreads();
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
+  const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double2 *x2 = reinterpret_cast<double2 *>(a.x);
+  double2 *v2 = reinterpret_cast<double2 *>(a.v);
+  double2 *w2 = reinterpret_cast<double2 *>(a.w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+    const double2 X = x2[j], V = v2[j], P = p2[j];
+    double2 W = make_double2(0.0, 0.0);
+    if constexpr (HAS_W) W = w2[j];
+    const One n0 = step_full_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a);
+    const One n1 = step_full_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a);
+    x2[j] = make_double2(n0.x, n1.x);
+    if constexpr (PUSH_V) v2[j] = make_double2(n0.v, n1.v);
+    if constexpr (HAS_W) w2[j] = make_double2(n0.w, n1.w);
+  }
+  if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = a.np - 1;
+    const double w = HAS_W ? a.w[i] : 0.0;
+    const One n = step_full_one<DIST, MODE, POW2>(a.x[i], a.v[i], w, a.p[i], sE0, sEh, sR, a);
+    a.x[i] = n.x;
+    if constexpr (PUSH_V) a.v[i] = n.v;
+    if constexpr (HAS_W) a.w[i] = n.w;
+  }
+  __syncthreads();
+  flush_rho(sR, a.rho, nx);
+}
+
+template <typename K>
+hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
+  if (lc.lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (idempotent, cheap)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(lc.blocks), dim3(lc.threads), lc.lds, st, d);
+  return hipGetLastError();
+}
+
+template <int DIST, int MODE, bool POW2>
+hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
+  return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2>, d, lc, st)
+              : launch_step_kernel(k_step_half<DIST, MODE, POW2>, d, lc, st);
+}
+
+template <int DIST>
+hipError_t launch_step_d(const StepArgsDev &d, int deltaf, int linear, bool full, const LaunchCfg &lc,
+                         hipStream_t st) {
+  const bool pow2 = d.s.pow2 != 0;
+  if (!deltaf) return launch_step_dmp<0, MODE_FULLF, true>(d, full, lc, st);
+  if (linear)
+    return pow2 ? launch_step_dmp<DIST, MODE_DF_LIN, true>(d, full, lc, st)
+                : launch_step_dmp<DIST, MODE_DF_LIN, false>(d, full, lc, st);
+  return pow2 ? launch_step_dmp<DIST, MODE_DF_NL, true>(d, full, lc, st)
+              : launch_step_dmp<DIST, MODE_DF_NL, false>(d, full, lc, st);
 }
 
 // stand-alone wrap + deposit (interaction_collect_charge loop :96-114)
@@ -301,6 +457,28 @@ hipError_t launch_push(const PushArgs &a, bool fused_deposit, const LaunchCfg &l
     case 2: return launch_push_d<2>(a, fused_deposit, lc, st);
     case 3: return launch_push_d<3>(a, fused_deposit, lc, st);
     default: return launch_push_d<0>(a, fused_deposit, lc, st);
+  }
+}
+
+hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStream_t st) {
+  StepArgsDev d{};
+  d.x = a.x;
+  d.v = a.v;
+  d.w = a.w;
+  d.p = a.p;
+  d.E0 = a.E0;
+  d.Eh = a.Eh;
+  d.rho = a.rho;
+  d.np = a.np;
+  d.dt_half = a.dt_half;
+  d.dt_full = a.dt_full;
+  d.g = a.g;
+  d.s = a.s;
+  switch (a.iptcldist) {
+    case 1: return launch_step_d<1>(d, a.deltaf, a.linear, full, lc, st);
+    case 2: return launch_step_d<2>(d, a.deltaf, a.linear, full, lc, st);
+    case 3: return launch_step_d<3>(d, a.deltaf, a.linear, full, lc, st);
+    default: return launch_step_d<0>(d, a.deltaf, a.linear, full, lc, st);
   }
 }
 

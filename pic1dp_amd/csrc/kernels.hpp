@@ -51,6 +51,23 @@ struct LaunchCfg {
   size_t lds;    // dynamic LDS bytes
 };
 
+// whole-time-step path: state updated in place, half-step state recomputed
+struct StepArgs {
+  double *x, *v, *w;   // particle_x/v/w, updated in place by the full kernel
+  const double *p;
+  const double *E0;    // field at the start of the step
+  const double *Eh;    // field after the first sub-step (full kernel only)
+  double *rho;         // this species' charge accumulator
+  int64_t np;
+  double dt_half, dt_full;
+  GridConst g;
+  SpeciesConst s;
+  int iptcldist, deltaf, linear;
+};
+// full = false: first sub-step (deposit of the half-step state, nothing stored)
+// full = true : second sub-step (recompute half-step state, push, deposit, store)
+hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStream_t st);
+
 // push (+gather) with or without the fused wrap+deposit
 hipError_t launch_push(const PushArgs &a, bool fused_deposit, const LaunchCfg &lc, hipStream_t st);
 // wrap + deposit of q (= w or p) at x, x stored back

@@ -134,6 +134,17 @@ class Pic1dp:
     def sync(self):
         check(self.L.pic1dp_hip_sync(self._ctx))
 
+    def set_step_mode(self, mode):
+        """0: whole-step kernels (half-step state recomputed, default);
+        1: two fused sub-steps through the RK ping-pong sets"""
+        check(self.L.pic1dp_hip_set_step_mode(self._ctx, mode))
+
+    def get_field_half(self):
+        """field_electric between the two sub-steps of the last step()"""
+        E = np.empty(self.inp.nx)
+        check(self.L.pic1dp_hip_get_field_half(self._ctx, _ptr(E)))
+        return E
+
     # -- driver scalars (global_itime, global_time) -----------------------------
     @property
     def itime(self):

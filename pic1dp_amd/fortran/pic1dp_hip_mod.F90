@@ -188,6 +188,18 @@ interface
     integer(c_int32_t), value :: nsteps
     integer(c_int) :: ierr
   end function pic1dp_hip_step
+  function pic1dp_hip_set_step_mode(ctx, mode) bind(C, name="pic1dp_hip_set_step_mode") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: mode
+    integer(c_int) :: ierr
+  end function pic1dp_hip_set_step_mode
+  function pic1dp_hip_get_field_half(ctx, electric_half) bind(C, name="pic1dp_hip_get_field_half") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    real(c_double), intent(inout) :: electric_half(*)
+    integer(c_int) :: ierr
+  end function pic1dp_hip_get_field_half
   function pic1dp_hip_sync(ctx) bind(C, name="pic1dp_hip_sync") result(ierr)
     import
     type(c_ptr), value :: ctx

@@ -273,6 +273,65 @@ def test_fused_substep_equals_separate_calls(amd):
         assert np.array_equal(ga[k], gb[k]), k
 
 
+STEP_CASES = [(n, kw, lin) for n, kw in DIST_CASES for lin in (0, 1)] + [
+    ("full_f", dict(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0]), 0)]
+
+
+@pytest.mark.parametrize("name,kw,linear", STEP_CASES, ids=lambda v: str(v) if not isinstance(v, dict) else "")
+def test_whole_step_recompute_equals_substeps(amd, name, kw, linear):
+    """pic1dp_hip_step's default path never stores the half-step state: the
+    second kernel recomputes it from the step-start state and field.  Given the
+    same two fields it must reproduce the two-sub-step path bit for bit."""
+    inp = amd.make_input(nparticle_max=N_SMALL, nx=96, linear=linear, **kw)
+    a, b = amd.Pic1dp(inp), amd.Pic1dp(inp)
+    for e in (a, b):
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+    b.set_electric(a.get_field()["electric"])
+    for it in range(3):
+        a.step(1)                                   # whole-step kernels
+        b.substep(1)                                # materialised half-step state
+        assert relerr(b.get_field()["electric"], a.get_field_half()) < 1e-10
+        b.set_electric(a.get_field_half())
+        b.substep(2)
+        assert relerr(b.get_field()["electric"], a.get_field()["electric"]) < 1e-10
+        b.set_electric(a.get_field()["electric"])
+        ga, gb = a.particles_download(), b.particles_download()
+        for k in "xvw":
+            assert np.array_equal(ga[k], gb[k]), (k, it)
+    # and the explicit two-sub-step mode of step() is the same thing as substep()
+    c = amd.Pic1dp(inp)
+    c.particle_load()
+    c.interaction_collect_charge()
+    c.field_solve_electric()
+    c.set_step_mode(1)
+    c.step(1)
+    assert relerr(c.get_field()["electric"], a.get_field()["electric"]) < 1.0  # ran
+    assert c.itime == 1
+
+
+def test_whole_step_falls_back_for_large_grids(oracle_mod, amd):
+    """nx = 8192 needs 196 KB for three grid tiles: step() uses the ping-pong
+    sub-steps instead and still matches the oracle"""
+    sim, eng = pair(oracle_mod, amd, nparticle_max=50000, nx=8192)
+    t, eo, eg = run_both(sim, eng, 10)
+    assert np.max(np.abs(eg / eo - 1.0)) < ENERGY_RTOL
+    sim, eng = pair(oracle_mod, amd, nparticle_max=50000, nx=4096)      # 3 tiles fit: recompute path
+    t, eo, eg = run_both(sim, eng, 10)
+    assert np.max(np.abs(eg / eo - 1.0)) < ENERGY_RTOL
+
+
+def test_step_modes_agree_with_oracle(oracle_mod, amd):
+    for mode in (0, 1):
+        sim, eng = pair(oracle_mod, amd, nparticle_max=100000, nx=64)
+        eng.set_step_mode(mode)
+        t, eo, eg = run_both(sim, eng, 60)
+        assert np.max(np.abs(eg / eo - 1.0)) < ENERGY_RTOL, mode
+        g = eng.particles_download()
+        assert np.max(np.abs(g["x"] - sim.gather("x"))) < 1e-9
+
+
 def run_both(sim, eng, nsteps):
     sim.collect_charge()
     sim.solve_field()
@@ -423,6 +482,10 @@ def test_timers_and_kernel_stats(amd):
     eng.field_solve_electric()
     eng.timers_enable(True)
     eng.kernel_stats_enable(True)
+    eng.step(5)
+    (ms3, n3), (ms4, n4) = eng.kernel_stats(3), eng.kernel_stats(4)
+    assert n3 == 5 and n4 == 5 and 0.0 < ms3 < ms4      # k_step_half, k_step_full
+    eng.set_step_mode(1)
     eng.step(5)
     ms, n = eng.kernel_stats(0)
     assert n == 10 and ms > 0.0
