@@ -217,6 +217,8 @@ def main():
         kbytes = ALG_BYTES_PER_UPDATE
         avg_ms = kms / max(kn, 1)
         achieved = kbytes * np_local / (avg_ms * 1e-3) / 1e9 if kn else 0.0
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes
+        # (profiles/summarize_pmc.py; FETCH_SIZE doubled per MI355X_MICROARCH.md)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -224,9 +226,15 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("particles_per_gpu") == per_gpu and tj.get("nx") == cfg["nx"]:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    key = "k_push" if (a.unfused or not full_n) else "k_step_full"
+                    traffic = tj.get("hbm_bytes_per_launch_by_kernel", {}).get(key)
             except (OSError, ValueError):
                 pass
+        # the box's own streaming rates (second denominator): plain copy
+        # and the dominant kernel's traffic shape (4 arrays read, 3 written)
+        probe_n = int(min(np_local, 10**8))
+        copy_gbs = max(eng.stream_probe(1, 1, probe_n, 10) for _ in range(3))
+        shape_gbs = max(eng.stream_probe(4, 3, probe_n, 10) for _ in range(3))
         out = {
             "metric": "particle-updates/sec", "value": value, "unit": "updates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -250,6 +258,8 @@ def main():
                 "deposit_kernel_avg_ms": dep_ms / dep_n if dep_n else None,
                 "step_half_kernel_avg_ms": half_ms / half_n if half_n else None,
                 "step_half_kernel_algorithmic_GBs": (kbytes * np_local / (half_ms / half_n * 1e-3) / 1e9) if half_n else None,
+                "measured_copy_GBs": copy_gbs, "measured_4read_3write_GBs": shape_gbs,
+                "traffic_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and kn) else None,
             },
             "field_energy_end": energy,
         }

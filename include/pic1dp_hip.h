@@ -160,6 +160,14 @@ int pic1dp_hip_host_multirand_int64(int32_t al_int, int32_t seed_type, int32_t m
                                     int32_t warmup, int32_t selftest, int64_t *out,
                                     int64_t n);
 
+/* self-check of the kernels' division by the constant lx (reciprocal + two FMA
+ * corrections, see kernels.hip div_lx) against the IEEE quotient on n generated
+ * positions (uniform, cell boundaries +- a few ulp, wide exponent range):
+ * *mismatches counts results differing in any bit.  host_: same algorithm with
+ * the host's fma(); debug_: on the device, against the hardware division. */
+int pic1dp_hip_host_div_check(double lx, int32_t nx, int64_t n, uint64_t seed,
+                              int64_t *mismatches);
+
 /* ---- life cycle -------------------------------------------------------
  * create  <-> input_init + particle_init + field_init
  *             (src/pic1dp.F90:57-59; src/pic1dp_particle.F90:66-139;
@@ -281,6 +289,18 @@ int pic1dp_hip_output_scalars(pic1dp_ctx *ctx, double *out, int32_t n);
 int pic1dp_hip_ptcldist(pic1dp_ctx *ctx, int32_t ispecies, int32_t finish,
                         double *markr_xv, double *total_xv, double *pertb_xv,
                         double *markr_v, double *total_v, double *pertb_v);
+
+int pic1dp_hip_debug_div_check(pic1dp_ctx *ctx, int64_t n, uint64_t seed,
+                               int64_t *mismatches);
+/* measured streaming bandwidth of this GPU with the particle kernels' access
+ * pattern (16 B per lane, grid-stride, the context's launch shape): nread
+ * (1, 4 or 7) arrays of n doubles read and nwrite (0, 1 or 3) written per pass,
+ * reps passes timed with HIP events; result in GB/s.  (4,0), (4,3) and (7,3)
+ * are the traffic shapes of k_step_half, k_step_full and the fused sub-step 2;
+ * (1,1) is a plain copy.  Gives the "achievable" denominator beside the 8 TB/s
+ * nominal peak. */
+int pic1dp_hip_stream_probe(pic1dp_ctx *ctx, int32_t nread, int32_t nwrite, int64_t n,
+                            int32_t reps, double *gbytes_per_s);
 
 /* ---- split-phase deposit for a host that owns the reduction (MPI) ------
  * charge_local: everything of collect_charge up to the all-reduce

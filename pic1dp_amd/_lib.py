@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpic1dp_hip.so")
+# PIC1DP_LIB: alternative build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("PIC1DP_LIB") or os.path.join(HERE, "lib", "libpic1dp_hip.so")
 
 MAX_SPECIES = 8
 MAX_MODES = 64
@@ -73,6 +74,9 @@ SIGNATURES = {
                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "pic1dp_hip_host_particle_load": [_INP, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64],
     "pic1dp_hip_host_multirand_int64": [C.c_int32] * 5 + [_P, C.c_int64],
+    "pic1dp_hip_host_div_check": [C.c_double, C.c_int32, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
+    "pic1dp_hip_debug_div_check": [_P, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
+    "pic1dp_hip_stream_probe": [_P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _D],
     "pic1dp_hip_create": [_INP, C.POINTER(Layout), C.POINTER(_P)],
     "pic1dp_hip_destroy": [_P],
     "pic1dp_hip_local_sizes": [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],

@@ -48,14 +48,18 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    tmp = LIB + ".tmp.%d" % os.getpid()
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + [
+    # tuning builds: PIC1DP_EXTRA_FLAGS="-DPIC1DP_NT=0" PIC1DP_LIB_OUT=/path/variant.so
+    # (load one with PIC1DP_LIB=/path/variant.so)
+    out = os.environ.get("PIC1DP_LIB_OUT") or LIB
+    extra = os.environ.get("PIC1DP_EXTRA_FLAGS", "").split()
+    tmp = out + ".tmp.%d" % os.getpid()
+    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + [
         "-o", tmp, "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    os.replace(tmp, LIB)
-    return LIB
+    os.replace(tmp, out)
+    return out
 
 
 if __name__ == "__main__":

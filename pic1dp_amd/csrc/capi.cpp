@@ -201,6 +201,9 @@ SpeciesConst make_species_const(const pic1dp_input &in, int s) {
   c.r_stm2 = 1.0 / c.stm2;
   c.pow2 = is_pow2(c.m) && is_pow2(T) && is_pow2(c.tm) && is_pow2(c.tm2) && is_pow2(c.two_tm) &&
            is_pow2(c.two_tm2) && is_pow2(c.stm) && is_pow2(c.stm2);
+  c.unit = c.m == 1.0 && T == 1.0 && T2 == 1.0 && c.tm == 1.0 && c.tm2 == 1.0 && c.stm == 1.0 &&
+           c.stm2 == 1.0 && c.two_tm == 2.0 && c.two_tm2 == 2.0;
+  if (const char *e = std::getenv("PIC1DP_UNIT_SPECIALISATION")) c.unit = c.unit && std::atoi(e) != 0;
   return c;
 }
 
@@ -429,6 +432,12 @@ int pic1dp_hip_host_multirand_int64(int32_t al_int, int32_t seed_type, int32_t m
   return 0;
 }
 
+int pic1dp_hip_host_div_check(double lx, int32_t nx, int64_t n, uint64_t seed, int64_t *mismatches) {
+  if (!mismatches || !(lx > 0.0) || nx < 1 || n < 0) return fail(PIC1DP_ERR_ARG, "bad argument");
+  *mismatches = host_div_check(lx, nx, seed, n);
+  return 0;
+}
+
 int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1dp_ctx **out) {
   if (!in || !layout || !out) return fail(PIC1DP_ERR_ARG, "null argument");
   *out = nullptr;
@@ -475,6 +484,9 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   c->grid.dnx = static_cast<double>(nx);
   c->grid.dt_full = in->dt;
   c->grid.nx = nx;
+  c->grid.rlx = 1.0 / in->lx;
+  c->grid.fast_div = 1;
+  if (const char *e = std::getenv("PIC1DP_FAST_DIV")) c->grid.fast_div = std::atoi(e) != 0;
 
   // particle storage: valid markers of the owned blocks packed first, block
   // tails (allocated but unloaded slots) behind them
@@ -1167,6 +1179,64 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *mark
   give(markr_v, mv, nvo);
   give(total_v, tv, nvo);
   give(pertb_v, pv, nvo);
+  return 0;
+}
+
+int pic1dp_hip_stream_probe(pic1dp_ctx *c, int32_t nread, int32_t nwrite, int64_t n, int32_t reps,
+                            double *gbytes_per_s) {
+  CHECK_CTX(c);
+  if (!gbytes_per_s || n < 2 || reps < 1) return fail(PIC1DP_ERR_ARG, "bad argument");
+  if ((nread != 1 && nread != 4 && nread != 7) || (nwrite != 0 && nwrite != 1 && nwrite != 3))
+    return fail(PIC1DP_ERR_ARG, "nread must be 1, 4 or 7 and nwrite 0, 1 or 3");
+  HIP_TRY(hipSetDevice(c->device));
+  const int nbuf = nread + (nwrite > 0 ? nwrite : 1);
+  double *base = nullptr;
+  HIP_TRY(hipMalloc(&base, sizeof(double) * static_cast<size_t>(n) * nbuf));
+  int rc = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  do {
+    hipError_t e = hipMemsetAsync(base, 0, sizeof(double) * static_cast<size_t>(n) * nbuf, c->st);
+    double *in[8] = {nullptr}, *out[4] = {nullptr};
+    for (int k = 0; k < nread; ++k) in[k] = base + static_cast<size_t>(k) * n;
+    for (int k = 0; k < (nwrite > 0 ? nwrite : 1); ++k) out[k] = base + static_cast<size_t>(nread + k) * n;
+    LaunchCfg lc = particle_launch(c, n, false, false);
+    // non-temporal accesses like the particle kernels; PIC1DP_PROBE_VARIANT (tuning
+    // only): 0 plain, 1 non-temporal, 2 plain with two pairs per lane
+    int variant = 1;
+    if (const char *ev = std::getenv("PIC1DP_PROBE_VARIANT")) variant = std::atoi(ev);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = launch_stream_probe(in, nread, out, nwrite, n, lc.blocks, lc.threads, variant, c->st);  // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, c->st);
+    for (int r = 0; r < reps && e == hipSuccess; ++r)
+      e = launch_stream_probe(in, nread, out, nwrite, n, lc.blocks, lc.threads, variant, c->st);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) {
+      rc = fail(PIC1DP_ERR_HIP, "stream probe: %s", hipGetErrorString(e));
+      break;
+    }
+    *gbytes_per_s = 8.0 * static_cast<double>(n) * (nread + nwrite) * reps / (ms * 1e-3) / 1e9;
+  } while (false);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(base);
+  return rc;
+}
+
+int pic1dp_hip_debug_div_check(pic1dp_ctx *c, int64_t n, uint64_t seed, int64_t *mismatches) {
+  CHECK_CTX(c);
+  if (!mismatches || n < 0) return fail(PIC1DP_ERR_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(c->d_scratch);
+  HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->st));
+  HIP_TRY(launch_div_check(c->grid, seed, n, d, c->st));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  unsigned long long h = 0;
+  HIP_TRY(hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost));
+  *mismatches = static_cast<int64_t>(h);
   return 0;
 }
 

@@ -13,11 +13,22 @@
 //  * Deposition accumulates into a per-workgroup LDS copy of rho with
 //    ds_add_f64, and is flushed with one global_atomic_add_f64 per cell per
 //    workgroup, start cell staggered by workgroup to spread contention.
-//  * RK2 uses two particle sets (ping-pong): sub-step 1 reads the step-start
-//    set and writes the half-step set; sub-step 2 reads both and overwrites
-//    the step-start set.  The reference's x_bak/v_bak/w_bak copies
+//  * Sub-step kernels (k_push, k_deposit; the drop-in call sites) use two
+//    particle sets (ping-pong): sub-step 1 reads the step-start set and writes
+//    the half-step set; sub-step 2 reads both and overwrites the step-start
+//    set.  The reference's x_bak/v_bak/w_bak copies
 //    (src/pic1dp_interaction.F90:178-189) are never materialised.
+//  * Whole-step kernels (k_step_half, k_step_full; pic1dp_hip_step) go further:
+//    the half-step state is recomputed bit-identically in the second kernel
+//    instead of being stored and re-read, and the state is updated in place.
+//  * x/lx, evaluated three times per marker and step, uses a correctly rounded
+//    reciprocal-plus-two-FMA division (div_lx) instead of the hardware sequence;
+//    species whose divisor constants are powers of two (or all 1) multiply instead
+//    of dividing -- every shortcut is bit-identical to the true division.
 #include "kernels.hpp"
+
+#include <cmath>
+#include <cstring>
 
 namespace pic1dp {
 
@@ -34,21 +45,87 @@ __device__ __forceinline__ void glb_add(double *p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// a / c, or a * (1/c) when c is a power of two (bit-identical, cheaper)
-template <bool POW2>
+// Marker arrays are streamed: every element is touched once per kernel, so the
+// loads and stores carry the non-temporal hint (global_load/store_dwordx4 ... nt),
+// which on MI355X raises the streaming rate of these access shapes by 5-15 %
+// (tools/probe_sweep.py).  PIC1DP_NT=0 at compile time restores plain accesses.
+#ifndef PIC1DP_NT
+#define PIC1DP_NT 1
+#endif
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double2 ld2(const double2 *p) {
+#if PIC1DP_NT
+  const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+  return make_double2(t.x, t.y);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st2(double2 *p, double a, double b) {
+#if PIC1DP_NT
+  v2d t;
+  t.x = a;
+  t.y = b;
+  __builtin_nontemporal_store(t, reinterpret_cast<v2d *>(p));
+#else
+  *p = make_double2(a, b);
+#endif
+}
+
+// Division by a species constant c, bit-identical to a / c in all three forms:
+//   POW2 = 0  a / c             (general)
+//   POW2 = 1  a * (1/c)         (every divisor constant is a power of two)
+//   POW2 = 2  a                 (unit species: m = T = T2 = 1, so T/m = sqrt(T/m) = 1
+//                                and 2T/m = 2 -- the reference's default input)
+template <int POW2>
 __device__ __forceinline__ double divc(double a, double c, double rc) {
-  if constexpr (POW2) {
+  if constexpr (POW2 == 2) {
+    return a;
+  } else if constexpr (POW2 == 1) {
+    return a * rc;
+  } else {
+    return a / c;
+  }
+}
+// the same for the constants 2T/m, 2T2/m (= 2 for a unit species)
+template <int POW2>
+__device__ __forceinline__ double divh(double a, double c, double rc) {
+  if constexpr (POW2 == 2) {
+    return a * 0.5;
+  } else if constexpr (POW2 == 1) {
     return a * rc;
   } else {
     return a / c;
   }
 }
 
+// x / lx, correctly rounded, without the hardware division sequence.
+// y = RN(1/lx).  q0 = RN(x*y) is within 2 ulp of x/lx; one FMA correction
+// (r0 = x - lx*q0, q1 = RN(q0 + r0*y)) makes it faithful; by Markstein's theorem
+// (faithful q, |y - 1/b| < 2^-53/b, r = a - b*q exact, q' = RN(q + r*y)  =>
+// q' = RN(a/b)) the second correction returns exactly RN(x/lx), the value the
+// reference's division produces.  5 full-rate FP64 ops instead of ~14 slots.
+// Tiny / huge / zero operands (outside the theorem's no-underflow premise) take
+// the hardware division.  tests: test_exact_division_by_lx (GPU and host).
+__device__ __forceinline__ double div_lx(double x, const GridConst &g) {
+  const double ax = fabs(x);
+  if (g.fast_div && ax > 0x1p-500 && ax < 0x1p+500) {
+    const double y = g.rlx;
+    const double q0 = x * y;
+    const double r0 = fma(-g.lx, q0, x);
+    const double q1 = fma(r0, y, q0);
+    const double r1 = fma(-g.lx, q1, x);
+    return fma(r1, y, q1);
+  }
+  return x / g.lx;
+}
+
 // cell index and left weight of position x (already inside [0, lx]):
 // sx = x/lx*nx; ix = floor(sx); wl = 1 - (sx - ix)
 // src/pic1dp_interaction.F90:106-108 and :250-252
 __device__ __forceinline__ void locate(double x, const GridConst &g, int &ix, double &wl) {
-  const double s = x / g.lx * g.dnx;
+  const double s = div_lx(x, g) * g.dnx;
   const double fl = floor(s);
   ix = static_cast<int>(fl);
   wl = 1.0 - (s - fl);
@@ -72,20 +149,20 @@ __device__ __forceinline__ double wrap(double x, double lx) {
 }
 
 // -(d f0/dv)/f0 at v, src/pic1dp_interaction.F90:274-326
-template <int DIST, bool POW2>
+template <int DIST, int POW2>
 __device__ __forceinline__ double dlnf0(double v, const SpeciesConst &c) {
   if constexpr (DIST == 1) {  // two-stream1 :276
     return v - 2.0 / v;
   } else if constexpr (DIST == 2) {  // two-stream2 :278-292
     const double vp = v + c.v0, vm = v - c.v0;
-    const double ep = exp(-divc<POW2>(vp * vp, c.two_tm, c.r_two_tm));
-    const double em = exp(-divc<POW2>(vm * vm, c.two_tm, c.r_two_tm));
+    const double ep = exp(-divh<POW2>(vp * vp, c.two_tm, c.r_two_tm));
+    const double em = exp(-divh<POW2>(vm * vm, c.two_tm, c.r_two_tm));
     const double q = (vp * ep + vm * em) / (ep + em);
     return divc<POW2>(q * c.m, c.T, c.r_T);
   } else if constexpr (DIST == 3) {  // bump-on-tail :294-321
     const double vm = v - c.v0;
-    const double e1 = exp(-divc<POW2>(v * v, c.two_tm, c.r_two_tm));
-    const double e2 = exp(-divc<POW2>(vm * vm, c.two_tm2, c.r_two_tm2));
+    const double e1 = exp(-divh<POW2>(v * v, c.two_tm, c.r_two_tm));
+    const double e2 = exp(-divh<POW2>(vm * vm, c.two_tm2, c.r_two_tm2));
     const double a = divc<POW2>(divc<POW2>(c.den * v, c.tm, c.r_tm) * e1, c.stm, c.r_stm);
     const double b = divc<POW2>(divc<POW2>(c.beam * vm, c.tm2, c.r_tm2) * e2, c.stm2, c.r_stm2);
     const double cc = divc<POW2>(c.den * e1, c.stm, c.r_stm);
@@ -102,7 +179,7 @@ struct One {
 
 // gather + push of one marker, src/pic1dp_interaction.F90:246-338:
 // derivatives at (x, v, w), base (xb, vb, wb), field tile sE, step dt
-template <int DIST, int MODE, bool POW2>
+template <int DIST, int MODE, int POW2>
 __device__ __forceinline__ One push_one(double x, double v, double w, double p, double xb,
                                         double vb, double wb, const double *sE, double dt,
                                         const GridConst &g, const SpeciesConst &s) {
@@ -152,7 +229,7 @@ __device__ __forceinline__ void flush_rho(const double *sR, double *rho, int nx)
   }
 }
 
-template <int DIST, int MODE, bool POW2, bool IRK2, bool FUSED>
+template <int DIST, int MODE, int POW2, bool IRK2, bool FUSED>
 __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *sE = reinterpret_cast<double *>(smem);
@@ -182,15 +259,15 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
 
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair;
        j += stride) {
-    const double2 X = sx2[j], V = sv2[j];
+    const double2 X = ld2(sx2 + j), V = ld2(sv2 + j);
     double2 W = make_double2(0.0, 0.0), P = make_double2(0.0, 0.0);
-    if constexpr (HAS_W) W = sw2[j];
-    if constexpr (MODE != MODE_FULLF || FUSED) P = p2[j];
+    if constexpr (HAS_W) W = ld2(sw2 + j);
+    if constexpr (MODE != MODE_FULLF || FUSED) P = ld2(p2 + j);
     double2 XB = X, VB = V, WB = W;
     if constexpr (IRK2) {
-      XB = bx2[j];
-      if constexpr (PUSH_V) VB = bv2[j];
-      if constexpr (HAS_W) WB = bw2[j];
+      XB = ld2(bx2 + j);
+      if constexpr (PUSH_V) VB = ld2(bv2 + j);
+      if constexpr (HAS_W) WB = ld2(bw2 + j);
     }
     One o0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, XB.x, VB.x, WB.x, sE, a.dt, a.g, a.s);
     One o1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, XB.y, VB.y, WB.y, sE, a.dt, a.g, a.s);
@@ -198,9 +275,9 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
       o0.x = deposit_one(o0.x, HAS_W ? o0.w : P.x, sR, a.g);
       o1.x = deposit_one(o1.x, HAS_W ? o1.w : P.y, sR, a.g);
     }
-    dx2[j] = make_double2(o0.x, o1.x);
-    if constexpr (PUSH_V) dv2[j] = make_double2(o0.v, o1.v);
-    if constexpr (HAS_W) dw2[j] = make_double2(o0.w, o1.w);
+    st2(dx2 + j, o0.x, o1.x);
+    if constexpr (PUSH_V) st2(dv2 + j, o0.v, o1.v);
+    if constexpr (HAS_W) st2(dw2 + j, o0.w, o1.w);
   }
   // odd tail marker
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -251,7 +328,7 @@ struct StepArgsDev {
   SpeciesConst s;
 };
 
-template <int DIST, int MODE, bool POW2>
+template <int DIST, int MODE, int POW2>
 __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *sE = reinterpret_cast<double *>(smem);
@@ -271,9 +348,9 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   const double2 *w2 = reinterpret_cast<const double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
-    const double2 X = x2[j], V = v2[j], P = p2[j];
+    const double2 X = ld2(x2 + j), V = ld2(v2 + j), P = ld2(p2 + j);
     double2 W = make_double2(0.0, 0.0);
-    if constexpr (HAS_W) W = w2[j];
+    if constexpr (HAS_W) W = ld2(w2 + j);
     const One h0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, X.x, V.x, W.x, sE, a.dt_half, a.g, a.s);
     const One h1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, X.y, V.y, W.y, sE, a.dt_half, a.g, a.s);
     deposit_one(h0.x, HAS_W ? h0.w : P.x, sR, a.g);
@@ -291,7 +368,7 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
 }
 
 // one marker through the second half of the time step
-template <int DIST, int MODE, bool POW2>
+template <int DIST, int MODE, int POW2>
 __device__ __forceinline__ One step_full_one(double x, double v, double w, double p, const double *sE0,
                                              const double *sEh, double *sR, const StepArgsDev &a) {
   constexpr bool HAS_W = (MODE != MODE_FULLF);
@@ -304,7 +381,7 @@ __device__ __forceinline__ One step_full_one(double x, double v, double w, doubl
   return n;
 }
 
-template <int DIST, int MODE, bool POW2>
+template <int DIST, int MODE, int POW2>
 __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nx = a.g.nx;
@@ -331,14 +408,14 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
-    const double2 X = x2[j], V = v2[j], P = p2[j];
+    const double2 X = ld2(x2 + j), V = ld2(v2 + j), P = ld2(p2 + j);
     double2 W = make_double2(0.0, 0.0);
-    if constexpr (HAS_W) W = w2[j];
+    if constexpr (HAS_W) W = ld2(w2 + j);
     const One n0 = step_full_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a);
     const One n1 = step_full_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a);
-    x2[j] = make_double2(n0.x, n1.x);
-    if constexpr (PUSH_V) v2[j] = make_double2(n0.v, n1.v);
-    if constexpr (HAS_W) w2[j] = make_double2(n0.w, n1.w);
+    st2(x2 + j, n0.x, n1.x);
+    if constexpr (PUSH_V) st2(v2 + j, n0.v, n1.v);
+    if constexpr (HAS_W) st2(w2 + j, n0.w, n1.w);
   }
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = a.np - 1;
@@ -363,7 +440,7 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc,
   return hipGetLastError();
 }
 
-template <int DIST, int MODE, bool POW2>
+template <int DIST, int MODE, int POW2>
 hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
   return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2>, d, lc, st)
               : launch_step_kernel(k_step_half<DIST, MODE, POW2>, d, lc, st);
@@ -373,12 +450,17 @@ template <int DIST>
 hipError_t launch_step_d(const StepArgsDev &d, int deltaf, int linear, bool full, const LaunchCfg &lc,
                          hipStream_t st) {
   const bool pow2 = d.s.pow2 != 0;
-  if (!deltaf) return launch_step_dmp<0, MODE_FULLF, true>(d, full, lc, st);
+  // full-f evaluates no f0 derivative (one instantiation serves all DIST), but
+  // still divides by the mass in the v push
+  if (!deltaf)
+    return pow2 ? launch_step_dmp<0, MODE_FULLF, 1>(d, full, lc, st)
+                : launch_step_dmp<0, MODE_FULLF, 0>(d, full, lc, st);
   if (linear)
-    return pow2 ? launch_step_dmp<DIST, MODE_DF_LIN, true>(d, full, lc, st)
-                : launch_step_dmp<DIST, MODE_DF_LIN, false>(d, full, lc, st);
-  return pow2 ? launch_step_dmp<DIST, MODE_DF_NL, true>(d, full, lc, st)
-              : launch_step_dmp<DIST, MODE_DF_NL, false>(d, full, lc, st);
+    return pow2 ? launch_step_dmp<DIST, MODE_DF_LIN, 1>(d, full, lc, st)
+                : launch_step_dmp<DIST, MODE_DF_LIN, 0>(d, full, lc, st);
+  if (d.s.unit) return launch_step_dmp<DIST, MODE_DF_NL, 2>(d, full, lc, st);
+  return pow2 ? launch_step_dmp<DIST, MODE_DF_NL, 1>(d, full, lc, st)
+              : launch_step_dmp<DIST, MODE_DF_NL, 0>(d, full, lc, st);
 }
 
 // stand-alone wrap + deposit (interaction_collect_charge loop :96-114)
@@ -394,11 +476,11 @@ k_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst g
   const double2 *q2 = reinterpret_cast<const double2 *>(q);
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair;
        j += stride) {
-    double2 X = x2[j];
-    const double2 Q = q2[j];
+    double2 X = ld2(x2 + j);
+    const double2 Q = ld2(q2 + j);
     X.x = deposit_one(X.x, Q.x, sR, g);
     X.y = deposit_one(X.y, Q.y, sR, g);
-    x2[j] = X;
+    st2(x2 + j, X.x, X.y);
   }
   if ((np & 1) && blockIdx.x == 0 && threadIdx.x == 0)
     x[np - 1] = deposit_one(x[np - 1], q[np - 1], sR, g);
@@ -406,7 +488,7 @@ k_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst g
   flush_rho(sR, rho, g.nx);
 }
 
-template <int DIST, int MODE, bool POW2, bool IRK2, bool FUSED>
+template <int DIST, int MODE, int POW2, bool IRK2, bool FUSED>
 hipError_t launch_push_t(const PushArgs &a, const LaunchCfg &lc, hipStream_t st) {
   auto kern = k_push<DIST, MODE, POW2, IRK2, FUSED>;
   static bool big_lds_ok = false;  // opt in once to > 64 KiB of dynamic LDS (nx >= 4096)
@@ -420,7 +502,7 @@ hipError_t launch_push_t(const PushArgs &a, const LaunchCfg &lc, hipStream_t st)
   return hipGetLastError();
 }
 
-template <int DIST, int MODE, bool POW2>
+template <int DIST, int MODE, int POW2>
 hipError_t launch_push_dm(const PushArgs &a, bool fused, const LaunchCfg &lc, hipStream_t st) {
   const bool irk2 = a.irk == 2;
   if (irk2) {
@@ -443,8 +525,10 @@ hipError_t launch_push_d(const PushArgs &a, bool fused, const LaunchCfg &lc, hip
       return pow2 ? launch_push_dm<DIST, MODE_DF_LIN, true>(a, fused, lc, st)
                   : launch_push_dm<DIST, MODE_DF_LIN, false>(a, fused, lc, st);
     default:
-      // full-f evaluates no f0 derivative: one instantiation serves all DIST
-      return launch_push_dm<0, MODE_FULLF, true>(a, fused, lc, st);
+      // full-f evaluates no f0 derivative (one instantiation serves all DIST)
+      // but still divides by the mass in the v push
+      return pow2 ? launch_push_dm<0, MODE_FULLF, true>(a, fused, lc, st)
+                  : launch_push_dm<0, MODE_FULLF, false>(a, fused, lc, st);
   }
 }
 
@@ -838,6 +922,176 @@ hipError_t launch_ptcldist(const double *x, const double *v, const double *p, co
   };
   if (lds) return deltaf ? go(k_ptcldist<true, true>) : go(k_ptcldist<true, false>);
   return deltaf ? go(k_ptcldist<false, true>) : go(k_ptcldist<false, false>);
+}
+
+namespace {
+
+// test positions for div_lx: uniform over three periods, cell boundaries and
+// their neighbours (where a wrong last bit would change the cell index), raw
+// bit patterns over a wide exponent range, small and large magnitudes
+__host__ __device__ inline double div_check_value(uint64_t seed, int64_t i, double lx, int nx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ULL * static_cast<uint64_t>(i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  const double u = static_cast<double>(z >> 11) * 0x1p-53;  // [0,1)
+  const int kind = static_cast<int>(z & 7);
+  if (kind <= 2) return lx * (u * 3.0 - 1.0);
+  if (kind == 3 || kind == 4) {
+    const int k = static_cast<int>((z >> 3) % static_cast<uint64_t>(nx + 1));
+    double x = lx * static_cast<double>(k) / static_cast<double>(nx);
+    const int steps = static_cast<int>((z >> 40) & 7) - 3;  // -3..4 ulps around the boundary
+    union { double d; int64_t b; } c;
+    c.d = x;
+    if (x != 0.0) c.b += steps;
+    return c.d;
+  }
+  if (kind == 5) {
+    union { double d; uint64_t b; } c;
+    const uint64_t e = 1023 - 400 + (z >> 12) % 800;
+    c.b = (z & 0x800FFFFFFFFFFFFFULL) | (e << 52);
+    return c.d;
+  }
+  if (kind == 6) return lx * u * 0x1p-30;
+  return lx * (u - 0.5) * 1e6;
+}
+
+__global__ void k_div_check(GridConst g, uint64_t seed, int64_t n, unsigned long long *bad) {
+  GridConst gf = g;
+  gf.fast_div = 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double x = div_check_value(seed, i, g.lx, g.nx);
+    const double a = div_lx(x, gf), b = x / g.lx;
+    if (__double_as_longlong(a) != __double_as_longlong(b)) atomicAdd(bad, 1ULL);
+  }
+}
+
+}  // namespace
+
+namespace {
+
+// bandwidth probe with the access pattern of the particle kernels: NR input
+// streams and NW output streams of doubles, 16 B per lane, grid-stride
+struct ProbeArgs {
+  const double2 *in[8];
+  double2 *out[4];
+  int64_t npair;
+};
+
+template <int NR, int NW, int VARIANT>
+__global__ void __launch_bounds__(1024) k_stream_probe(const ProbeArgs a) {
+  // VARIANT 0: plain loads/stores; 1: non-temporal; 2: plain, two pairs per lane per trip
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double2 acc = make_double2(0.0, 0.0);
+  constexpr int U = VARIANT == 2 ? 2 : 1;
+  for (int64_t j0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j0 < a.npair; j0 += U * stride) {
+    double2 s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s[u] = make_double2(0.0, 0.0);
+      const int64_t j = j0 + u * stride;
+      if (j < a.npair) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          double2 t;
+          if constexpr (VARIANT == 1) {
+            t.x = __builtin_nontemporal_load(&a.in[k][j].x);
+            t.y = __builtin_nontemporal_load(&a.in[k][j].y);
+          } else {
+            t = a.in[k][j];
+          }
+          s[u].x += t.x;
+          s[u].y += t.y;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = j0 + u * stride;
+      if (j < a.npair) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+          if constexpr (VARIANT == 1) {
+            __builtin_nontemporal_store(s[u].x + k, &a.out[k][j].x);
+            __builtin_nontemporal_store(s[u].y - k, &a.out[k][j].y);
+          } else {
+            a.out[k][j] = make_double2(s[u].x + k, s[u].y - k);
+          }
+        }
+      }
+      if constexpr (NW == 0) {
+        acc.x += s[u].x;
+        acc.y += s[u].y;
+      }
+    }
+  }
+  if constexpr (NW == 0) {
+    if (acc.x == 1.2345e300 && acc.y == -1.2345e300) a.out[0][0] = acc;  // keeps the loads alive
+  }
+}
+
+template <int NR, int NW>
+hipError_t launch_probe_v(const ProbeArgs &a, int variant, int blocks, int threads, hipStream_t st) {
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((k_stream_probe<NR, NW, 1>), dim3(blocks), dim3(threads), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_stream_probe<NR, NW, 2>), dim3(blocks), dim3(threads), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_stream_probe<NR, NW, 0>), dim3(blocks), dim3(threads), 0, st, a); break;
+  }
+  return hipGetLastError();
+}
+
+template <int NR>
+hipError_t launch_probe_nr(const ProbeArgs &a, int nw, int variant, int blocks, int threads, hipStream_t st) {
+  switch (nw) {
+    case 0: return launch_probe_v<NR, 0>(a, variant, blocks, threads, st);
+    case 1: return launch_probe_v<NR, 1>(a, variant, blocks, threads, st);
+    case 3: return launch_probe_v<NR, 3>(a, variant, blocks, threads, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_stream_probe(double *const *in, int nr, double *const *out, int nw, int64_t n,
+                               int blocks, int threads, int variant, hipStream_t st) {
+  ProbeArgs a{};
+  for (int k = 0; k < nr && k < 8; ++k) a.in[k] = reinterpret_cast<const double2 *>(in[k]);
+  for (int k = 0; k < 4; ++k) a.out[k] = reinterpret_cast<double2 *>(out[k < nw ? k : 0]);
+  a.npair = n >> 1;
+  switch (nr) {
+    case 1: return launch_probe_nr<1>(a, nw, variant, blocks, threads, st);
+    case 4: return launch_probe_nr<4>(a, nw, variant, blocks, threads, st);
+    case 7: return launch_probe_nr<7>(a, nw, variant, blocks, threads, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_div_check(const GridConst &g, uint64_t seed, int64_t n, unsigned long long *bad,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(k_div_check, dim3(2048), dim3(256), 0, st, g, seed, n, bad);
+  return hipGetLastError();
+}
+
+// the same check with the host's FMA (libm fma is exact): div_lx's algorithm
+int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n) {
+  const double y = 1.0 / lx;
+  int64_t bad = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double x = div_check_value(seed, i, lx, nx);
+    const double ax = fabs(x);
+    double a;
+    if (ax > 0x1p-500 && ax < 0x1p+500) {
+      const double q0 = x * y;
+      const double q1 = fma(fma(-lx, q0, x), y, q0);
+      a = fma(fma(-lx, q1, x), y, q1);
+    } else {
+      a = x / lx;
+    }
+    const double b = x / lx;
+    if (std::memcmp(&a, &b, 8) != 0) ++bad;
+  }
+  return bad;
 }
 
 hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t n,

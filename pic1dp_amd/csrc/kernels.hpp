@@ -19,11 +19,14 @@ struct SpeciesConst {
   // reciprocals, used only when every divisor is a power of two (exact)
   double r_m, r_T, r_tm, r_tm2, r_two_tm, r_two_tm2, r_stm, r_stm2;
   int pow2;             // 1: all divisors above are powers of two
+  int unit;             // 1: m = T = T2 = 1 (T/m = sqrt(T/m) = 1, 2T/m = 2): divisions vanish
 };
 
 struct GridConst {
   double lx, dnx, dt_full;
+  double rlx;    // RN(1/lx), for the exact division by the constant lx
   int nx;
+  int fast_div;  // 1: x/lx by reciprocal + two FMA corrections (bit-identical), 0: hardware division
 };
 
 // One particle set = the three pushed arrays of a species.
@@ -109,6 +112,15 @@ hipError_t launch_energy_sums(const double *v, const double *p, const double *w,
 hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
                            int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
                            double *out, int num_cu, hipStream_t st);
+// streaming-bandwidth probe with the particle kernels' access pattern:
+// (nr, nw) in {1,4,7} x {0,1,3} arrays of n doubles read / written
+hipError_t launch_stream_probe(double *const *in, int nr, double *const *out, int nw, int64_t n,
+                               int blocks, int threads, int variant, hipStream_t st);
+// div_lx (reciprocal + FMA corrections) against the hardware division on n test
+// positions; *bad counts results that differ in any bit
+hipError_t launch_div_check(const GridConst &g, uint64_t seed, int64_t n, unsigned long long *bad,
+                            hipStream_t st);
+int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n);
 // cell index per marker and per-cell counts from (wrapped) x
 hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
                                unsigned long long *count, hipStream_t st);

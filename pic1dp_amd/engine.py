@@ -273,6 +273,12 @@ class Pic1dp:
     def set_launch(self, threads=0, blocks_per_cu=0):
         check(self.L.pic1dp_hip_set_launch(self._ctx, threads, blocks_per_cu))
 
+    def stream_probe(self, nread, nwrite, n, reps=10):
+        """measured GB/s of a pure streaming pass with the kernels' access shape"""
+        g = C.c_double()
+        check(self.L.pic1dp_hip_stream_probe(self._ctx, nread, nwrite, n, reps, C.byref(g)))
+        return g.value
+
     def kernel_stats_enable(self, on=True):
         check(self.L.pic1dp_hip_kernel_stats_enable(self._ctx, int(on)))
 

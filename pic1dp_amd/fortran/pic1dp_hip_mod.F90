@@ -102,6 +102,33 @@ interface
     integer(c_int64_t), value :: n
     integer(c_int) :: ierr
   end function pic1dp_hip_host_multirand_int64
+  function pic1dp_hip_host_div_check(lx, nx, n, seed, mismatches) bind(C, name="pic1dp_hip_host_div_check") result(ierr)
+    import
+    real(c_double), value :: lx
+    integer(c_int32_t), value :: nx
+    integer(c_int64_t), value :: n
+    integer(c_int64_t), value :: seed
+    integer(c_int64_t), intent(out) :: mismatches
+    integer(c_int) :: ierr
+  end function pic1dp_hip_host_div_check
+  function pic1dp_hip_debug_div_check(ctx, n, seed, mismatches) bind(C, name="pic1dp_hip_debug_div_check") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int64_t), value :: n
+    integer(c_int64_t), value :: seed
+    integer(c_int64_t), intent(out) :: mismatches
+    integer(c_int) :: ierr
+  end function pic1dp_hip_debug_div_check
+  function pic1dp_hip_stream_probe(ctx, nread, nwrite, n, reps, gbytes_per_s) bind(C, name="pic1dp_hip_stream_probe") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: nread
+    integer(c_int32_t), value :: nwrite
+    integer(c_int64_t), value :: n
+    integer(c_int32_t), value :: reps
+    real(c_double), intent(out) :: gbytes_per_s
+    integer(c_int) :: ierr
+  end function pic1dp_hip_stream_probe
   function pic1dp_hip_create(inp, layout, ctx) bind(C, name="pic1dp_hip_create") result(ierr)
     import
     type(pic1dp_input_t), intent(in) :: inp

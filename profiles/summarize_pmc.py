@@ -7,19 +7,39 @@ exact.  Both counters are in KiB.
 
     python profiles/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> \
         <particles_per_gpu> <nx> [out.json]
+
+Several (fetch, write) pairs may be merged: pass "a.csv,b.csv" for either.
 """
 import collections
 import csv
 import json
+import re
 import sys
 
+PARTICLE_KERNELS = ("k_push", "k_step_half", "k_step_full", "k_deposit")
 
-def mean_by_kernel(path, counter):
+
+def short_name(full):
+    for k in PARTICLE_KERNELS:
+        if k in full:
+            if k == "k_push":
+                m = re.search(r"k_push<\d+, \d+, \w+, (\w+), (\w+)>", full)
+                if m:
+                    irk = "irk2" if m.group(1) in ("true", "1") else "irk1"
+                    fused = "fused" if m.group(2) in ("true", "1") else "push_only"
+                    return "k_push_%s_%s" % (fused, irk)
+            return k
+    return None
+
+
+def mean_by_kernel(paths, counter):
     acc = collections.defaultdict(list)
-    with open(path) as f:
-        for r in csv.DictReader(f):
-            if r["Counter_Name"] == counter and "k_push" in r["Kernel_Name"]:
-                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for path in paths.split(","):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                name = short_name(r["Kernel_Name"])
+                if name and r["Counter_Name"] == counter:
+                    acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
@@ -28,16 +48,21 @@ def main():
     out = sys.argv[5] if len(sys.argv) > 5 else None
     fetch, nf = mean_by_kernel(fetch_csv, "FETCH_SIZE")
     write, _ = mean_by_kernel(write_csv, "WRITE_SIZE")
-    rows = []
+    rows, by_kernel = [], {}
     for k in sorted(fetch):
         rd = fetch[k] * 1024 * 2.0      # KiB -> B, x2 gfx950 wide-read correction
         wr = write.get(k, 0.0) * 1024
         rows.append(dict(kernel=k, launches=nf[k], fetch_size_raw_kib=fetch[k], write_size_raw_kib=write.get(k),
                          read_bytes=rd, write_bytes=wr, hbm_bytes=rd + wr,
                          read_bytes_per_particle=rd / n, write_bytes_per_particle=wr / n))
-    tot = sum(r["hbm_bytes"] * r["launches"] for r in rows) / max(1, sum(r["launches"] for r in rows))
-    res = dict(particles_per_gpu=n, nx=nx, hbm_bytes_per_launch=tot,
-               hbm_bytes_per_update=tot / n, algorithmic_bytes_per_update=80.0,
+        by_kernel[k] = rd + wr
+    # the fused sub-step kernel has two instantiations (irk 1 / irk 2): bench.py
+    # reports their mean launch as "k_push"
+    fused = [r for r in rows if r["kernel"].startswith("k_push_fused")]
+    if fused:
+        by_kernel["k_push"] = sum(r["hbm_bytes"] * r["launches"] for r in fused) / sum(r["launches"] for r in fused)
+    res = dict(particles_per_gpu=n, nx=nx, hbm_bytes_per_launch_by_kernel=by_kernel,
+               algorithmic_bytes_per_update=80.0,
                correction="FETCH_SIZE x2 (gfx950 wide coalesced reads), WRITE_SIZE exact; KiB units",
                kernels=rows)
     print(json.dumps(res, indent=1))

@@ -535,3 +535,37 @@ def test_full_size_properties(amd, n, nx):
     c1 = eng.get_field()["chargeden"]
     eng.interaction_collect_charge()
     assert relerr(eng.get_field()["chargeden"], c1) < CHARGE_RTOL
+
+
+@pytest.mark.parametrize("kw", [dict(nx=1024), dict(nx=4096, lx=4 * np.pi), dict(nx=192, lx=17.0),
+                                dict(nx=64, lx=1.0 / 3.0)], ids=lambda d: "nx%d" % d["nx"])
+def test_exact_division_by_lx_device(amd, kw):
+    """div_lx (reciprocal + two FMA corrections) against the hardware IEEE
+    division on 4e8 generated positions, cell boundaries +- ulps included"""
+    eng = amd.Pic1dp(amd.make_input(nparticle_max=16, **kw))
+    m = C.c_int64(-1)
+    amd._lib.check(eng.L.pic1dp_hip_debug_div_check(eng._ctx, 400_000_000, 77, C.byref(m)))
+    assert m.value == 0
+
+
+@pytest.mark.parametrize("mass", [1.0, 4.0, 1.3])
+def test_full_f_mass_division(oracle_mod, amd, mass):
+    """full-f still divides by the species mass in the v push
+    (src/pic1dp_interaction.F90:336-337): true division unless m is a power of two"""
+    kw = dict(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0], species_mass=[mass])
+    sim, eng = pair(oracle_mod, amd, nparticle_max=50001, **kw)
+    E = smooth_field(sim.inp.nx, 3)
+    sim.set_field(E)
+    eng.set_electric(E)
+    for irk in (1, 2):
+        sim.push(irk)
+        eng.interaction_push_particle(irk)
+        g = eng.particles_download()
+        assert np.array_equal(g["v"], sim.gather("v")) and np.array_equal(g["x"], sim.gather("x"))
+        sim.collect_charge()
+        eng.interaction_collect_charge()
+    # and through the whole-step kernels
+    sim2, eng2 = pair(oracle_mod, amd, nparticle_max=50001, **kw)
+    t, eo, eg = run_both(sim2, eng2, 5)
+    assert np.array_equal(eng2.particles_download()["x"], sim2.gather("x")) or \
+        np.max(np.abs(eng2.particles_download()["x"] - sim2.gather("x"))) < 1e-9

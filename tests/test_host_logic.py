@@ -204,3 +204,15 @@ def test_fortran_binding_matches_header(amd):
     bound = set(re.findall(r'name\s*=\s*"(pic1dp_hip_\w+)"', src))
     missing = [n for n in declared_functions() if n not in bound]
     assert not missing, missing
+
+
+@pytest.mark.parametrize("lx,nx", [(2.0 * 3.1415926535897932384626 / 0.36, 1024), (4 * 3.141592653589793, 4096),
+                                    (17.0, 192), (1.0 / 3.0, 64), (0.007, 100), (1e5 / 7.0, 8192)])
+def test_exact_division_by_lx_host(amd, lx, nx):
+    """the kernels divide by the constant lx with a reciprocal and two FMA
+    corrections; the result must equal the IEEE quotient bit for bit (cell
+    indices depend on it).  Same algorithm on the host, with libm's exact fma."""
+    L = amd._lib.load()
+    m = C.c_int64(-1)
+    assert L.pic1dp_hip_host_div_check(lx, nx, 5_000_000, 20261003, C.byref(m)) == 0
+    assert m.value == 0

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""quick_bench.py -- kernel-level timing without torch: one engine, the
+streaming probes, then the whole-step and two-sub-step paths.
+    python tools/quick_bench.py [particles] [nx] [steps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pic1dp_amd  # noqa: E402
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 5 * 10**7
+nx = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=n, nx=nx))
+if os.environ.get("PIC1DP_THREADS") or os.environ.get("PIC1DP_BPC"):
+    eng.set_launch(int(os.environ.get("PIC1DP_THREADS", "0")), int(os.environ.get("PIC1DP_BPC", "0")))
+if "--probe" in sys.argv:
+    for nr, nw in ((1, 1), (4, 0), (4, 3), (7, 3), (1, 0), (7, 0)):
+        print("probe read %d write %d: %.0f GB/s" % (nr, nw, eng.stream_probe(nr, nw, n, 10)), flush=True)
+eng.particle_load()
+eng.interaction_collect_charge()
+eng.field_solve_electric()
+for mode in (0, 1):
+    eng.set_step_mode(mode)
+    eng.step(3)
+    eng.sync()
+    eng.kernel_stats_enable(True)
+    eng.timers_reset()
+    t0 = time.perf_counter()
+    eng.step(steps)
+    eng.sync()
+    dt = time.perf_counter() - t0
+    ks = [eng.kernel_stats(k) for k in range(5)]
+    names = ["fused", "push", "deposit", "step_half", "step_full"]
+    parts = ["%s %.4f ms" % (nm, ms / cnt) for nm, (ms, cnt) in zip(names, ks) if cnt]
+    print("mode %d: %.4e updates/s  %.4f ms/step  | %s" % (mode, n * 2 * steps / dt, dt / steps * 1e3, ", ".join(parts)), flush=True)
+    eng.kernel_stats_enable(False)
