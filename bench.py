@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--unfused", action="store_true", help="time separate push / deposit kernels")
     ap.add_argument("--step-mode", type=int, default=0, choices=[0, 1],
                     help="0: whole-step kernels (half-step state recomputed); 1: two fused sub-steps")
+    ap.add_argument("--force-host-allreduce", action="store_true",
+                    help="testing only: skip RCCL, reduce the charge on the host with gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles-per-core", type=int, default=2 * 10**6)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -113,6 +115,9 @@ def cpu_baseline(cfg, per_core, steps):
 
 
 def main():
+    if os.environ.get("PIC1DP_BENCH_TRACE"):     # debugging aid: dump all stacks after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PIC1DP_BENCH_TRACE"]), exit=True)
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,9 +137,10 @@ def main():
     total = per_gpu * world
 
     dist = None
-    if world > 1:
+    if world > 1 or a.force_host_allreduce:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         # control plane only (barrier, max over ranks, unique-id broadcast); the
         # data-path all-reduce is RCCL inside libpic1dp_hip.so, on the engine's stream
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -145,11 +151,39 @@ def main():
     if a.threads or a.blocks_per_cu:
         eng.set_launch(a.threads, a.blocks_per_cu)
     eng.set_step_mode(a.step_mode)
-    pic1dp_amd.parallel.bootstrap_comm(eng, dist)
+
+    # charge all-reduce: RCCL on the engine's stream.  Safety net only: if the RCCL
+    # communicator cannot be created on some rank, every rank switches to the
+    # split-phase deposit with a host-staged gloo all-reduce (slow, and flagged in
+    # the JSON line) instead of producing no number at all.
+    allreduce_kind, comm_error = "rccl", None
+    if dist is not None:
+        import torch
+        ok = 0 if a.force_host_allreduce else 1
+        if ok:
+            try:
+                pic1dp_amd.parallel.bootstrap_comm(eng, dist)
+            except Exception as e:          # noqa: BLE001
+                ok, comm_error = 0, str(e)
+        flag = torch.tensor([ok])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            allreduce_kind = "host-staged gloo (RCCL unavailable: %s)" % (comm_error or "forced / failed on another rank")
+    host_staged = allreduce_kind != "rccl"
+
+    def collect_charge():
+        if not host_staged:
+            eng.interaction_collect_charge()
+            return
+        import torch
+        t = torch.from_numpy(eng.charge_local())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        eng.charge_reduced(t.numpy())
+
     t0 = time.perf_counter()
     eng.particle_load()
     load_s = time.perf_counter() - t0
-    eng.interaction_collect_charge()
+    collect_charge()
     eng.field_solve_electric()
     eng.sync()
 
@@ -169,13 +203,13 @@ def main():
             dist.barrier()
 
     def run(nsteps):
-        if not a.unfused:
+        if not a.unfused and not host_staged:
             eng.step(nsteps)
             return
         for _ in range(nsteps):
             for irk in (1, 2):
                 eng.interaction_push_particle(irk)
-                eng.interaction_collect_charge()
+                collect_charge()
                 eng.field_solve_electric()
 
     run(a.warmup)
@@ -207,7 +241,7 @@ def main():
         value = total * 2.0 * a.steps / elapsed
         # dominant kernel of the path that ran; one launch = np_local particle-updates,
         # algorithmic bytes 80 B per update whatever the kernel really moves
-        if a.unfused:
+        if a.unfused or host_staged:
             kname, kms, kn, path = "k_push (separate gather+push)", push_ms, push_n, "separate push / deposit kernels"
         elif full_n:
             kname, kms, kn = "k_step_full (2nd sub-step: recompute half-step state, push+gather, deposit)", full_ms, full_n
@@ -247,7 +281,7 @@ def main():
                 "particles_total": total, "particles_per_gpu": per_gpu, "nx": cfg["nx"],
                 "nmode": 1, "dt": 0.05,
                 "parallelism": "particle shard x%d, replicated grid, RCCL all-reduce of the charge vector" % world,
-                "path": path,
+                "path": path, "allreduce": allreduce_kind if world > 1 or host_staged else "none (1 GPU)",
                 "sync": sync_kind, "load_seconds": load_s,
             },
             "roofline": {
