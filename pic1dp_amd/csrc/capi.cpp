@@ -688,7 +688,19 @@ int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, con
   if (np < 0 || np > n) return fail(PIC1DP_ERR_ARG, "np out of range");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->st));
-  PSet &A = S.set[c->cur];
+  // an upload (re)starts from set 0 for every species: slots beyond np live there
+  if (c->cur != 0) {
+    for (Species &T : c->sp) {
+      if (&T == &S) continue;
+      HIP_TRY(hipMemcpy(T.set[0].x, T.set[1].x, sizeof(double) * T.np, hipMemcpyDeviceToDevice));
+      if (T.set[1].v != T.set[0].v)
+        HIP_TRY(hipMemcpy(T.set[0].v, T.set[1].v, sizeof(double) * T.np, hipMemcpyDeviceToDevice));
+      if (T.set[1].w != T.set[0].w)
+        HIP_TRY(hipMemcpy(T.set[0].w, T.set[1].w, sizeof(double) * T.np, hipMemcpyDeviceToDevice));
+    }
+    c->cur = 0;
+  }
+  PSet &A = S.set[0];
   HIP_TRY(hipMemcpy(A.x, x, sizeof(double) * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(A.v, v, sizeof(double) * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(A.w, w, sizeof(double) * n, hipMemcpyHostToDevice));

@@ -588,26 +588,25 @@ constexpr int FIELD_THREADS = 256;
 
 // charge2(:) = charge2(:) + charge1(:)*Z over species, from 0
 // (src/pic1dp_interaction.F90:81,126-127); accumulators are re-zeroed
-__device__ __forceinline__ void charge_local_body(const FieldArgs &f) {
-  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) {
-    double c2 = 0.0;
-    for (int s = 0; s < f.nspecies; ++s) {
-      double *r = f.rho_sp + static_cast<size_t>(s) * f.nx + ix;
-      c2 = c2 + *r * f.Z[s];
-      *r = 0.0;
-    }
-    f.charge[ix] = c2;
+__device__ __forceinline__ double charge_local_one(const FieldArgs &f, int ix) {
+  double c2 = 0.0;
+  for (int s = 0; s < f.nspecies; ++s) {
+    double *r = f.rho_sp + static_cast<size_t>(s) * f.nx + ix;
+    c2 = c2 + *r * f.Z[s];
+    *r = 0.0;
   }
+  f.charge[ix] = c2;
+  return c2;
 }
 
 __global__ void __launch_bounds__(FIELD_THREADS) k_charge_local(const FieldArgs f) {
-  charge_local_body(f);
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) charge_local_one(f, ix);
 }
 
 // chargeden = charge1*nx/lx (- Z*n0 per species for full-f)
 // src/pic1dp_interaction.F90:138-148
-__device__ __forceinline__ double chargeden_of(const FieldArgs &f, int ix) {
-  double cd = f.charge[ix] * f.dnx / f.lx;
+__device__ __forceinline__ double chargeden_from(const FieldArgs &f, double charge1) {
+  double cd = charge1 * f.dnx / f.lx;
   if (!f.deltaf)
     for (int s = 0; s < f.nspecies; ++s) cd = cd - f.Z[s] * f.n0[s];
   return cd;
@@ -615,11 +614,8 @@ __device__ __forceinline__ double chargeden_of(const FieldArgs &f, int ix) {
 
 template <bool WITH_LOCAL>
 __global__ void __launch_bounds__(FIELD_THREADS) k_chargeden(const FieldArgs f) {
-  if constexpr (WITH_LOCAL) {
-    charge_local_body(f);
-    __syncthreads();
-  }
-  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) f.chargeden[ix] = chargeden_of(f, ix);
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x)
+    f.chargeden[ix] = chargeden_from(f, WITH_LOCAL ? charge_local_one(f, ix) : f.charge[ix]);
 }
 
 // sum of squares reduced over the workgroup (tree order)
@@ -646,50 +642,73 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
   double *sScr = sMode + 2 * f.nmode;                   // [16]
   double *sTab = sScr + 16;                             // [2][nmode][nx] when tab_lds
   const int nx = f.nx, nm = f.nmode;
-  if (f.tab_lds) {  // stage the cos / -sin tables (coalesced) for the serial sums
-    const int n = nm * nx;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      sTab[i] = f.fre[i];
-      sTab[n + i] = f.fim[i];
-    }
-  }
 
-  if constexpr (WITH_LOCAL) {
-    charge_local_body(f);
-    __syncthreads();
-  }
   for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
     double cd;
     if constexpr (FROM_CD) {
       cd = f.chargeden[ix];
     } else {
-      cd = chargeden_of(f, ix);
+      cd = chargeden_from(f, WITH_LOCAL ? charge_local_one(f, ix) : f.charge[ix]);
       f.chargeden[ix] = cd;
     }
     sCD[ix] = cd;
   }
   __syncthreads();
 
-  // forward partial DFT: thread t -> mode t>>1, (t&1 ? cos-table : -sin-table)
+  // forward partial DFT.  Every term table[ix]*chargeden[ix] is rounded on its
+  // own in the reference too (no FMA), so the products are formed by all threads
+  // at once (coalesced table reads) and only the additions run serially, in the
+  // reference's ascending-ix order.
+  if (f.tab_lds) {
+    const int n = nm * nx;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const double cd = sCD[i % nx];
+      sTab[i] = f.fre[i] * cd;
+      sTab[n + i] = f.fim[i] * cd;
+    }
+    __syncthreads();
+  }
+  // thread t -> mode t>>1, (t&1 ? cos-table : -sin-table)
   if (threadIdx.x < 2 * nm) {
     const int m = threadIdx.x >> 1;
     const bool use_cos = threadIdx.x & 1;
-    const double *tab = f.tab_lds
-                            ? sTab + (use_cos ? 0 : nm * nx) + m * nx
-                            : (use_cos ? f.fre : f.fim) + static_cast<size_t>(m) * nx;
     double acc = 0.0;
     int ix = 0;
-    for (; ix + 8 <= nx; ix += 8) {
-      double t[8], r[8];
+    if (f.tab_lds) {
+      const double *prod = sTab + (use_cos ? 0 : nm * nx) + m * nx;
+      double cur[8], nxt[8];
+      if (nx >= 8) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        t[k] = tab[ix + k];
-        r[k] = sCD[ix + k];
+        for (int k = 0; k < 8; ++k) cur[k] = prod[k];
       }
+      for (; ix + 8 <= nx; ix += 8) {
+        const bool more = ix + 16 <= nx;
+        if (more) {  // fetch the next eight terms while the current ones are added
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc = acc + t[k] * r[k];
+          for (int k = 0; k < 8; ++k) nxt[k] = prod[ix + 8 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = acc + cur[k];
+        if (more) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+        }
+      }
+      for (; ix < nx; ++ix) acc = acc + prod[ix];
+    } else {
+      const double *tab = (use_cos ? f.fre : f.fim) + static_cast<size_t>(m) * nx;
+      for (; ix + 8 <= nx; ix += 8) {
+        double t[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          t[k] = tab[ix + k];
+          r[k] = sCD[ix + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = acc + t[k] * r[k];
+      }
+      for (; ix < nx; ++ix) acc = acc + tab[ix] * sCD[ix];
     }
-    for (; ix < nx; ++ix) acc = acc + tab[ix] * sCD[ix];
     // :234/:239 VecScale by -1/nx resp. 1/nx, then :243-247 times 1/k
     if (use_cos) {
       const double im = acc * f.sc_im * f.grad_inv[m];

@@ -569,3 +569,27 @@ def test_full_f_mass_division(oracle_mod, amd, mass):
     t, eo, eg = run_both(sim2, eng2, 5)
     assert np.array_equal(eng2.particles_download()["x"], sim2.gather("x")) or \
         np.max(np.abs(eng2.particles_download()["x"] - sim2.gather("x"))) < 1e-9
+
+
+def test_upload_between_substeps_restarts_cleanly(oracle_mod, amd):
+    """particles_upload after an odd number of pushes (half-step set current):
+    the uploaded markers become particle_x/v/p/w, tails included"""
+    sim, eng = pair(oracle_mod, amd, nparticle_max=30000, species_nparticle_init=[25000], nx=32)
+    eng.interaction_push_particle(1)
+    n, npv = eng.local_sizes()
+    rng = np.random.default_rng(3)
+    x, v = rng.uniform(0, sim.inp.lx, n), rng.uniform(-8, 8, n)
+    p, w = rng.uniform(0.5, 1.5, n), rng.uniform(-1e-3, 1e-3, n)
+    eng.particles_upload(x, v, p, w, np_valid=npv)
+    got = eng.particles_download()
+    for k, a in zip("xvpw", (x, v, p, w)):
+        assert np.array_equal(got[k], a), k
+        sim.array(0, 0, k)[:] = a
+    sim.collect_charge()
+    sim.solve_field()
+    eng.interaction_collect_charge()
+    eng.field_solve_electric()
+    sim.step(2)
+    eng.step(2)
+    assert abs(eng.field_energy() / sim.field_energy() - 1.0) < ENERGY_RTOL
+    assert relerr(eng.energy_sums(), sim.energy_sums()) < 1e-11

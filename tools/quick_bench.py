@@ -12,7 +12,9 @@ import pic1dp_amd  # noqa: E402
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 5 * 10**7
 nx = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=n, nx=nx))
+import json  # noqa: E402
+extra = json.loads(os.environ.get("PIC1DP_INPUT", "{}"))     # e.g. '{"iptcldist": 2, "species_v0": [3.0]}'
+eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=n, nx=nx, **extra))
 if os.environ.get("PIC1DP_THREADS") or os.environ.get("PIC1DP_BPC"):
     eng.set_launch(int(os.environ.get("PIC1DP_THREADS", "0")), int(os.environ.get("PIC1DP_BPC", "0")))
 if "--probe" in sys.argv:
