@@ -1,0 +1,62 @@
+"""Physics validation on the GPU at BASELINE-size marker counts: linear growth /
+damping rates of the field energy against the roots of the Vlasov dispersion
+relation (BASELINE.md "physics anchors", computed with the reference's own
+tools/dispersion.py).  This is how the reference itself is validated
+(tools/visual.py, tools/runinfo.py print the fitted rate)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def fit_rate(t, e, t1, t2):
+    """least-squares slope of ln(int E^2 dx), tools/OutputData.py:153-170"""
+    i1 = int(np.searchsorted(t, t1)) - 1
+    i2 = int(np.searchsorted(t, t2))
+    tt, ln = t[i1:i2], np.log(e[i1:i2])
+    n = i2 - i1
+    return (n * np.sum(tt * ln) - np.sum(tt) * np.sum(ln)) / (n * np.sum(tt * tt) - np.sum(tt) ** 2)
+
+
+def run(amd, nsteps, **kw):
+    eng = amd.Pic1dp(amd.make_input(**kw))
+    eng.particle_load()
+    eng.interaction_collect_charge()
+    eng.field_solve_electric()
+    e0 = eng.field_energy()
+    eng.step(nsteps)
+    e = np.concatenate([[e0], eng.energy_history()])
+    t = np.arange(nsteps + 1) * eng.inp.dt
+    return t, e, eng
+
+
+def test_bump_on_tail_growth_rate(amd):
+    """default input, 10^7 markers, nx 256 (BASELINE configs[1]): 2 gamma = 0.16766"""
+    t, e, eng = run(amd, 1000, nparticle_max=10**7, nx=256)
+    g2 = fit_rate(t, e, 15.0, 45.0)
+    assert abs(g2 / 0.16766 - 1.0) < 0.02, g2
+    # the perturbation started at (1e-5/k)^2 lx/2 and has grown by orders of magnitude
+    assert e[-1] > 50 * e[0]
+
+
+def test_two_stream_growth_rate(amd):
+    """two-stream2 with v0 = 3 (BASELINE configs[3] physics): purely growing mode,
+    2 gamma = 0.30505"""
+    t, e, eng = run(amd, 700, nparticle_max=10**7, nx=512, iptcldist=2, species_density=[1.0], species_v0=[3.0])
+    g2 = fit_rate(t, e, 12.0, 28.0)
+    assert abs(g2 / 0.30505 - 1.0) < 0.03, g2
+
+
+def test_landau_damping_rate(amd):
+    """Maxwellian, k = 0.5 (lx = 4 pi), linear delta-f (BASELINE configs[4] physics):
+    field energy decays with 2 gamma = -0.30672 while oscillating at 2 omega"""
+    t, e, eng = run(amd, 400, nparticle_max=10**7, nx=1024, iptcldist=0, species_density=[1.0],
+                    species_v0=[0.0], lx=4 * np.pi, linear=1)
+    # fit through the maxima of the oscillating energy
+    pk = [i for i in range(1, len(e) - 1) if e[i] > e[i - 1] and e[i] > e[i + 1] and 1.0 < t[i] < 16.0]
+    assert len(pk) >= 5
+    slope = np.polyfit(t[pk], np.log(e[pk]), 1)[0]
+    assert abs(slope / -0.30672 - 1.0) < 0.05, slope
+    # oscillation of E^2 at 2 omega_r, omega_r = 1.41566
+    period = np.mean(np.diff(t[pk]))
+    assert abs(period / (np.pi / 1.41566) - 1.0) < 0.03, period
