@@ -10,7 +10,10 @@
 !   :80      interaction_push_particle       pic1dp_hip_push(ctx, global_irk)
 !
 ! With PIC1DP_FUSED=1 in the environment the three calls of a sub-step are
-! replaced by the fused pic1dp_hip_substep(ctx, global_irk).
+! replaced by the fused pic1dp_hip_substep(ctx, global_irk); with PIC1DP_FUSED=2
+! the whole irk loop is one pic1dp_hip_step(ctx, 1) (fastest: the half-step
+! state is recomputed instead of stored; the library then advances
+! global_itime / global_time itself, exactly as src/pic1dp.F90:92-93).
 program pic1dp_host
 use iso_c_binding
 use pic1dp_hip
@@ -25,7 +28,7 @@ integer(c_int32_t) :: global_irk, global_itime, itermination, due
 real(c_double) :: global_time, ms_push, ms_charge, ms_field
 character(len=8) :: buf
 integer :: stat
-logical :: fused
+logical :: fused, whole_step
 
 call input_fill(inp)
 lay = pic1dp_layout_t(0, 1, 0, -1)          ! one process, one GPU
@@ -33,6 +36,7 @@ call pic1dp_hip_check(pic1dp_hip_create(inp, lay, ctx), 'create')      ! particl
 call output_init(inp)
 call get_environment_variable('PIC1DP_FUSED', buf, status=stat)
 fused = (stat == 0 .and. buf(1:1) == '1')
+whole_step = (stat == 0 .and. buf(1:1) == '2')
 
 call pic1dp_hip_check(pic1dp_hip_particle_load(ctx), 'particle_load')
 call pic1dp_hip_check(pic1dp_hip_timers_enable(ctx, 1), 'timers_enable')
@@ -49,18 +53,23 @@ call output_all(ctx, inp, input_verbosity)
 
 call pic1dp_hip_check(pic1dp_hip_check_termination(ctx, itermination), 'check_termination')
 do while (itermination == 0)                 ! main time evolution loop
-  do global_irk = 1, 2
-    if (fused) then
-      call pic1dp_hip_check(pic1dp_hip_substep(ctx, global_irk), 'substep')
-    else
-      call pic1dp_hip_check(pic1dp_hip_push(ctx, global_irk), 'push')
-      call pic1dp_hip_check(pic1dp_hip_collect_charge(ctx), 'collect_charge')
-      call pic1dp_hip_check(pic1dp_hip_solve_field(ctx), 'solve_field')
-    end if
-  end do
-  global_itime = global_itime + 1
-  global_time = global_time + inp%dt
-  call pic1dp_hip_check(pic1dp_hip_set_time(ctx, global_itime, global_time), 'set_time')
+  if (whole_step) then
+    call pic1dp_hip_check(pic1dp_hip_step(ctx, 1), 'step')
+    call pic1dp_hip_check(pic1dp_hip_get_time(ctx, global_itime, global_time), 'get_time')
+  else
+    do global_irk = 1, 2
+      if (fused) then
+        call pic1dp_hip_check(pic1dp_hip_substep(ctx, global_irk), 'substep')
+      else
+        call pic1dp_hip_check(pic1dp_hip_push(ctx, global_irk), 'push')
+        call pic1dp_hip_check(pic1dp_hip_collect_charge(ctx), 'collect_charge')
+        call pic1dp_hip_check(pic1dp_hip_solve_field(ctx), 'solve_field')
+      end if
+    end do
+    global_itime = global_itime + 1
+    global_time = global_time + inp%dt
+    call pic1dp_hip_check(pic1dp_hip_set_time(ctx, global_itime, global_time), 'set_time')
+  end if
   call pic1dp_hip_check(pic1dp_hip_check_termination(ctx, itermination), 'check_termination')
   call pic1dp_hip_check(pic1dp_hip_output_due(ctx, itermination, due), 'output_due')
   if (due == 1) call output_all(ctx, inp, input_verbosity)

@@ -128,7 +128,7 @@ def test_fortran_host_drop_in(oracle_mod, amd, tmp_path):
     from pic1dp_amd import output
     env = dict(os.environ, PIC1DP_NPARTICLE="80000", PIC1DP_NX="64", PIC1DP_TIME_MAX="1.0")
     outs = {}
-    for fused in ("0", "1"):
+    for fused in ("0", "1", "2"):        # three call sites / fused sub-step / whole-step kernels
         wd = tmp_path / ("fused" + fused)
         wd.mkdir()
         r = subprocess.run([exe], cwd=str(wd), env=dict(env, PIC1DP_FUSED=fused), capture_output=True,
