@@ -272,7 +272,28 @@ PushArgs make_push_args(pic1dp_ctx *c, int isp, int irk) {
   return a;
 }
 
+// second particle set of the RK ping-pong (sub-step kernels only)
+int ensure_second_set(pic1dp_ctx *c) {
+  for (Species &S : c->sp) {
+    if (S.set[1].x) continue;
+    const size_t bytes = sizeof(double) * static_cast<size_t>(S.nalloc + 2);
+    HIP_TRY(hipMalloc(&S.set[1].x, bytes));
+    if (c->in.linear == 1) {
+      S.set[1].v = S.set[0].v;  // v is never pushed in a linear run
+    } else {
+      HIP_TRY(hipMalloc(&S.set[1].v, bytes));
+    }
+    if (c->in.deltaf == 0) {
+      S.set[1].w = S.set[0].w;  // w is not evolved in a full-f run
+    } else {
+      HIP_TRY(hipMalloc(&S.set[1].w, bytes));
+    }
+  }
+  return 0;
+}
+
 int enqueue_push(pic1dp_ctx *c, int irk, bool fused) {
+  if (int rc = ensure_second_set(c)) return rc;
   for (int s = 0; s < c->in.nspecies; ++s) {
     PushArgs a = make_push_args(c, s, irk);
     if (a.np <= 0) continue;
@@ -503,20 +524,13 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     S.sc = make_species_const(*in, s);
     S.rho = c->d_rho_sp + static_cast<size_t>(s) * nx;
     const size_t bytes = sizeof(double) * static_cast<size_t>(nalloc + 2);
+    // four arrays per species up front (x, v, w, p: 32 B per marker, 9e9 markers
+    // in 288 GB); the second set of the RK ping-pong is allocated on the first
+    // sub-step call that needs it (ensure_second_set) -- pic1dp_hip_step never does
     HIP_TRY_C(hipMalloc(&S.p, bytes));
-    for (int k = 0; k < 2; ++k) {
-      HIP_TRY_C(hipMalloc(&S.set[k].x, bytes));
-      if (k == 1 && in->linear == 1) {
-        S.set[1].v = S.set[0].v;  // v is never pushed in a linear run
-      } else {
-        HIP_TRY_C(hipMalloc(&S.set[k].v, bytes));
-      }
-      if (k == 1 && in->deltaf == 0) {
-        S.set[1].w = S.set[0].w;  // w is not evolved in a full-f run
-      } else {
-        HIP_TRY_C(hipMalloc(&S.set[k].w, bytes));
-      }
-    }
+    HIP_TRY_C(hipMalloc(&S.set[0].x, bytes));
+    HIP_TRY_C(hipMalloc(&S.set[0].v, bytes));
+    HIP_TRY_C(hipMalloc(&S.set[0].w, bytes));
   }
 
   // field storage and the operators of field_init (src/pic1dp_field.F90:158-210),
@@ -741,6 +755,7 @@ int pic1dp_hip_particles_download_bak(pic1dp_ctx *c, int32_t isp, double *xb, do
   if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
   Species &S = c->sp[isp];
   if (n != S.nalloc) return fail(PIC1DP_ERR_ARG, "n does not match the owned slots");
+  if (!S.set[1].x) return fail(PIC1DP_ERR_STATE, "no RK backup exists before the first push / substep call");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->st));
   const PSet &B = S.set[1 - c->cur];
