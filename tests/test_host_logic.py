@@ -216,3 +216,27 @@ def test_exact_division_by_lx_host(amd, lx, nx):
     m = C.c_int64(-1)
     assert L.pic1dp_hip_host_div_check(lx, nx, 5_000_000, 20261003, C.byref(m)) == 0
     assert m.value == 0
+
+
+def test_product_never_touches_the_oracle(amd):
+    """the oracle is test infrastructure: nothing under pic1dp_amd/ or include/
+    may import, link or mention it, and the built library must not depend on it"""
+    import subprocess
+    hits = []
+    for base in ("pic1dp_amd", "include"):
+        for root, _, files in os.walk(os.path.join(ROOT, base)):
+            if os.sep + "build" in root or "__pycache__" in root:
+                continue
+            for fn in files:
+                if fn.endswith((".so", ".o", ".mod", ".pyc")) or fn == "pic1dp_host":
+                    continue
+                with open(os.path.join(root, fn), errors="ignore") as f:
+                    if "oracle" in f.read().lower():
+                        hits.append(os.path.join(root, fn))
+    assert not hits, hits
+    needed = subprocess.run(["readelf", "-d", amd._lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in needed.lower()
+    # bench.py may use it only inside cpu_baseline()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("import oracle") == 1 and src.index("import oracle") > src.index("def cpu_baseline")
+    assert src.index("import oracle") < src.index("def main")
