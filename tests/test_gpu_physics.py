@@ -60,3 +60,41 @@ def test_landau_damping_rate(amd):
     # oscillation of E^2 at 2 omega_r, omega_r = 1.41566
     period = np.mean(np.diff(t[pk]))
     assert abs(period / (np.pi / 1.41566) - 1.0) < 0.03, period
+
+
+def test_long_run_through_saturation(oracle_mod, amd):
+    """3000 steps (t = 150) of the default bump-on-tail case on the GPU and in the
+    oracle (16 reference ranks on 16 threads): identical to 1e-10 while the run is
+    linear, and statistically the same saturation (peak level and time) afterwards,
+    when rounding differences have grown to order one"""
+    kw = dict(nparticle_max=1_600_000, nx=128)
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw), npe=16, nthreads=16)
+    assert sim.load() == 0
+    eng = amd.Pic1dp(amd.make_input(**kw), npe=16)
+    eng.particle_load()
+    sim.collect_charge()
+    sim.solve_field()
+    eng.interaction_collect_charge()
+    eng.field_solve_electric()
+    nsteps = 3000
+    eo = [sim.field_energy()]
+    for _ in range(nsteps // 100):
+        sim.step(100)
+        eo.append(sim.field_energy())
+    eng.energy_history_reset()
+    e0 = eng.field_energy()
+    eng.step(nsteps)
+    eg_all = np.concatenate([[e0], eng.energy_history()])
+    eg = eg_all[::100]
+    eo = np.array(eo)
+    assert np.all(np.isfinite(eg_all)) and eg.size == eo.size
+    lin = slice(0, 9)                                   # t <= 40: linear phase
+    assert np.max(np.abs(eg[lin] / eo[lin] - 1.0)) < 1e-10
+    # saturation: peak field energy and its time agree statistically
+    assert abs(np.max(eg) / np.max(eo) - 1.0) < 0.05
+    assert abs(int(np.argmax(eg)) - int(np.argmax(eo))) <= 1
+    # every marker still inside the box, none lost
+    _, cnt = eng.cell_indices()
+    assert cnt.sum() == kw["nparticle_max"]
+    x = eng.particles_download()["x"]
+    assert x.min() >= 0.0 and x.max() <= eng.inp.lx
