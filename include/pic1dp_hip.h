@@ -234,6 +234,15 @@ int pic1dp_hip_step(pic1dp_ctx *ctx, int32_t nsteps);
  *     for three grid tiles in LDS
  *   1 two fused sub-steps through the RK ping-pong sets (136 B per marker) */
 int pic1dp_hip_set_step_mode(pic1dp_ctx *ctx, int32_t mode);
+/* which field solve pic1dp_hip_solve_field / substep / step perform:
+ *   0 (default) the reference's field_solve_electric: mode-filtered partial DFT
+ *     (src/pic1dp_field.F90:218-270) -- the only solver with reference parity
+ *   1 opt-in alternative, NOT in the reference: second-order finite differences
+ *     keeping all modes, -phi'' = rho - <rho> as a tridiagonal system solved by
+ *     parallel cyclic reduction on the GPU, E = -dphi/dx by central differences
+ *     (3 <= nx <= 4096).  field_mode_re/im still hold the kept modes of the
+ *     mode-filter solve. */
+int pic1dp_hip_set_field_solver(pic1dp_ctx *ctx, int32_t kind);
 /* field_electric as it was between the two sub-steps of the last time step
  * taken by pic1dp_hip_step ([nx]) */
 int pic1dp_hip_get_field_half(pic1dp_ctx *ctx, double *electric_half);

@@ -131,6 +131,7 @@ def lib():
         "orc_field_free": (None, [P]),
         "orc_field_solve": (None, [IN, P, _dp, _dp, _dp, _dp]),
         "orc_field_energy": (C.c_double, [IN, _dp]),
+        "orc_field_solve_fd": (None, [IN, _dp, _dp]),
         "orc_energy_sums": (None, [C.c_int64, _dp, _dp, _dp, C.c_int, _dp]),
         "orc_ptcldist": (None, [IN, C.c_int64, _dp, _dp, _dp, _dp] + [_dp] * 6),
         "orc_sim_new": (P, [IN, C.c_int]),

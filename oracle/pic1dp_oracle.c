@@ -650,6 +650,39 @@ void orc_field_solve(const orc_input *in, const orc_field *f,
   }
 }
 
+/* CPU statement of the engine's OPT-IN finite-difference solver (NOT part of
+ * the reference; checks pic1dp_hip_set_field_solver(1) only):
+ * (phi[i-1] - 2 phi[i] + phi[i+1])/h^2 = -(rho[i] - <rho>), phi[0] = 0, periodic;
+ * E[i] = -(phi[i+1] - phi[i-1])/(2h).  Thomas algorithm on the nx-1 unknowns. */
+void orc_field_solve_fd(const orc_input *in, const double *rho, double *E) {
+  const int nx = in->nx, n = nx - 1;
+  const double h = in->lx / (double)nx;
+  double mean = 0.0;
+  for (int i = 0; i < nx; i++) mean += rho[i];
+  mean /= (double)nx;
+  double *cp = (double *)malloc(sizeof(double) * (size_t)nx);
+  double *dp = (double *)malloc(sizeof(double) * (size_t)nx);
+  double *phi = (double *)calloc((size_t)nx + 1, sizeof(double));
+  /* rows j = 0..n-1 for phi[j+1]: -phi[j] + 2 phi[j+1] - phi[j+2] = h^2 (rho[j+1]-mean) */
+  for (int j = 0; j < n; j++) {
+    double a = j == 0 ? 0.0 : -1.0, b = 2.0, c = j == n - 1 ? 0.0 : -1.0;
+    double d = h * h * (rho[j + 1] - mean);
+    double den = j == 0 ? b : b - a * cp[j - 1];
+    cp[j] = c / den;
+    dp[j] = j == 0 ? d / den : (d - a * dp[j - 1]) / den;
+  }
+  for (int j = n - 1; j >= 0; j--)
+    phi[j + 1] = j == n - 1 ? dp[j] : dp[j] - cp[j] * phi[j + 2];
+  phi[0] = 0.0;
+  for (int i = 0; i < nx; i++) {
+    int ip = i + 1 == nx ? 0 : i + 1, im = i == 0 ? nx - 1 : i - 1;
+    E[i] = -(phi[ip] - phi[im]) / (2.0 * h);
+  }
+  free(cp);
+  free(dp);
+  free(phi);
+}
+
 /* src/pic1dp_output.F90:120-124 (VecNorm NORM_2, then squared) */
 double orc_field_energy(const orc_input *in, const double *E) {
   double s = 0.0;

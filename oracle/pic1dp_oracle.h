@@ -144,6 +144,8 @@ void orc_field_free(orc_field *f);
 void orc_field_solve(const orc_input *in, const orc_field *f,
                      const double *chargeden, double *E, double *mode_re,
                      double *mode_im);
+/* the engine's opt-in finite-difference solver (not in the reference) */
+void orc_field_solve_fd(const orc_input *in, const double *rho, double *E);
 /* int E^2 dx as output_field does (src/pic1dp_output.F90:120-124) */
 double orc_field_energy(const orc_input *in, const double *E);
 

@@ -91,6 +91,7 @@ SIGNATURES = {
     "pic1dp_hip_step": [_P, C.c_int32],
     "pic1dp_hip_set_step_mode": [_P, C.c_int32],
     "pic1dp_hip_get_field_half": [_P, _P],
+    "pic1dp_hip_set_field_solver": [_P, C.c_int32],
     "pic1dp_hip_sync": [_P],
     "pic1dp_hip_get_time": [_P, C.POINTER(C.c_int32), _D],
     "pic1dp_hip_set_time": [_P, C.c_int32, C.c_double],

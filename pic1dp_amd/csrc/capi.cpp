@@ -91,6 +91,7 @@ struct pic1dp_ctx {
   double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
   double *d_Eh = nullptr;  // field after the first sub-step of the last whole-step call
   int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
+  int field_solver = 0;    // 0 the reference's mode-filter DFT solve, 1 finite-difference tridiagonal (opt-in)
   int64_t hist_count = 0;
   int32_t itime = 0;
   double time = 0.0;
@@ -790,12 +791,32 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   return tm.end();
 }
 
+// field_solve_electric: the reference's mode-filter solve, optionally followed by
+// the finite-difference alternative overwriting E (field_solver = 1)
+static int enqueue_field_solve(pic1dp_ctx *c, FieldArgs f, bool with_local, bool from_chargeden) {
+  double *hist = f.history;
+  if (c->field_solver == 1) f.history = nullptr;
+  HIP_TRY(launch_field_solve(f, with_local, from_chargeden, c->st));
+  if (c->field_solver == 1)
+    HIP_TRY(launch_field_fd(f.chargeden, f.E, hist, f.nx, f.lx, f.dnx, c->st));
+  return 0;
+}
+
+int pic1dp_hip_set_field_solver(pic1dp_ctx *c, int32_t kind) {
+  CHECK_CTX(c);
+  if (kind != 0 && kind != 1) return fail(PIC1DP_ERR_ARG, "field solver must be 0 (reference mode filter) or 1 (finite differences)");
+  if (kind == 1 && (c->in.nx < 3 || c->in.nx > 4096))
+    return fail(PIC1DP_ERR_ARG, "the finite-difference solver needs 3 <= nx <= 4096");
+  c->field_solver = kind;
+  return 0;
+}
+
 int pic1dp_hip_solve_field(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
   Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
-  HIP_TRY(launch_field_solve(f, false, true, c->st));
+  if (int rc = enqueue_field_solve(c, f, false, true)) return rc;
   return tm.end();
 }
 
@@ -816,7 +837,7 @@ static int substep_impl(pic1dp_ctx *c, int irk, bool record) {
   Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
   if (record && c->hist_count < kHistCap) f.history = c->d_hist + c->hist_count++;
-  HIP_TRY(launch_field_solve(f, !multi, false, c->st));
+  if (int rc = enqueue_field_solve(c, f, !multi, false)) return rc;
   return tm.end();
 }
 
@@ -894,7 +915,7 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
   FieldArgs f = c->fa;
   f.E = Eout;
   if (record && c->hist_count < kHistCap) f.history = c->d_hist + c->hist_count++;
-  HIP_TRY(launch_field_solve(f, !multi, false, c->st));
+  if (int rc = enqueue_field_solve(c, f, !multi, false)) return rc;
   return tm.end();
 }
 

@@ -753,7 +753,111 @@ k_field_energy(const double *E, int nx, double lx, double dnx, double *out) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Opt-in ALTERNATIVE field solve (NOT the reference's algorithm, which is the
+// mode-filtered partial DFT above): second-order finite differences
+// keeping every mode,
+//     (phi[i-1] - 2 phi[i] + phi[i+1]) / h^2 = -(rho[i] - <rho>),
+//     E[i] = -(phi[i+1] - phi[i-1]) / (2 h),      periodic, gauge phi[0] = 0.
+// The nx-1 unknowns form a tridiagonal system, solved by parallel cyclic
+// reduction held in LDS (ceil(log2(nx-1)) sweeps, every row eliminated against
+// its neighbours at distance 1, 2, 4, ...).  One workgroup; nx <= 4096.
+// ---------------------------------------------------------------------------
+constexpr int FD_THREADS = 1024;
+constexpr int FD_MAX_NX = 4096;
+constexpr int FD_PER_THREAD = FD_MAX_NX / FD_THREADS;
+
+__global__ void __launch_bounds__(FD_THREADS)
+k_field_fd(const double *chargeden, double *E, double *history, int nx, double lx, double dnx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double scr[16];
+  __shared__ double s_mean;
+  double *A = reinterpret_cast<double *>(smem), *B = A + nx, *Cc = B + nx, *D = Cc + nx;
+  const int n = nx - 1;
+  const double h = lx / dnx;
+  double part = 0.0;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) part += chargeden[ix];
+  const double tot = block_sum(part, scr);
+  if (threadIdx.x == 0) s_mean = tot / dnx;
+  __syncthreads();
+  const double mean = s_mean;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    A[j] = j == 0 ? 0.0 : -1.0;
+    B[j] = 2.0;
+    Cc[j] = j == n - 1 ? 0.0 : -1.0;
+    D[j] = h * h * (chargeden[j + 1] - mean);
+  }
+  __syncthreads();
+  for (int s = 1; s < n; s <<= 1) {
+    double na[FD_PER_THREAD], nb[FD_PER_THREAD], nc[FD_PER_THREAD], nd[FD_PER_THREAD];
+    int k = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x, ++k) {
+      const int lo = j - s, hi = j + s;
+      double a = A[j], b = B[j], c = Cc[j], d = D[j];
+      double a2 = 0.0, c2 = 0.0;
+      if (lo >= 0) {
+        const double al = -a / B[lo];
+        a2 = al * A[lo];
+        b += al * Cc[lo];
+        d += al * D[lo];
+      }
+      if (hi < n) {
+        const double ga = -c / B[hi];
+        c2 = ga * Cc[hi];
+        b += ga * A[hi];
+        d += ga * D[hi];
+      }
+      na[k] = a2;
+      nb[k] = b;
+      nc[k] = c2;
+      nd[k] = d;
+    }
+    __syncthreads();
+    k = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x, ++k) {
+      A[j] = na[k];
+      B[j] = nb[k];
+      Cc[j] = nc[k];
+      D[j] = nd[k];
+    }
+    __syncthreads();
+  }
+  for (int j = threadIdx.x; j < n; j += blockDim.x) D[j] = D[j] / B[j];  // phi[j+1]
+  __syncthreads();
+  double e2 = 0.0;
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    const int ip = i + 1 == nx ? 0 : i + 1, im = i == 0 ? nx - 1 : i - 1;
+    const double pp = ip == 0 ? 0.0 : D[ip - 1], pm = im == 0 ? 0.0 : D[im - 1];
+    const double e = -(pp - pm) / (2.0 * h);
+    E[i] = e;
+    e2 += e * e;
+  }
+  if (history) {
+    const double t2 = block_sum(e2, scr);
+    if (threadIdx.x == 0) {
+      const double nrm = sqrt(t2);
+      *history = nrm * nrm * lx / dnx;
+    }
+  }
+}
+
 }  // namespace
+
+hipError_t launch_field_fd(const double *chargeden, double *E, double *history, int nx, double lx,
+                           double dnx, hipStream_t st) {
+  if (nx < 3 || nx > FD_MAX_NX) return hipErrorInvalidValue;
+  const size_t lds = sizeof(double) * 4 * static_cast<size_t>(nx);
+  static bool big_lds_ok = false;
+  if (lds > 64 * 1024 && !big_lds_ok) {
+    // the kernel also holds 136 B of static LDS: leave room for it
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_field_fd),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return e;
+    big_lds_ok = true;
+  }
+  hipLaunchKernelGGL(k_field_fd, dim3(1), dim3(FD_THREADS), lds, st, chargeden, E, history, nx, lx, dnx);
+  return hipGetLastError();
+}
 
 hipError_t launch_charge_local(const FieldArgs &f, hipStream_t st) {
   hipLaunchKernelGGL(k_charge_local, dim3(1), dim3(FIELD_THREADS), 0, st, f);

@@ -100,6 +100,10 @@ hipError_t launch_chargeden(const FieldArgs &f, bool with_local, hipStream_t st)
 // launch_charge_local's work first in the same kernel (single-rank path)
 hipError_t launch_field_solve(const FieldArgs &f, bool with_local, bool from_chargeden,
                               hipStream_t st);
+// opt-in alternative solve (all modes): finite-difference Poisson equation as a
+// tridiagonal system, parallel cyclic reduction in LDS; chargeden -> E (+ energy)
+hipError_t launch_field_fd(const double *chargeden, double *E, double *history, int nx, double lx,
+                           double dnx, hipStream_t st);
 // int E^2 dx into *out (device)
 hipError_t launch_field_energy(const double *E, int nx, double lx, double dnx, double *out,
                                hipStream_t st);

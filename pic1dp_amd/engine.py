@@ -139,6 +139,11 @@ class Pic1dp:
         1: two fused sub-steps through the RK ping-pong sets"""
         check(self.L.pic1dp_hip_set_step_mode(self._ctx, mode))
 
+    def set_field_solver(self, kind):
+        """0: the reference's mode-filter solve (default); 1: opt-in finite-difference
+        tridiagonal solve by parallel cyclic reduction (not in the reference)"""
+        check(self.L.pic1dp_hip_set_field_solver(self._ctx, kind))
+
     def get_field_half(self):
         """field_electric between the two sub-steps of the last step()"""
         E = np.empty(self.inp.nx)

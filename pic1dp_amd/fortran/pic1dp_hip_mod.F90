@@ -221,6 +221,12 @@ interface
     integer(c_int32_t), value :: mode
     integer(c_int) :: ierr
   end function pic1dp_hip_set_step_mode
+  function pic1dp_hip_set_field_solver(ctx, kind) bind(C, name="pic1dp_hip_set_field_solver") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: kind
+    integer(c_int) :: ierr
+  end function pic1dp_hip_set_field_solver
   function pic1dp_hip_get_field_half(ctx, electric_half) bind(C, name="pic1dp_hip_get_field_half") result(ierr)
     import
     type(c_ptr), value :: ctx
