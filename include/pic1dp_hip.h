@@ -33,11 +33,12 @@
 extern "C" {
 #endif
 
-#define PIC1DP_ABI_VERSION 1
+#define PIC1DP_ABI_VERSION 2
 #define PIC1DP_MAX_SPECIES 8
 #define PIC1DP_MAX_MODES 64
 #define PIC1DP_MAX_INIT_MODES 16
 #define PIC1DP_COMM_ID_BYTES 128
+#define PIC1DP_MAX_OPT 32
 
 /* error codes */
 enum {
@@ -89,6 +90,21 @@ typedef struct pic1dp_input {
   int32_t init_mode[PIC1DP_MAX_INIT_MODES];        /* :90 */
   double init_mode_cos[PIC1DP_MAX_INIT_MODES];     /* :97 */
   double init_mode_sin[PIC1DP_MAX_INIT_MODES];     /* :98 */
+  /* marker optimisation, :141-206 (all counts 0 = disabled, the default) */
+  int32_t nmerge;               /* :146 */
+  int32_t nremove;              /* :162 */
+  int32_t nsplit;               /* :188 */
+  int32_t typeremove;           /* :172 1 threshold + fraction, 2 by the |delta f| profile */
+  int32_t split_ngroup;         /* :203 */
+  int32_t reserved0;
+  double remove_frac;           /* :184 */
+  double split_dv_sig_frac;     /* :206 */
+  double tmerge[PIC1DP_MAX_OPT];      /* :149 ascending */
+  double thshmerge[PIC1DP_MAX_OPT];   /* :155 */
+  double tremove[PIC1DP_MAX_OPT];     /* :165 */
+  double thshremove[PIC1DP_MAX_OPT];  /* :177 */
+  double tsplit[PIC1DP_MAX_OPT];      /* :191 */
+  double thshsplit[PIC1DP_MAX_OPT];   /* :197 */
 } pic1dp_input;
 
 /* Placement of this process in the particle decomposition.
@@ -219,8 +235,18 @@ int pic1dp_hip_solve_field(pic1dp_ctx *ctx);
 /* interaction_push_particle (src/pic1dp_interaction.F90:161-370, call site
  * src/pic1dp.F90:80); irk = global_irk = 1 or 2 */
 int pic1dp_hip_push(pic1dp_ctx *ctx, int32_t irk);
-/* one Runge-Kutta sub-step = push(irk); collect_charge; solve_field
- * (src/pic1dp.F90:80-89) with push+wrap+deposit fused into one kernel */
+/* particle_optimize (src/pic1dp_particle.F90:724-783; call site src/pic1dp.F90:82,
+ * right after the push of sub-step irk): when global_time + dt has reached the
+ * next entry of tmerge / tremove / tsplit and irk == 2, runs particle_merge /
+ * particle_remove / particle_split (:411-715) on every owned reference block and
+ * sets *flag_optimized = 1.  These routines are sequential and consume the
+ * block's random stream, so they run on the host (download, apply, upload);
+ * they are off the timed path and disabled by default.  pic1dp_hip_step calls
+ * this itself.  Needs markers loaded by pic1dp_hip_particle_load (the blocks'
+ * generators continue from the load), delta-f only like the reference. */
+int pic1dp_hip_particle_optimize(pic1dp_ctx *ctx, int32_t irk, int32_t *flag_optimized);
+/* one Runge-Kutta sub-step = push(irk); [particle_optimize;] collect_charge;
+ * solve_field (src/pic1dp.F90:80-89) with push+wrap+deposit fused into one kernel */
 int pic1dp_hip_substep(pic1dp_ctx *ctx, int32_t irk);
 /* nsteps time steps: {substep(1); substep(2); itime += 1; time += dt}
  * (src/pic1dp.F90:79-93).  The field energy int E^2 dx after every step is

@@ -18,6 +18,7 @@ MAX_SPECIES = 8
 MAX_MODES = 64
 MAX_INIT_MODES = 16
 NSEED = 20635
+MAX_OPT = 32
 
 
 class OrcInput(C.Structure):
@@ -44,6 +45,12 @@ class OrcInput(C.Structure):
         ("init_mode", C.c_int32 * MAX_INIT_MODES),
         ("init_mode_cos", C.c_double * MAX_INIT_MODES),
         ("init_mode_sin", C.c_double * MAX_INIT_MODES),
+        ("nmerge", C.c_int32), ("nremove", C.c_int32), ("nsplit", C.c_int32),
+        ("typeremove", C.c_int32), ("split_ngroup", C.c_int32), ("pad1", C.c_int32),
+        ("remove_frac", C.c_double), ("split_dv_sig_frac", C.c_double),
+        ("tmerge", C.c_double * MAX_OPT), ("thshmerge", C.c_double * MAX_OPT),
+        ("tremove", C.c_double * MAX_OPT), ("thshremove", C.c_double * MAX_OPT),
+        ("tsplit", C.c_double * MAX_OPT), ("thshsplit", C.c_double * MAX_OPT),
     ]
 
 
@@ -60,7 +67,26 @@ DEFAULTS = dict(
     iptclshape=4, multirand_al_int=3, multirand_seed_type=1,
     multirand_warmup=5, multirand_selftest=1, output_interval=0.5,
     nx_opd=64, nv_opd=64,
+    # marker optimisation (src/pic1dp_input.F90:141-206): off by default; the time and
+    # threshold lists default to the reference's implied-do formulas when left None
+    nmerge=0, nremove=0, nsplit=0, typeremove=2, split_ngroup=5, remove_frac=0.9,
+    split_dv_sig_frac=0.1, tmerge=None, thshmerge=None, tremove=None, thshremove=None,
+    tsplit=None, thshsplit=None,
 )
+
+
+def opt_defaults(d):
+    """the implied-do lists of src/pic1dp_input.F90:149-158,165-180,191-200"""
+    for kind, sign in (("merge", None), ("remove", None), ("split", None)):
+        n = d["n" + kind]
+        if d["t" + kind] is None:
+            d["t" + kind] = [50.0 + i * 0.5 for i in range(1, n + 1)]
+        if d["thsh" + kind] is None:
+            if kind == "split":
+                d["thsh" + kind] = [1.0 - 0.9 / max(n, 1) * float(i) for i in range(1, n + 1)]
+            else:
+                d["thsh" + kind] = [0.1 / max(n, 1) * float(i) for i in range(1, n + 1)]
+    return d
 
 
 def make_input(**kw):
@@ -71,9 +97,10 @@ def make_input(**kw):
     d.update(kw)
     if d["species_nparticle_init"] is None:
         d["species_nparticle_init"] = [d["nparticle_max"]] * d["nspecies"]
+    opt_defaults(d)
     inp = OrcInput()
     for name, _ in OrcInput._fields_:
-        if name == "pad0":
+        if name in ("pad0", "pad1"):
             continue
         val = d[name]
         cur = getattr(inp, name)
@@ -154,6 +181,13 @@ def lib():
         "orc_ptcldist_finish": (None, [IN, C.c_int] + [_dp] * 6),
         "orc_sim_ptcldist": (None, [P, C.c_int, C.c_int] + [_dp] * 6),
         "orc_sim_output_scalars": (None, [P, _dp]),
+        "orc_dist_pertb_abs_v": (None, [IN, C.c_int64, _dp, _dp, _dp]),
+        "orc_particle_merge": (None, [IN, C.c_double, _dp, C.POINTER(C.c_int64), _dp, _dp, _dp, _dp]),
+        "orc_particle_remove": (None, [IN, C.c_double, _dp, P, C.POINTER(C.c_int64), _dp, _dp, _dp, _dp]),
+        "orc_particle_split": (None, [IN, C.c_double, _dp, P, C.c_int64, C.POINTER(C.c_int64), _dp, _dp, _dp, _dp]),
+        "orc_sim_optimize": (C.c_int, [P, C.c_int]),
+        "orc_sim_rank_rng": (P, [P, C.c_int]),
+        "orc_sim_set_rank_np": (None, [P, C.c_int, C.c_int, C.c_int64]),
         "orc_check_termination": (C.c_int, [IN, C.c_int32, C.c_double]),
         "orc_output_due": (C.c_int, [IN, C.c_double, C.c_int]),
     }
@@ -297,6 +331,13 @@ class Sim:
 
     def step(self, n=1):
         lib().orc_sim_step(self.s, n)
+
+    def optimize(self, irk=2):
+        """particle_optimize on every rank; True when a merge/remove/split ran"""
+        return bool(lib().orc_sim_optimize(self.s, irk))
+
+    def set_rank_np(self, rank, np_valid, isp=0):
+        lib().orc_sim_set_rank_np(self.s, rank, isp, np_valid)
 
     @property
     def itime(self):

@@ -745,6 +745,179 @@ void orc_ptcldist(const orc_input *in, int64_t np, const double *x,
   }
 }
 
+/* ======================================================================
+ * marker optimisation -- src/pic1dp_particle.F90:356-813 (one rank)
+ * Indices are kept 1-based like the reference (arrays are passed 0-based, so
+ * element ip lives at [ip-1]); stale bin references after a swap-with-last are
+ * reproduced, not repaired.
+ * ====================================================================== */
+
+/* :372-388 */
+void orc_dist_pertb_abs_v(const orc_input *in, int64_t np, const double *v,
+                          const double *w, double *hist) {
+  const double vmax = in->v_max;
+  const int nv = in->nv;
+  for (int64_t ip = 0; ip < np; ip++) {
+    if (fabs(v[ip]) >= vmax) continue; /* :375 */
+    double sv = (v[ip] + vmax) / (vmax * 2.0) * (double)(nv - 1);
+    int iv = (int)floor(sv);
+    sv = 1.0 - (sv - (double)iv);
+    hist[iv] = hist[iv] + sv * fabs(w[ip]);
+    hist[iv + 1] = hist[iv + 1] + (1.0 - sv) * fabs(w[ip]);
+  }
+}
+
+static double hist_max(const orc_input *in, const double *hist) {
+  double m = hist[0];
+  for (int i = 1; i < in->nv; i++)
+    if (hist[i] > m) m = hist[i];
+  return m;
+}
+
+/* |delta f| interpolated at v, and the v bin: :449-463 (same in remove, split) */
+static double df_at(const orc_input *in, const double *hist, double v, int *iv_out) {
+  const int nv = in->nv;
+  double sv = (v + in->v_max) / (in->v_max * 2.0) * (double)(nv - 1);
+  int iv = (int)floor(sv);
+  double df;
+  if (iv < 0) {
+    iv = 0;
+    df = hist[iv];
+  } else if (iv >= nv - 1) {
+    iv = nv - 1;
+    df = hist[iv];
+  } else {
+    sv = 1.0 - (sv - (double)iv);
+    df = hist[iv] * sv + hist[iv + 1] * (1.0 - sv);
+  }
+  *iv_out = iv;
+  return df;
+}
+
+/* particle_merge, :411-519 */
+void orc_particle_merge(const orc_input *in, double thsh, const double *hist,
+                        int64_t *np_io, double *x, double *v, double *p, double *w) {
+  const int nx = in->nx, nv = in->nv;
+  const double lx = in->lx;
+  int64_t np = *np_io;
+  /* ipbin(ix, iv, iw, 1) and ipbin_top(ix, iv, iw): one slot per bin */
+  int64_t *bin = (int64_t *)calloc((size_t)nx * nv * 2, sizeof(int64_t));
+  char *full = (char *)calloc((size_t)nx * nv * 2, 1);
+  const double df_thsh = hist_max(in, hist) * thsh;
+  int64_t ip = 0;
+  for (;;) {
+    ip = ip + 1;
+    if (ip > np) break;
+    int iv;
+    double df = df_at(in, hist, v[ip - 1], &iv);
+    if (df >= df_thsh) continue; /* :466 */
+    double px = fmod(x[ip - 1], lx); /* :469-471 */
+    if (px < 0.0) px = px + lx;
+    x[ip - 1] = px;
+    double sx = px / lx * (double)nx;
+    int ix = (int)floor(sx);
+    if (ix >= nx) ix = nx - 1; /* memory safety only (px == lx) */
+    const int iw = w[ip - 1] > 0.0 ? 1 : 0;
+    const size_t b = ((size_t)ix * nv + iv) * 2 + iw;
+    if (!full[b]) { /* :480-482 */
+      bin[b] = ip;
+      full[b] = 1;
+    } else { /* :483-505 */
+      const int64_t ip1 = bin[b];
+      x[ip1 - 1] = (w[ip1 - 1] * x[ip1 - 1] + w[ip - 1] * x[ip - 1]) / (w[ip1 - 1] + w[ip - 1]);
+      v[ip1 - 1] = (w[ip1 - 1] * v[ip1 - 1] + w[ip - 1] * v[ip - 1]) / (w[ip1 - 1] + w[ip - 1]);
+      p[ip1 - 1] = p[ip1 - 1] + p[ip - 1];
+      w[ip1 - 1] = w[ip1 - 1] + w[ip - 1];
+      if (ip < np) {
+        x[ip - 1] = x[np - 1];
+        v[ip - 1] = v[np - 1];
+        p[ip - 1] = p[np - 1];
+        w[ip - 1] = w[np - 1];
+        ip = ip - 1;
+      }
+      np = np - 1;
+      full[b] = 0;
+    }
+  }
+  free(bin);
+  free(full);
+  *np_io = np;
+}
+
+/* particle_remove, :531-602 */
+void orc_particle_remove(const orc_input *in, double thsh, const double *hist,
+                         orc_multirand *g, int64_t *np_io, double *x, double *v,
+                         double *p, double *w) {
+  int64_t np = *np_io;
+  const double hmax = hist_max(in, hist);
+  const double df_thsh = hmax * thsh;
+  int64_t ip = 0;
+  for (;;) {
+    ip = ip + 1;
+    if (ip > np) break;
+    int iv;
+    double df = df_at(in, hist, v[ip - 1], &iv);
+    if (in->typeremove == 1 && df >= df_thsh) continue; /* :567-570 */
+    df = df / hmax;                                      /* :571 */
+    const double dice = orc_multirand_real64(g);
+    if ((in->typeremove == 1 && dice < in->remove_frac) ||
+        (in->typeremove == 2 && dice > df)) { /* :577-588 */
+      if (ip < np) {
+        x[ip - 1] = x[np - 1];
+        v[ip - 1] = v[np - 1];
+        p[ip - 1] = p[np - 1];
+        w[ip - 1] = w[np - 1];
+        ip = ip - 1;
+      }
+      np = np - 1;
+    } else if (in->typeremove == 1) { /* :590-593 */
+      p[ip - 1] = p[ip - 1] / (1.0 - in->remove_frac);
+      w[ip - 1] = w[ip - 1] / (1.0 - in->remove_frac);
+    } else { /* :594-596 */
+      p[ip - 1] = p[ip - 1] / df;
+      w[ip - 1] = w[ip - 1] / df;
+    }
+  }
+  *np_io = np;
+}
+
+/* particle_split, :610-715 */
+void orc_particle_split(const orc_input *in, double thsh, const double *hist,
+                        orc_multirand *g, int64_t nalloc, int64_t *np_io, double *x,
+                        double *v, double *p, double *w) {
+  const int ng = in->split_ngroup;
+  const int64_t np = *np_io;
+  if (nalloc - np < 2 * ng - 1) return; /* :638-639 */
+  int64_t np_inc = 0;
+  const double df_thsh = hist_max(in, hist) * thsh;
+  double *grand = (double *)malloc(sizeof(double) * (size_t)ng);
+  const double share = (double)ng * 2.0;
+  for (int64_t ip = 1; ip <= np; ip++) {
+    if (nalloc - (np + np_inc) < 2 * ng - 1) break; /* :655-656 */
+    int iv;
+    double df = df_at(in, hist, v[ip - 1], &iv);
+    if (df <= df_thsh) continue; /* :676 */
+    orc_multirand_gaussian_array64(g, grand, ng);
+    for (int k = 0; k < ng; k++) /* :680-681 */
+      grand[k] = grand[k] * 2.0 * in->v_max / (double)in->nv * in->split_dv_sig_frac;
+    for (int ig = 1; ig <= ng; ig++) { /* :686-707 */
+      int64_t ip1 = np + np_inc + ig * 2 - 1;
+      x[ip1 - 1] = x[ip - 1];
+      v[ip1 - 1] = v[ip - 1] + grand[ig - 1];
+      p[ip1 - 1] = p[ip - 1] / share;
+      if (in->deltaf == 1) w[ip1 - 1] = w[ip - 1] / share;
+      ip1 = ig == ng ? ip : np + np_inc + ig * 2;
+      x[ip1 - 1] = x[ip - 1];
+      v[ip1 - 1] = v[ip - 1] - grand[ig - 1];
+      p[ip1 - 1] = p[ip - 1] / share;
+      if (in->deltaf == 1) w[ip1 - 1] = w[ip - 1] / share;
+    }
+    np_inc = np_inc + (2 * ng - 1);
+  }
+  free(grand);
+  *np_io = np + np_inc;
+}
+
 /* equilibrium f0(v) of the full-f branch, src/pic1dp_output.F90:375-451
  * (the reference normalises by T/m where sqrt(T/m) would be expected) */
 static double output_f0(const orc_input *in, int isp, double sv) {
@@ -814,6 +987,8 @@ struct orc_sim {
   double *charge1, *chargeden, *E, *mode_re, *mode_im;
   int32_t itime;
   double time;
+  orc_multirand **rng;          /* [npe] each rank's generator, kept after the load */
+  int imerge, iremove, isplit;  /* particle_imerge / _iremove / _isplit */
 };
 
 #define SIM_ARR(s, r, isp, k) ((s)->arr[((size_t)(r) * (s)->in.nspecies + (isp)) * 7 + (k)])
@@ -842,6 +1017,11 @@ orc_sim *orc_sim_new(const orc_input *in, int npe) {
   s->E = (double *)calloc((size_t)in->nx, sizeof(double));
   s->mode_re = (double *)calloc((size_t)in->nmode, sizeof(double));
   s->mode_im = (double *)calloc((size_t)in->nmode, sizeof(double));
+  s->rng = (orc_multirand **)calloc((size_t)npe, sizeof(orc_multirand *));
+  /* particle_init, src/pic1dp_particle.F90:73-87 */
+  s->imerge = in->nmerge > 0 ? 1 : 0;
+  s->iremove = in->nremove > 0 ? 1 : 0;
+  s->isplit = in->nsplit > 0 ? 1 : 0;
   return s;
 }
 
@@ -849,6 +1029,8 @@ void orc_sim_free(orc_sim *s) {
   if (!s) return;
   for (size_t i = 0; i < (size_t)s->npe * s->in.nspecies * 7; i++) free(s->arr[i]);
   free(s->arr);
+  for (int r = 0; r < s->npe; r++) orc_multirand_free(s->rng[r]);
+  free(s->rng);
   free(s->nalloc);
   free(s->np);
   free(s->charge_rank);
@@ -883,7 +1065,8 @@ int orc_sim_load(orc_sim *s) {
         orc_particle_load_species(&s->in, isp, g, s->nalloc[r],
                                   SIM_ARR(s, r, isp, 0), SIM_ARR(s, r, isp, 1),
                                   SIM_ARR(s, r, isp, 2), SIM_ARR(s, r, isp, 3));
-    orc_multirand_free(g);
+    orc_multirand_free(s->rng[r]);
+    s->rng[r] = g;
   }
   s->itime = 0;
   s->time = 0.0;
@@ -943,12 +1126,67 @@ void orc_sim_step(orc_sim *s, int nsteps) {
   for (int it = 0; it < nsteps; it++) {
     for (int irk = 1; irk <= 2; irk++) {
       orc_sim_push(s, irk);
+      orc_sim_optimize(s, irk); /* src/pic1dp.F90:82 */
       orc_sim_collect_charge(s);
       orc_sim_solve_field(s);
     }
     s->itime += 1;
     s->time = s->time + s->in.dt;
   }
+}
+
+/* particle_compute_dist_pertb_abs_v over all ranks (:356-403, MPI_Allreduce in
+ * rank order) for one species */
+static void sim_dist_pertb_abs_v(orc_sim *s, int isp, double *hist) {
+  const int nv = s->in.nv;
+  double *loc = (double *)malloc(sizeof(double) * (size_t)nv);
+  for (int r = 0; r < s->npe; r++) {
+    for (int i = 0; i < nv; i++) loc[i] = 0.0;
+    orc_dist_pertb_abs_v(&s->in, s->np[(size_t)r * s->in.nspecies + isp], SIM_ARR(s, r, isp, 1),
+                         SIM_ARR(s, r, isp, 3), loc);
+    for (int i = 0; i < nv; i++) hist[i] = r == 0 ? loc[i] : hist[i] + loc[i];
+  }
+  free(loc);
+}
+
+/* particle_optimize, src/pic1dp_particle.F90:724-783 */
+int orc_sim_optimize(orc_sim *s, int irk) {
+  const orc_input *in = &s->in;
+  int done = 0;
+  if (in->deltaf == 0) return 0;
+  double *hist = (double *)malloc(sizeof(double) * (size_t)in->nv * in->nspecies);
+  for (int kind = 0; kind < 3; kind++) {
+    int *idx = kind == 0 ? &s->imerge : (kind == 1 ? &s->iremove : &s->isplit);
+    const int n = kind == 0 ? in->nmerge : (kind == 1 ? in->nremove : in->nsplit);
+    const double *tt = kind == 0 ? in->tmerge : (kind == 1 ? in->tremove : in->tsplit);
+    const double *th = kind == 0 ? in->thshmerge : (kind == 1 ? in->thshremove : in->thshsplit);
+    if (!(*idx > 0 && *idx <= n)) continue;
+    if (!(s->time + in->dt >= tt[*idx - 1] && irk == 2)) continue;
+    /* the histogram of every species first (it is global), then rank by rank */
+    for (int isp = 0; isp < in->nspecies; isp++) sim_dist_pertb_abs_v(s, isp, hist + (size_t)isp * in->nv);
+    for (int r = 0; r < s->npe; r++)
+      for (int isp = 0; isp < in->nspecies; isp++) {
+        int64_t *np = &s->np[(size_t)r * in->nspecies + isp];
+        double *x = SIM_ARR(s, r, isp, 0), *v = SIM_ARR(s, r, isp, 1);
+        double *p = SIM_ARR(s, r, isp, 2), *w = SIM_ARR(s, r, isp, 3);
+        const double *h = hist + (size_t)isp * in->nv;
+        if (kind == 0)
+          orc_particle_merge(in, th[*idx - 1], h, np, x, v, p, w);
+        else if (kind == 1)
+          orc_particle_remove(in, th[*idx - 1], h, s->rng[r], np, x, v, p, w);
+        else
+          orc_particle_split(in, th[*idx - 1], h, s->rng[r], s->nalloc[r], np, x, v, p, w);
+      }
+    *idx += 1;
+    done = 1;
+  }
+  free(hist);
+  return done;
+}
+
+orc_multirand *orc_sim_rank_rng(orc_sim *s, int rank) { return s->rng[rank]; }
+void orc_sim_set_rank_np(orc_sim *s, int rank, int isp, int64_t np) {
+  s->np[(size_t)rank * s->in.nspecies + isp] = np;
 }
 
 int32_t orc_sim_itime(const orc_sim *s) { return s->itime; }

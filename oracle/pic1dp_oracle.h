@@ -35,6 +35,7 @@ extern "C" {
 #define ORC_MAX_MODES 64
 #define ORC_MAX_INIT_MODES 16
 #define ORC_MULTIRAND_NSEED 20635
+#define ORC_MAX_OPT 32
 
 /* mirrors the compile-time parameters of src/pic1dp_input.F90:32-256 */
 typedef struct orc_input {
@@ -73,6 +74,12 @@ typedef struct orc_input {
   int32_t init_mode[ORC_MAX_INIT_MODES];
   double init_mode_cos[ORC_MAX_INIT_MODES];
   double init_mode_sin[ORC_MAX_INIT_MODES];
+  /* marker optimisation, src/pic1dp_input.F90:141-206 */
+  int32_t nmerge, nremove, nsplit, typeremove, split_ngroup, pad1;
+  double remove_frac, split_dv_sig_frac;
+  double tmerge[ORC_MAX_OPT], thshmerge[ORC_MAX_OPT];
+  double tremove[ORC_MAX_OPT], thshremove[ORC_MAX_OPT];
+  double tsplit[ORC_MAX_OPT], thshsplit[ORC_MAX_OPT];
 } orc_input;
 
 /* ---- multirand (src/multirand.F90) ---- */
@@ -157,6 +164,20 @@ void orc_ptcldist(const orc_input *in, int64_t np, const double *x,
                   double *markr_xv, double *total_xv, double *pertb_xv,
                   double *markr_v, double *total_v, double *pertb_v);
 
+/* ---- marker optimisation (src/pic1dp_particle.F90:356-813), one rank ---- */
+/* :356-403 local |delta f|(v) histogram, added into hist[nv] */
+void orc_dist_pertb_abs_v(const orc_input *in, int64_t np, const double *v,
+                          const double *w, double *hist);
+/* :411-519, :531-602, :610-715; hist = the rank-summed histogram; np in/out */
+void orc_particle_merge(const orc_input *in, double thsh, const double *hist,
+                        int64_t *np, double *x, double *v, double *p, double *w);
+void orc_particle_remove(const orc_input *in, double thsh, const double *hist,
+                         orc_multirand *g, int64_t *np, double *x, double *v,
+                         double *p, double *w);
+void orc_particle_split(const orc_input *in, double thsh, const double *hist,
+                        orc_multirand *g, int64_t nalloc, int64_t *np, double *x,
+                        double *v, double *p, double *w);
+
 /* root-rank post-processing of output_ptcldist (src/pic1dp_output.F90:328-454) */
 void orc_ptcldist_finish(const orc_input *in, int isp, double *markr_xv,
                          double *total_xv, double *pertb_xv, double *markr_v,
@@ -185,6 +206,12 @@ int64_t orc_sim_rank_nalloc(const orc_sim *s, int rank);
 /* pointers into rank-owned arrays: which = 0..6 -> x v p w xb vb wb */
 double *orc_sim_array(orc_sim *s, int rank, int isp, int which);
 void orc_sim_energy_sums(const orc_sim *s, int isp, double out[3]);
+/* particle_optimize (:724-783) on every rank; returns 1 when something ran.
+ * orc_sim_step calls it after each push like the driver (src/pic1dp.F90:82). */
+int orc_sim_optimize(orc_sim *s, int irk);
+/* the rank's generator as particle_load left it (continues in remove / split) */
+orc_multirand *orc_sim_rank_rng(orc_sim *s, int rank);
+void orc_sim_set_rank_np(orc_sim *s, int rank, int isp, int64_t np);
 void orc_sim_ptcldist(const orc_sim *s, int isp, int finish, double *markr_xv,
                       double *total_xv, double *pertb_xv, double *markr_v,
                       double *total_v, double *pertb_v);

@@ -14,7 +14,8 @@ MAX_SPECIES = 8
 MAX_MODES = 64
 MAX_INIT_MODES = 16
 COMM_ID_BYTES = 128
-ABI_VERSION = 1
+ABI_VERSION = 2
+MAX_OPT = 32
 
 ERR_NAMES = {1: "ARG", 2: "HIP", 3: "NODEVICE", 4: "STATE", 5: "COMM", 6: "RNG", 7: "NOMEM"}
 
@@ -49,6 +50,12 @@ class Input(C.Structure):
         ("init_mode", C.c_int32 * MAX_INIT_MODES),
         ("init_mode_cos", C.c_double * MAX_INIT_MODES),
         ("init_mode_sin", C.c_double * MAX_INIT_MODES),
+        ("nmerge", C.c_int32), ("nremove", C.c_int32), ("nsplit", C.c_int32),
+        ("typeremove", C.c_int32), ("split_ngroup", C.c_int32), ("reserved0", C.c_int32),
+        ("remove_frac", C.c_double), ("split_dv_sig_frac", C.c_double),
+        ("tmerge", C.c_double * MAX_OPT), ("thshmerge", C.c_double * MAX_OPT),
+        ("tremove", C.c_double * MAX_OPT), ("thshremove", C.c_double * MAX_OPT),
+        ("tsplit", C.c_double * MAX_OPT), ("thshsplit", C.c_double * MAX_OPT),
     ]
 
 
@@ -87,6 +94,7 @@ SIGNATURES = {
     "pic1dp_hip_collect_charge": [_P],
     "pic1dp_hip_solve_field": [_P],
     "pic1dp_hip_push": [_P, C.c_int32],
+    "pic1dp_hip_particle_optimize": [_P, C.c_int32, C.POINTER(C.c_int32)],
     "pic1dp_hip_substep": [_P, C.c_int32],
     "pic1dp_hip_step": [_P, C.c_int32],
     "pic1dp_hip_set_step_mode": [_P, C.c_int32],

@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpic1dp_hip.so")
-SOURCES = ["kernels.hip", "capi.cpp", "loader.cpp", "multirand.cpp"]
-HEADERS = ["kernels.hpp", "loader.hpp", "multirand.hpp", "rccl_dyn.hpp",
+SOURCES = ["kernels.hip", "capi.cpp", "loader.cpp", "multirand.cpp", "optimize.cpp"]
+HEADERS = ["kernels.hpp", "loader.hpp", "multirand.hpp", "optimize.hpp", "rccl_dyn.hpp",
            os.path.join("..", "..", "include", "pic1dp_hip.h")]
 
 # -ffp-contract=off : products and sums round separately, like the reference's

@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 #include "loader.hpp"
 #include "multirand.hpp"
+#include "optimize.hpp"
 #include "rccl_dyn.hpp"
 
 using namespace pic1dp;
@@ -83,6 +84,11 @@ struct pic1dp_ctx {
   int cur = 0;  // which particle set is particle_x/v/w right now
   std::vector<Species> sp;
   int blk0 = 0, nblk = 1;  // owned reference blocks [blk0, blk0+nblk)
+  std::vector<int64_t> blk_alloc;                 // [nblk] allocated slots of each owned block
+  std::vector<std::vector<int64_t>> blk_np;       // [nspecies][nblk] valid markers
+  std::vector<Multirand> blk_rng;                 // [nblk] generators as particle_load left them
+  bool rng_ready = false;
+  int imerge = 0, iremove = 0, isplit = 0;        // particle_imerge / _iremove / _isplit
   bool loaded = false;
   bool charge_pending = false;  // charge_local ran, waiting for charge_reduced
   // field
@@ -235,6 +241,14 @@ int validate(const pic1dp_input &in, const pic1dp_layout &lay) {
   }
   for (int m = 0; m < in.nmode; ++m)
     if (in.modes[m] < 1) return fail(PIC1DP_ERR_ARG, "modes must be >= 1");
+  if (in.nmerge < 0 || in.nmerge > PIC1DP_MAX_OPT || in.nremove < 0 || in.nremove > PIC1DP_MAX_OPT ||
+      in.nsplit < 0 || in.nsplit > PIC1DP_MAX_OPT)
+    return fail(PIC1DP_ERR_ARG, "nmerge, nremove, nsplit must be in [0, %d]", PIC1DP_MAX_OPT);
+  if (in.nmerge + in.nremove + in.nsplit > 0) {
+    if (in.nv < 2) return fail(PIC1DP_ERR_ARG, "marker optimisation needs nv >= 2");
+    if (in.typeremove != 1 && in.typeremove != 2) return fail(PIC1DP_ERR_ARG, "typeremove must be 1 or 2");
+    if (in.nsplit > 0 && in.split_ngroup < 1) return fail(PIC1DP_ERR_ARG, "split_ngroup must be >= 1");
+  }
   if (lay.nranks < 1 || lay.rank < 0 || lay.rank >= lay.nranks) return fail(PIC1DP_ERR_ARG, "bad rank/nranks");
   const int npe = lay.npe > 0 ? lay.npe : lay.nranks;
   if (npe % lay.nranks) return fail(PIC1DP_ERR_ARG, "npe must be a multiple of nranks");
@@ -381,6 +395,15 @@ int pic1dp_hip_input_defaults(pic1dp_input *in) {
   in->output_interval = 0.5;
   in->nx_opd = 64;
   in->nv_opd = 64;
+  // marker optimisation: disabled (src/pic1dp_input.F90:146,162,188).  Whoever
+  // raises a count fills the time / threshold lists (the reference derives them
+  // with implied-do formulas of the count, :149-158,165-180,191-200; the Python
+  // and Fortran hosts do the same).
+  in->nmerge = in->nremove = in->nsplit = 0;
+  in->typeremove = 2;
+  in->remove_frac = 0.9;
+  in->split_ngroup = 5;
+  in->split_dv_sig_frac = 0.1;
   return 0;
 }
 
@@ -501,6 +524,17 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   const int npe = c->lay.npe;
   c->nblk = npe / c->lay.nranks;
   c->blk0 = c->lay.rank * c->nblk;
+  c->blk_alloc.resize(c->nblk);
+  c->blk_np.assign(in->nspecies, std::vector<int64_t>(c->nblk, 0));
+  for (int b = 0; b < c->nblk; ++b) {
+    c->blk_alloc[b] = block_alloc(in->nparticle_max, c->blk0 + b, npe);
+    for (int s = 0; s < in->nspecies; ++s) c->blk_np[s][b] = block_np(*in, s, c->blk0 + b, npe);
+  }
+  c->blk_rng.resize(c->nblk);
+  // particle_init, src/pic1dp_particle.F90:73-87
+  c->imerge = in->nmerge > 0 ? 1 : 0;
+  c->iremove = in->nremove > 0 ? 1 : 0;
+  c->isplit = in->nsplit > 0 ? 1 : 0;
   const int nx = in->nx, nm = in->nmode, ns = in->nspecies;
   c->grid.lx = in->lx;
   c->grid.dnx = static_cast<double>(nx);
@@ -654,6 +688,18 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   double *stage = nullptr;
   HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&stage), sizeof(double) * 4 * static_cast<size_t>(max_alloc), 0));
   double *hx = stage, *hv = stage + max_alloc, *hp = stage + 2 * max_alloc, *hw = stage + 3 * max_alloc;
+  // a (re)load restores the loader's marker counts and optimisation counters
+  for (int s = 0; s < ns; ++s) {
+    c->sp[s].np = 0;
+    for (int b = 0; b < c->nblk; ++b) {
+      c->blk_np[s][b] = block_np(in, s, c->blk0 + b, npe);
+      c->sp[s].np += c->blk_np[s][b];
+    }
+  }
+  c->imerge = in.nmerge > 0 ? 1 : 0;
+  c->iremove = in.nremove > 0 ? 1 : 0;
+  c->isplit = in.nsplit > 0 ? 1 : 0;
+  c->rng_ready = false;
   std::vector<int64_t> voff(ns, 0), toff(ns);
   for (int s = 0; s < ns; ++s) toff[s] = c->sp[s].np;
   int rc = 0;
@@ -682,9 +728,11 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
       voff[s] += np;
       toff[s] += nt;
     }
+    if (!rc) c->blk_rng[b] = g;  // remove / split continue this block's stream
   }
   (void)hipHostFree(stage);
   if (rc) return rc;
+  c->rng_ready = true;
   c->cur = 0;
   c->loaded = true;
   c->itime = 0;
@@ -721,6 +769,8 @@ int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, con
   HIP_TRY(hipMemcpy(A.w, w, sizeof(double) * n, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S.p, p, sizeof(double) * n, hipMemcpyHostToDevice));
   S.np = np;
+  if (c->nblk == 1) c->blk_np[isp][0] = np;
+  c->rng_ready = false;  // the host's loader owns the random stream now
   c->loaded = true;
   return 0;
 }
@@ -827,8 +877,142 @@ int pic1dp_hip_push(pic1dp_ctx *c, int32_t irk) {
   return enqueue_push(c, irk, false);
 }
 
+static int allreduce_doubles(pic1dp_ctx *c, double *d, size_t n);
+
+// ---- marker optimisation (host side, rare; see optimize.hpp) -------------------
+// which events are due for the step that is being taken: merge, remove, split
+static void optimize_due(const pic1dp_ctx *c, bool due[3]) {
+  const pic1dp_input &in = c->in;
+  const double t = c->time + in.dt;  // src/pic1dp_particle.F90:742,756,770
+  due[0] = c->imerge > 0 && c->imerge <= in.nmerge && t >= in.tmerge[c->imerge - 1];
+  due[1] = c->iremove > 0 && c->iremove <= in.nremove && t >= in.tremove[c->iremove - 1];
+  due[2] = c->isplit > 0 && c->isplit <= in.nsplit && t >= in.tsplit[c->isplit - 1];
+  if (in.deltaf == 0) due[0] = due[1] = due[2] = false;  // :734
+}
+
+static bool optimize_due_any(const pic1dp_ctx *c) {
+  bool due[3];
+  optimize_due(c, due);
+  return due[0] || due[1] || due[2];
+}
+
+int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optimized) {
+  CHECK_CTX(c);
+  if (flag_optimized) *flag_optimized = 0;
+  if (irk != 1 && irk != 2) return fail(PIC1DP_ERR_ARG, "irk must be 1 or 2");
+  bool due[3];
+  optimize_due(c, due);
+  if (irk != 2 || !(due[0] || due[1] || due[2])) return 0;
+  if (int rc = require_loaded(c)) return rc;
+  if (c->cur != 0) return fail(PIC1DP_ERR_STATE, "particle_optimize must follow the push of sub-step 2");
+  if ((due[1] || due[2]) && !c->rng_ready)
+    return fail(PIC1DP_ERR_STATE,
+                "particle_remove / particle_split continue the loader's random stream: load the markers with "
+                "pic1dp_hip_particle_load");
+  const pic1dp_input &in = c->in;
+  const int ns = in.nspecies, nb = c->nblk, nv = in.nv;
+  for (int s = 0; s < ns; ++s) {
+    int64_t sum = 0;
+    for (int b = 0; b < nb; ++b) sum += c->blk_np[s][b];
+    if (sum != c->sp[s].np) return fail(PIC1DP_ERR_STATE, "marker counts per block unknown (uploaded over several blocks)");
+  }
+  Span tm(c, PIC1DP_IWT_PARTICLE_OPTIMIZE, c->timers_on);
+  HIP_TRY(hipStreamSynchronize(c->st));
+  // host copy of every owned block, full allocation (valid markers + tail slots)
+  struct Block {
+    std::vector<double> a[4];  // x v p w
+  };
+  std::vector<std::vector<Block>> host(ns, std::vector<Block>(nb));
+  for (int s = 0; s < ns; ++s) {
+    Species &S = c->sp[s];
+    const double *dev[4] = {S.set[0].x, S.set[0].v, S.p, S.set[0].w};
+    int64_t voff = 0, toff = S.np;
+    for (int b = 0; b < nb; ++b) {
+      const int64_t na = c->blk_alloc[b], np = c->blk_np[s][b];
+      for (int k = 0; k < 4; ++k) {
+        host[s][b].a[k].resize(static_cast<size_t>(na));
+        HIP_TRY(hipMemcpy(host[s][b].a[k].data(), dev[k] + voff, sizeof(double) * np, hipMemcpyDeviceToHost));
+        if (na > np)
+          HIP_TRY(hipMemcpy(host[s][b].a[k].data() + np, dev[k] + toff, sizeof(double) * (na - np), hipMemcpyDeviceToHost));
+      }
+      voff += np;
+      toff += na - np;
+    }
+  }
+  const double *times[3] = {in.tmerge, in.tremove, in.tsplit};
+  const double *thresholds[3] = {in.thshmerge, in.thshremove, in.thshsplit};
+  int *counters[3] = {&c->imerge, &c->iremove, &c->isplit};
+  (void)times;
+  std::vector<double> hist(static_cast<size_t>(ns) * nv), local(nv);
+  for (int kind = 0; kind < 3; ++kind) {
+    if (!due[kind]) continue;
+    // particle_compute_dist_pertb_abs_v: block by block, summed in block order,
+    // then over processes (MPI_Allreduce, :392)
+    for (int s = 0; s < ns; ++s) {
+      double *h = &hist[static_cast<size_t>(s) * nv];
+      for (int b = 0; b < nb; ++b) {
+        std::fill(local.begin(), local.end(), 0.0);
+        opt_histogram(in, c->blk_np[s][b], host[s][b].a[1].data(), host[s][b].a[3].data(), local.data());
+        for (int i = 0; i < nv; ++i) h[i] = b == 0 ? local[i] : h[i] + local[i];
+      }
+    }
+    if (c->lay.nranks > 1 || c->comm) {
+      double *d = c->d_scratch;
+      if (static_cast<size_t>(ns) * nv > static_cast<size_t>(kEnergyBlocks) * 3)
+        return fail(PIC1DP_ERR_ARG, "nv too large for the reduction scratch");
+      HIP_TRY(hipMemcpy(d, hist.data(), sizeof(double) * ns * nv, hipMemcpyHostToDevice));
+      if (int rc = allreduce_doubles(c, d, static_cast<size_t>(ns) * nv)) return rc;
+      HIP_TRY(hipStreamSynchronize(c->st));
+      HIP_TRY(hipMemcpy(hist.data(), d, sizeof(double) * ns * nv, hipMemcpyDeviceToHost));
+    }
+    const double th = thresholds[kind][*counters[kind] - 1];
+    for (int b = 0; b < nb; ++b)
+      for (int s = 0; s < ns; ++s) {
+        Block &B = host[s][b];
+        const double *h = &hist[static_cast<size_t>(s) * nv];
+        int64_t &np = c->blk_np[s][b];
+        if (kind == 0)
+          opt_merge(in, th, h, np, B.a[0].data(), B.a[1].data(), B.a[2].data(), B.a[3].data());
+        else if (kind == 1)
+          opt_remove(in, th, h, c->blk_rng[b], np, B.a[0].data(), B.a[1].data(), B.a[2].data(), B.a[3].data());
+        else
+          opt_split(in, th, h, c->blk_rng[b], c->blk_alloc[b], np, B.a[0].data(), B.a[1].data(), B.a[2].data(),
+                    B.a[3].data());
+      }
+    *counters[kind] += 1;
+  }
+  // back to the device: valid markers of all blocks packed first, tails behind
+  for (int s = 0; s < ns; ++s) {
+    Species &S = c->sp[s];
+    S.np = 0;
+    for (int b = 0; b < nb; ++b) S.np += c->blk_np[s][b];
+    double *dev[4] = {S.set[0].x, S.set[0].v, S.p, S.set[0].w};
+    int64_t voff = 0, toff = S.np;
+    for (int b = 0; b < nb; ++b) {
+      const int64_t na = c->blk_alloc[b], np = c->blk_np[s][b];
+      for (int k = 0; k < 4; ++k) {
+        HIP_TRY(hipMemcpy(dev[k] + voff, host[s][b].a[k].data(), sizeof(double) * np, hipMemcpyHostToDevice));
+        if (na > np)
+          HIP_TRY(hipMemcpy(dev[k] + toff, host[s][b].a[k].data() + np, sizeof(double) * (na - np), hipMemcpyHostToDevice));
+      }
+      voff += np;
+      toff += na - np;
+    }
+  }
+  if (flag_optimized) *flag_optimized = 1;
+  return tm.end();
+}
+
 static int substep_impl(pic1dp_ctx *c, int irk, bool record) {
-  if (int rc = enqueue_push(c, irk, true)) return rc;
+  if (irk == 2 && optimize_due_any(c)) {
+    // src/pic1dp.F90:80-88: push, particle_optimize, collect_charge -- the pushed
+    // state has to exist in memory for the host-side optimisation
+    if (int rc = enqueue_push(c, irk, false)) return rc;
+    if (int rc = pic1dp_hip_particle_optimize(c, irk, nullptr)) return rc;
+    if (int rc = enqueue_deposit(c)) return rc;
+  } else if (int rc = enqueue_push(c, irk, true)) {
+    return rc;
+  }
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (multi) {
     HIP_TRY(launch_charge_local(c->fa, c->st));
@@ -925,7 +1109,8 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
   if (int rc = require_loaded(c)) return rc;
   const bool recompute = step_recompute_ok(c);
   for (int it = 0; it < nsteps; ++it) {
-    if (recompute) {
+    // a step in which a marker optimisation is due goes through the sub-steps
+    if (recompute && !optimize_due_any(c)) {
       // E0 = d_E stays untouched until the second solve overwrites it
       if (int rc = step_phase(c, false, c->d_Eh, false)) return rc;
       if (int rc = step_phase(c, true, c->d_E, true)) return rc;

@@ -24,6 +24,7 @@ class Multirand {
   bool selftest(int al_int);
 
   uint64_t next();                         // multirand_int64 (as unsigned bits)
+  double real() { return to_real(next()); }  // multirand_real64
   void fill_real(double *a, int64_t n);    // multirand_real_array64
   void fill_gaussian(double *a, int64_t n);  // multirand_gaussian_array64
 

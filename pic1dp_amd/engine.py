@@ -47,6 +47,17 @@ def make_input(**kw):
         # input_species_nparticle_init = input_nparticle_max (src/pic1dp_input.F90:117)
         for s in range(max(0, min(inp.nspecies, _lib.MAX_SPECIES))):
             inp.species_nparticle_init[s] = inp.nparticle_max
+    # marker-optimisation lists not given: the reference's implied-do formulas of the
+    # counts (src/pic1dp_input.F90:149-158, 165-180, 191-200)
+    for kind in ("merge", "remove", "split"):
+        n = max(0, min(getattr(inp, "n" + kind), _lib.MAX_OPT))
+        if "t" + kind not in kw:
+            for i in range(1, n + 1):
+                getattr(inp, "t" + kind)[i - 1] = 50.0 + i * 0.5
+        if "thsh" + kind not in kw:
+            for i in range(1, n + 1):
+                val = 1.0 - 0.9 / max(n, 1) * float(i) if kind == "split" else 0.1 / max(n, 1) * float(i)
+                getattr(inp, "thsh" + kind)[i - 1] = val
     return inp
 
 
@@ -123,6 +134,13 @@ class Pic1dp:
 
     def interaction_push_particle(self, irk):
         check(self.L.pic1dp_hip_push(self._ctx, irk))
+
+    def particle_optimize(self, irk=2):
+        """particle_optimize (src/pic1dp_particle.F90:724-783) after the push of
+        sub-step irk; True when a merge / remove / split was performed"""
+        flag = C.c_int32()
+        check(self.L.pic1dp_hip_particle_optimize(self._ctx, irk, C.byref(flag)))
+        return bool(flag.value)
 
     def substep(self, irk):
         """push(irk) + collect_charge + solve_field, push and deposit fused"""
@@ -310,6 +328,7 @@ class Pic1dp:
             else:
                 for irk in (1, 2):
                     self.interaction_push_particle(irk)
+                    self.particle_optimize(irk)            # src/pic1dp.F90:82
                     self.interaction_collect_charge()
                     self.field_solve_electric()
                 self.set_time(self.itime + 1, self.time + self.inp.dt)

@@ -37,6 +37,15 @@ real(kpr), parameter :: input_v_max = 8.0_kpr
 integer(c_int32_t), parameter :: input_nx = 192
 integer(c_int32_t), parameter :: input_nv = 128
 integer(c_int32_t), parameter :: input_iptclshape = 4
+! marker optimisation: counts, times and thresholds (the lists are implied-do
+! expressions of the counts, like the reference's)
+integer(c_int32_t), parameter :: input_nmerge = 0
+integer(c_int32_t), parameter :: input_nremove = 0
+integer(c_int32_t), parameter :: input_typeremove = 2
+real(kpr), parameter :: input_remove_frac = 0.9_kpr
+integer(c_int32_t), parameter :: input_nsplit = 0
+integer(c_int32_t), parameter :: input_split_ngroup = 5
+real(kpr), parameter :: input_split_dv_sig_frac = 0.1_kpr
 integer(c_int32_t), parameter :: input_multirand_al_int = 3
 ! the reference ships 3 (/dev/urandom); 1 = constant seeds, reproducible
 integer(c_int32_t), parameter :: input_multirand_seed_type = 1
@@ -116,6 +125,25 @@ subroutine input_fill(inp)
   inp%output_interval = input_output_interval
   inp%nx_opd = input_nx_opd
   inp%nv_opd = input_nv_opd
+  inp%nmerge = input_nmerge
+  inp%nremove = input_nremove
+  inp%nsplit = input_nsplit
+  inp%typeremove = input_typeremove
+  inp%remove_frac = input_remove_frac
+  inp%split_ngroup = input_split_ngroup
+  inp%split_dv_sig_frac = input_split_dv_sig_frac
+  do s = 1, input_nmerge
+    inp%tmerge(s) = 50.0_kpr + s * 0.5_kpr
+    inp%thshmerge(s) = 0.1_kpr / max(input_nmerge, 1) * real(s, kpr)
+  end do
+  do s = 1, input_nremove
+    inp%tremove(s) = 50.0_kpr + s * 0.5_kpr
+    inp%thshremove(s) = 0.1_kpr / max(input_nremove, 1) * real(s, kpr)
+  end do
+  do s = 1, input_nsplit
+    inp%tsplit(s) = 50.0_kpr + s * 0.5_kpr
+    inp%thshsplit(s) = 1.0_kpr - 0.9_kpr / max(input_nsplit, 1) * real(s, kpr)
+  end do
   ! test-size overrides
   n = inp%nparticle_max
   call env_int64('PIC1DP_NPARTICLE', n)

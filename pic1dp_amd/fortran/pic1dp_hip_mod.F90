@@ -10,15 +10,16 @@ module pic1dp_hip
 use iso_c_binding
 implicit none
 
-integer(c_int), parameter :: PIC1DP_ABI_VERSION = 1
+integer(c_int), parameter :: PIC1DP_ABI_VERSION = 2
 integer(c_int), parameter :: PIC1DP_MAX_SPECIES = 8
 integer(c_int), parameter :: PIC1DP_MAX_MODES = 64
 integer(c_int), parameter :: PIC1DP_MAX_INIT_MODES = 16
 integer(c_int), parameter :: PIC1DP_COMM_ID_BYTES = 128
+integer(c_int), parameter :: PIC1DP_MAX_OPT = 32
 
 ! wall-clock timer ids = the reference's (src/pic1dp_global.F90:38-50)
 integer(c_int32_t), parameter :: PIC1DP_IWT_PUSH_PARTICLE = 4, PIC1DP_IWT_COLLECT_CHARGE = 6, &
-  PIC1DP_IWT_FIELD_ELECTRIC = 7, PIC1DP_IWT_MPIALLREDU = 21
+  PIC1DP_IWT_FIELD_ELECTRIC = 7, PIC1DP_IWT_PARTICLE_OPTIMIZE = 8, PIC1DP_IWT_MPIALLREDU = 21
 
 ! struct pic1dp_input: run-time mirror of the parameters of src/pic1dp_input.F90
 type, bind(C) :: pic1dp_input_t
@@ -34,6 +35,12 @@ type, bind(C) :: pic1dp_input_t
   integer(c_int32_t) :: modes(PIC1DP_MAX_MODES)
   integer(c_int32_t) :: init_mode(PIC1DP_MAX_INIT_MODES)
   real(c_double) :: init_mode_cos(PIC1DP_MAX_INIT_MODES), init_mode_sin(PIC1DP_MAX_INIT_MODES)
+  ! marker optimisation (src/pic1dp_input.F90:141-206)
+  integer(c_int32_t) :: nmerge, nremove, nsplit, typeremove, split_ngroup, reserved0
+  real(c_double) :: remove_frac, split_dv_sig_frac
+  real(c_double) :: tmerge(PIC1DP_MAX_OPT), thshmerge(PIC1DP_MAX_OPT)
+  real(c_double) :: tremove(PIC1DP_MAX_OPT), thshremove(PIC1DP_MAX_OPT)
+  real(c_double) :: tsplit(PIC1DP_MAX_OPT), thshsplit(PIC1DP_MAX_OPT)
 end type pic1dp_input_t
 
 ! struct pic1dp_layout: this process in the particle decomposition
@@ -203,6 +210,13 @@ interface
     integer(c_int32_t), value :: irk
     integer(c_int) :: ierr
   end function pic1dp_hip_push
+  function pic1dp_hip_particle_optimize(ctx, irk, flag_optimized) bind(C, name="pic1dp_hip_particle_optimize") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: irk
+    integer(c_int32_t), intent(out) :: flag_optimized
+    integer(c_int) :: ierr
+  end function pic1dp_hip_particle_optimize
   function pic1dp_hip_substep(ctx, irk) bind(C, name="pic1dp_hip_substep") result(ierr)
     import
     type(c_ptr), value :: ctx

@@ -8,6 +8,7 @@
 !   :71,:88  interaction_collect_charge      pic1dp_hip_collect_charge(ctx)
 !   :72,:89  field_solve_electric            pic1dp_hip_solve_field(ctx)
 !   :80      interaction_push_particle       pic1dp_hip_push(ctx, global_irk)
+!   :82      particle_optimize               pic1dp_hip_particle_optimize(ctx, global_irk, flag)
 !
 ! With PIC1DP_FUSED=1 in the environment the three calls of a sub-step are
 ! replaced by the fused pic1dp_hip_substep(ctx, global_irk); with PIC1DP_FUSED=2
@@ -24,7 +25,7 @@ implicit none
 type(pic1dp_input_t) :: inp
 type(pic1dp_layout_t) :: lay
 type(c_ptr) :: ctx
-integer(c_int32_t) :: global_irk, global_itime, itermination, due
+integer(c_int32_t) :: global_irk, global_itime, itermination, due, flag_optimized
 real(c_double) :: global_time, ms_push, ms_charge, ms_field
 character(len=8) :: buf
 integer :: stat
@@ -62,6 +63,7 @@ do while (itermination == 0)                 ! main time evolution loop
         call pic1dp_hip_check(pic1dp_hip_substep(ctx, global_irk), 'substep')
       else
         call pic1dp_hip_check(pic1dp_hip_push(ctx, global_irk), 'push')
+        call pic1dp_hip_check(pic1dp_hip_particle_optimize(ctx, global_irk, flag_optimized), 'particle_optimize')
         call pic1dp_hip_check(pic1dp_hip_collect_charge(ctx), 'collect_charge')
         call pic1dp_hip_check(pic1dp_hip_solve_field(ctx), 'solve_field')
       end if

@@ -70,8 +70,10 @@ def test_input_defaults_mirror_reference_input_file(amd, oracle_mod):
     assert g.output_interval == 0.5 and g.nx_opd == 64 and g.nv_opd == 64
     assert (g.species_charge[0], g.species_mass[0], g.species_density[0], g.species_v0[0]) == (-1.0, 1.0, 0.9, 5.0)
     assert g.init_mode_sin[0] == 1e-5 and g.init_mode_cos[0] == 0.0
+    assert (g.nmerge, g.nremove, g.nsplit, g.typeremove, g.split_ngroup) == (0, 0, 0, 2, 5)
+    assert (g.remove_frac, g.split_dv_sig_frac) == (0.9, 0.1)
     for name, _ in oracle_mod.OrcInput._fields_:
-        if name == "pad0":
+        if name in ("pad0", "pad1"):
             continue
         a, b = getattr(g, name), getattr(o, name)
         if hasattr(a, "__len__"):
