@@ -98,6 +98,10 @@ struct pic1dp_ctx {
   double *d_Eh = nullptr;  // field after the first sub-step of the last whole-step call
   int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
   int field_solver = 0;    // 0 the reference's mode-filter DFT solve, 1 finite-difference tridiagonal (opt-in)
+  // marker state (bytes) above which k_step_half / k_step_full stream non-temporally
+  // (measured crossovers at nx = 1024: 0.9e7 markers for the read-only half kernel, ~3e7 for the
+  // read-modify-write full kernel, whose plain stores stay ahead for longer)
+  double nt_threshold_half = 288.0 * 1048576.0, nt_threshold_full = 768.0 * 1048576.0;
   int64_t hist_count = 0;
   int32_t itime = 0;
   double time = 0.0;
@@ -543,6 +547,9 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   c->grid.rlx = 1.0 / in->lx;
   c->grid.fast_div = 1;
   if (const char *e = std::getenv("PIC1DP_FAST_DIV")) c->grid.fast_div = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_MB"))
+    c->nt_threshold_half = c->nt_threshold_full = std::atof(e) * 1048576.0;
+  if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_FULL_MB")) c->nt_threshold_full = std::atof(e) * 1048576.0;
 
   // particle storage: valid markers of the owned blocks packed first, block
   // tails (allocated but unloaded slots) behind them
@@ -1064,6 +1071,10 @@ static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
 
 // sub-step of the whole-step path: particle kernel(s), charge, field into Eout
 static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
+  // x, v, w, p of all species against the 256 MiB Infinity Cache
+  double state_bytes = 0.0;
+  for (int s = 0; s < c->in.nspecies; ++s) state_bytes += 32.0 * static_cast<double>(c->sp[s].np);
+  const int stream_nt = state_bytes > (full ? c->nt_threshold_full : c->nt_threshold_half) ? 1 : 0;
   for (int s = 0; s < c->in.nspecies; ++s) {
     Species &S = c->sp[s];
     if (S.np <= 0) continue;
@@ -1083,6 +1094,7 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
     a.iptcldist = c->in.iptcldist;
     a.deltaf = c->in.deltaf;
     a.linear = c->in.linear;
+    a.stream_nt = stream_nt;
     LaunchCfg lc = step_launch(c, S.np, full);
     Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
     Span ks(c, full ? kTagStepFull : kTagStepHalf, c->stats_on);

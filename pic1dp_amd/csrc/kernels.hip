@@ -54,24 +54,28 @@ __device__ __forceinline__ void glb_add(double *p, double v) {
 #endif
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ double2 ld2(const double2 *p) {
-#if PIC1DP_NT
-  const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
-  return make_double2(t.x, t.y);
-#else
-  return *p;
-#endif
+template <bool NT>
+__device__ __forceinline__ double2 ld2t(const double2 *p) {
+  if constexpr (NT) {
+    const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+    return make_double2(t.x, t.y);
+  } else {
+    return *p;
+  }
 }
-__device__ __forceinline__ void st2(double2 *p, double a, double b) {
-#if PIC1DP_NT
-  v2d t;
-  t.x = a;
-  t.y = b;
-  __builtin_nontemporal_store(t, reinterpret_cast<v2d *>(p));
-#else
-  *p = make_double2(a, b);
-#endif
+template <bool NT>
+__device__ __forceinline__ void st2t(double2 *p, double a, double b) {
+  if constexpr (NT) {
+    v2d t;
+    t.x = a;
+    t.y = b;
+    __builtin_nontemporal_store(t, reinterpret_cast<v2d *>(p));
+  } else {
+    *p = make_double2(a, b);
+  }
 }
+__device__ __forceinline__ double2 ld2(const double2 *p) { return ld2t<PIC1DP_NT != 0>(p); }
+__device__ __forceinline__ void st2(double2 *p, double a, double b) { st2t<PIC1DP_NT != 0>(p, a, b); }
 
 // Division by a species constant c, bit-identical to a / c in all three forms:
 //   POW2 = 0  a / c             (general)
@@ -326,9 +330,14 @@ struct StepArgsDev {
   double dt_half, dt_full;
   GridConst g;
   SpeciesConst s;
+  int nt;
 };
 
-template <int DIST, int MODE, int POW2>
+// NT: non-temporal loads and stores.  They win once the marker state no longer
+// fits the 256 MiB Infinity Cache (+15 % at 2e7 markers); below that, plain
+// accesses keep the state cache-resident between the two kernels of a step
+// (+5 % at the reference's default 6.4e6 markers).  Chosen per launch.
+template <int DIST, int MODE, int POW2, bool NT>
 __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *sE = reinterpret_cast<double *>(smem);
@@ -348,9 +357,9 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   const double2 *w2 = reinterpret_cast<const double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
-    const double2 X = ld2(x2 + j), V = ld2(v2 + j), P = ld2(p2 + j);
+    const double2 X = ld2t<NT>(x2 + j), V = ld2t<NT>(v2 + j), P = ld2t<NT>(p2 + j);
     double2 W = make_double2(0.0, 0.0);
-    if constexpr (HAS_W) W = ld2(w2 + j);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + j);
     const One h0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, X.x, V.x, W.x, sE, a.dt_half, a.g, a.s);
     const One h1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, X.y, V.y, W.y, sE, a.dt_half, a.g, a.s);
     deposit_one(h0.x, HAS_W ? h0.w : P.x, sR, a.g);
@@ -381,7 +390,7 @@ __device__ __forceinline__ One step_full_one(double x, double v, double w, doubl
   return n;
 }
 
-template <int DIST, int MODE, int POW2>
+template <int DIST, int MODE, int POW2, bool NT>
 __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nx = a.g.nx;
@@ -408,14 +417,14 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
-    const double2 X = ld2(x2 + j), V = ld2(v2 + j), P = ld2(p2 + j);
+    const double2 X = ld2t<NT>(x2 + j), V = ld2t<NT>(v2 + j), P = ld2t<NT>(p2 + j);
     double2 W = make_double2(0.0, 0.0);
-    if constexpr (HAS_W) W = ld2(w2 + j);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + j);
     const One n0 = step_full_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a);
     const One n1 = step_full_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a);
-    st2(x2 + j, n0.x, n1.x);
-    if constexpr (PUSH_V) st2(v2 + j, n0.v, n1.v);
-    if constexpr (HAS_W) st2(w2 + j, n0.w, n1.w);
+    st2t<NT>(x2 + j, n0.x, n1.x);
+    if constexpr (PUSH_V) st2t<NT>(v2 + j, n0.v, n1.v);
+    if constexpr (HAS_W) st2t<NT>(w2 + j, n0.w, n1.w);
   }
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = a.np - 1;
@@ -442,8 +451,11 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc,
 
 template <int DIST, int MODE, int POW2>
 hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
-  return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2>, d, lc, st)
-              : launch_step_kernel(k_step_half<DIST, MODE, POW2>, d, lc, st);
+  if (d.nt)
+    return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true>, d, lc, st)
+                : launch_step_kernel(k_step_half<DIST, MODE, POW2, true>, d, lc, st);
+  return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, false>, d, lc, st)
+              : launch_step_kernel(k_step_half<DIST, MODE, POW2, false>, d, lc, st);
 }
 
 template <int DIST>
@@ -558,6 +570,7 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.dt_full = a.dt_full;
   d.g = a.g;
   d.s = a.s;
+  d.nt = a.stream_nt;
   switch (a.iptcldist) {
     case 1: return launch_step_d<1>(d, a.deltaf, a.linear, full, lc, st);
     case 2: return launch_step_d<2>(d, a.deltaf, a.linear, full, lc, st);

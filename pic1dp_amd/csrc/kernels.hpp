@@ -66,6 +66,7 @@ struct StepArgs {
   GridConst g;
   SpeciesConst s;
   int iptcldist, deltaf, linear;
+  int stream_nt;       // 1: non-temporal loads/stores (state larger than the Infinity Cache)
 };
 // full = false: first sub-step (deposit of the half-step state, nothing stored)
 // full = true : second sub-step (recompute half-step state, push, deposit, store)

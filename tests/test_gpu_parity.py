@@ -277,11 +277,15 @@ STEP_CASES = [(n, kw, lin) for n, kw in DIST_CASES for lin in (0, 1)] + [
     ("full_f", dict(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0]), 0)]
 
 
+@pytest.mark.parametrize("stream", ["plain", "nt"])
 @pytest.mark.parametrize("name,kw,linear", STEP_CASES, ids=lambda v: str(v) if not isinstance(v, dict) else "")
-def test_whole_step_recompute_equals_substeps(amd, name, kw, linear):
+def test_whole_step_recompute_equals_substeps(amd, monkeypatch, name, kw, linear, stream):
     """pic1dp_hip_step's default path never stores the half-step state: the
     second kernel recomputes it from the step-start state and field.  Given the
-    same two fields it must reproduce the two-sub-step path bit for bit."""
+    same two fields it must reproduce the two-sub-step path bit for bit -- in
+    both instantiations of the kernels (plain accesses for cache-resident
+    marker counts, non-temporal ones above PIC1DP_NT_THRESHOLD_MB)."""
+    monkeypatch.setenv("PIC1DP_NT_THRESHOLD_MB", "0" if stream == "nt" else "1e9")
     inp = amd.make_input(nparticle_max=N_SMALL, nx=96, linear=linear, **kw)
     a, b = amd.Pic1dp(inp), amd.Pic1dp(inp)
     for e in (a, b):
