@@ -33,9 +33,9 @@
 extern "C" {
 #endif
 
-#define PIC1DP_ABI_VERSION 2
+#define PIC1DP_ABI_VERSION 3
 #define PIC1DP_MAX_SPECIES 8
-#define PIC1DP_MAX_MODES 64
+#define PIC1DP_MAX_MODES 4096 /* up to the full spectrum nx/2 of the largest grid */
 #define PIC1DP_MAX_INIT_MODES 16
 #define PIC1DP_COMM_ID_BYTES 128
 #define PIC1DP_MAX_OPT 32

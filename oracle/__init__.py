@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_LIB_PATH = os.path.join(HERE, "_ref", "libmultirand_ref.so")
 
 MAX_SPECIES = 8
-MAX_MODES = 64
+MAX_MODES = 4096
 MAX_INIT_MODES = 16
 NSEED = 20635
 MAX_OPT = 32

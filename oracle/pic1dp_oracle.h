@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define ORC_MAX_SPECIES 8
-#define ORC_MAX_MODES 64
+#define ORC_MAX_MODES 4096
 #define ORC_MAX_INIT_MODES 16
 #define ORC_MULTIRAND_NSEED 20635
 #define ORC_MAX_OPT 32

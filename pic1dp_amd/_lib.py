@@ -11,10 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIC1DP_LIB") or os.path.join(HERE, "lib", "libpic1dp_hip.so")
 
 MAX_SPECIES = 8
-MAX_MODES = 64
+MAX_MODES = 4096
 MAX_INIT_MODES = 16
 COMM_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_OPT = 32
 
 ERR_NAMES = {1: "ARG", 2: "HIP", 3: "NODEVICE", 4: "STATE", 5: "COMM", 6: "RNG", 7: "NOMEM"}

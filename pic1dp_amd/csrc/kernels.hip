@@ -754,6 +754,58 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
   }
 }
 
+// Many kept modes (2*nmode > FIELD_THREADS, up to the full spectrum nmode = nx/2,
+// SURVEY N4): the same arithmetic in the same order, spread over workgroups.
+// The reference's operators are then O(nx^2) dense matrices exactly as here
+// (doc/formulation.tex:288-290); one thread still owns one serial sum.
+constexpr int WIDE_THREADS = 64;
+
+// forward sums: chain t -> mode t>>1, (t&1 ? cos-table : -sin-table), ascending ix
+__global__ void __launch_bounds__(WIDE_THREADS) k_field_modes_wide(const FieldArgs f) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sCD = reinterpret_cast<double *>(smem);  // [nx]
+  const int nx = f.nx, nm = f.nmode;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sCD[ix] = f.chargeden[ix];
+  __syncthreads();
+  const int chain = blockIdx.x * blockDim.x + threadIdx.x;
+  if (chain >= 2 * nm) return;
+  const int m = chain >> 1;
+  const bool use_cos = chain & 1;
+  const double *tab = (use_cos ? f.fre : f.fim) + static_cast<size_t>(m) * nx;
+  double acc = 0.0;
+  int ix = 0;
+  for (; ix + 8 <= nx; ix += 8) {
+    double t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = tab[ix + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = acc + t[k] * sCD[ix + k];
+  }
+  for (; ix < nx; ++ix) acc = acc + tab[ix] * sCD[ix];
+  if (use_cos)
+    f.mode_im[m] = acc * f.sc_im * f.grad_inv[m];
+  else
+    f.mode_re[m] = acc * f.sc_re * f.grad_inv[m];
+}
+
+// inverse: one grid point per thread, serial over ascending mode (:251-256)
+__global__ void __launch_bounds__(WIDE_THREADS) k_field_inverse_wide(const FieldArgs f) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sMode = reinterpret_cast<double *>(smem);  // [2*nmode]: re then im
+  const int nx = f.nx, nm = f.nmode;
+  for (int m = threadIdx.x; m < nm; m += blockDim.x) {
+    sMode[m] = f.mode_re[m];
+    sMode[nm + m] = f.mode_im[m];
+  }
+  __syncthreads();
+  const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ix >= nx) return;
+  double s = 0.0;
+  for (int m = 0; m < nm; ++m) s = s + f.fre[static_cast<size_t>(m) * nx + ix] * sMode[m];
+  for (int m = 0; m < nm; ++m) s = s + f.fim[static_cast<size_t>(m) * nx + ix] * sMode[nm + m];
+  f.E[ix] = s * 2.0;
+}
+
 __global__ void __launch_bounds__(FIELD_THREADS)
 k_field_energy(const double *E, int nx, double lx, double dnx, double *out) {
   __shared__ double scr[16];
@@ -888,6 +940,18 @@ hipError_t launch_chargeden(const FieldArgs &f, bool with_local, hipStream_t st)
 
 hipError_t launch_field_solve(const FieldArgs &f, bool with_local, bool from_chargeden,
                               hipStream_t st) {
+  if (2 * f.nmode > FIELD_THREADS) {  // many modes: chargeden, forward, inverse, energy
+    if (!from_chargeden) {
+      hipError_t e = launch_chargeden(f, with_local, st);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_field_modes_wide, dim3((2 * f.nmode + WIDE_THREADS - 1) / WIDE_THREADS),
+                       dim3(WIDE_THREADS), sizeof(double) * f.nx, st, f);
+    hipLaunchKernelGGL(k_field_inverse_wide, dim3((f.nx + WIDE_THREADS - 1) / WIDE_THREADS), dim3(WIDE_THREADS),
+                       sizeof(double) * 2 * f.nmode, st, f);
+    if (f.history) hipLaunchKernelGGL(k_field_energy, dim3(1), dim3(FIELD_THREADS), 0, st, f.E, f.nx, f.lx, f.dnx, f.history);
+    return hipGetLastError();
+  }
   const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
                                        (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
   if (from_chargeden) {

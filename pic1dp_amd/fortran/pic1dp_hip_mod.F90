@@ -10,9 +10,9 @@ module pic1dp_hip
 use iso_c_binding
 implicit none
 
-integer(c_int), parameter :: PIC1DP_ABI_VERSION = 2
+integer(c_int), parameter :: PIC1DP_ABI_VERSION = 3
 integer(c_int), parameter :: PIC1DP_MAX_SPECIES = 8
-integer(c_int), parameter :: PIC1DP_MAX_MODES = 64
+integer(c_int), parameter :: PIC1DP_MAX_MODES = 4096
 integer(c_int), parameter :: PIC1DP_MAX_INIT_MODES = 16
 integer(c_int), parameter :: PIC1DP_COMM_ID_BYTES = 128
 integer(c_int), parameter :: PIC1DP_MAX_OPT = 32

@@ -56,6 +56,25 @@ def test_field_solve_matches_numpy_fft(oracle_mod):
     assert np.max(np.abs(E - np.fft.ifft(Ek).real)) < 1e-12 * np.max(np.abs(E))
 
 
+def test_field_solve_full_spectrum(oracle_mod):
+    """every mode below Nyquist kept: the filter becomes the plain
+    spectral integral of the zero-mean, Nyquist-free part of chargeden"""
+    nx = 256
+    modes = list(range(1, nx // 2))
+    inp = oracle_mod.make_input(nx=nx, nmode=len(modes), modes=modes)
+    rng = np.random.default_rng(11)
+    rho = rng.standard_normal(nx)
+    E, re, im = oracle_mod.Field(inp).solve(rho)
+    k = 2 * np.pi / inp.lx * np.fft.fftfreq(nx, 1.0 / nx)
+    rk = np.fft.fft(rho)
+    rk[0] = rk[nx // 2] = 0.0
+    ek = np.zeros(nx, dtype=complex)
+    ek[1:] = rk[1:] / (1j * k[1:])
+    want = np.fft.ifft(ek).real
+    assert np.max(np.abs(E - want)) < 1e-12 * np.max(np.abs(want))
+    assert len(re) == len(modes) and len(im) == len(modes)
+
+
 def test_deposit_conserves_charge_and_wraps(oracle_mod):
     inp = oracle_mod.make_input(nx=50)
     rng = np.random.default_rng(2)
