@@ -67,8 +67,45 @@ subroutine output_all(ctx, inp, verbosity)
       cprogress = 't'
     end if
     write (*, '(a, f5.1, a, i7, f9.3, es12.3e3)') cprogress, maxval(progress), '%', itime, time, scal(2)
+  else if (verbosity >= 2) then
+    call pic1dp_hip_check(pic1dp_hip_get_time(ctx, itime, time), 'get_time')
+    write (*, '(a, i7, a, f9.3)') 'Info: finished itime = ', itime, ', time = ', time
   end if
 end subroutine output_all
+
+! output_progress(2) (src/pic1dp_output.F90:487-543): the line after a merge /
+! remove / split event; it is printed inside the time step, hence itime + 1 and
+! time + dt
+subroutine output_progress_optimized(ctx, inp, verbosity)
+  type(c_ptr), intent(in) :: ctx
+  type(pic1dp_input_t), intent(in) :: inp
+  integer(c_int32_t), intent(in) :: verbosity
+  integer(c_int64_t) :: nalloc, np, nparticle_allspec
+  integer(c_int32_t) :: s, itime
+  real(c_double) :: time, progress(2)
+  character :: cprogress
+
+  if (verbosity == 0) return
+  nparticle_allspec = 0
+  do s = 0, inp%nspecies - 1
+    call pic1dp_hip_check(pic1dp_hip_local_sizes(ctx, s, nalloc, np), 'local_sizes')
+    nparticle_allspec = nparticle_allspec + np
+  end do
+  call pic1dp_hip_check(pic1dp_hip_get_time(ctx, itime, time), 'get_time')
+  if (verbosity == 1) then
+    progress(1) = 1e2_c_double * real(itime, c_double) / inp%ntime_max
+    progress(2) = 1e2_c_double * time / inp%time_max
+    if (maxloc(progress, 1) == 1) then
+      cprogress = 'i'
+    else
+      cprogress = 't'
+    end if
+    write (*, '(a, f5.1, a, i7, f9.3, a, i9)') cprogress, maxval(progress), '%', itime + 1, time + inp%dt, &
+      ' : optimization performed, current # of particles ', nparticle_allspec
+  else
+    write (*, '(2a, i9)') 'Info: particle_optimize performed, ', 'current # of particles:', nparticle_allspec
+  end if
+end subroutine output_progress_optimized
 
 subroutine output_final
   close (output_unit_out)

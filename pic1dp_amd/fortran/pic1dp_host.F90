@@ -64,6 +64,7 @@ do while (itermination == 0)                 ! main time evolution loop
       else
         call pic1dp_hip_check(pic1dp_hip_push(ctx, global_irk), 'push')
         call pic1dp_hip_check(pic1dp_hip_particle_optimize(ctx, global_irk, flag_optimized), 'particle_optimize')
+        if (flag_optimized == 1) call output_progress_optimized(ctx, inp, input_verbosity)
         call pic1dp_hip_check(pic1dp_hip_collect_charge(ctx), 'collect_charge')
         call pic1dp_hip_check(pic1dp_hip_solve_field(ctx), 'solve_field')
       end if

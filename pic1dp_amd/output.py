@@ -163,3 +163,14 @@ def progress_line(inp, itime, time, electric_energy):
     pt = 1e2 * time / inp.time_max
     c, pct = ("i", pi) if pi >= pt else ("t", pt)
     return "%s%5.1f%%%7d%9.3f%s\n" % (c, pct, itime, time, _es12_3e3(electric_energy))
+
+
+def progress_line_optimized(inp, itime, time, nparticle_allspec):
+    """output_progress(2) at verbosity 1, printed inside the step that performed a
+    merge / remove / split: '(a, f5.1, a, i7, f9.3, a, i9, a)' with itime + 1 and
+    time + dt (src/pic1dp_output.F90:527-532)"""
+    pi = 1e2 * float(itime) / inp.ntime_max
+    pt = 1e2 * time / inp.time_max
+    c, pct = ("i", pi) if pi >= pt else ("t", pt)
+    return "%s%5.1f%%%7d%9.3f : optimization performed, current # of particles %9d\n" % (
+        c, pct, itime + 1, time + inp.dt, nparticle_allspec)

@@ -73,3 +73,10 @@ def test_progress_line_format(amd):
     assert output.progress_line(inp, 10000, 500.0, 1.2345e+02) == "t100.0%  10000  500.000  1.234E+002\n" \
         or output.progress_line(inp, 10000, 500.0, 1.2345e+02) == "t100.0%  10000  500.000  1.235E+002\n"
     assert output.progress_header().startswith("Info: progress:\nprogrss  itime")
+
+
+def test_progress_line_optimized_format(amd):
+    from pic1dp_amd import output
+    inp = amd.make_input(nparticle_max=1000)
+    assert output.progress_line_optimized(inp, 99, 4.95, 123456) == \
+        "t  1.0%    100    5.000 : optimization performed, current # of particles    123456\n"
