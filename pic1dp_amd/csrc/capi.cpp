@@ -103,6 +103,12 @@ struct pic1dp_ctx {
   // read-modify-write full kernel, whose plain stores stay ahead for longer)
   double nt_threshold_half = 288.0 * 1048576.0, nt_threshold_full = 768.0 * 1048576.0;
   int64_t hist_count = 0;
+  // marker diagnostics of output_all: one fused pass per species (histograms +
+  // kinetic sums), kept until the markers change
+  uint64_t state_version = 1;              // bumped by everything that writes marker arrays
+  std::vector<uint64_t> diag_version;      // [nspecies] version the cached results belong to
+  std::vector<double> diag_sums;           // [nspecies][3]
+  double *d_diag_part = nullptr;           // per-workgroup partial sums of the fused pass
   int32_t itime = 0;
   double time = 0.0;
   GridConst grid{};
@@ -313,6 +319,7 @@ int ensure_second_set(pic1dp_ctx *c) {
 
 int enqueue_push(pic1dp_ctx *c, int irk, bool fused) {
   if (int rc = ensure_second_set(c)) return rc;
+  c->state_version++;
   for (int s = 0; s < c->in.nspecies; ++s) {
     PushArgs a = make_push_args(c, s, irk);
     if (a.np <= 0) continue;
@@ -328,6 +335,7 @@ int enqueue_push(pic1dp_ctx *c, int irk, bool fused) {
 }
 
 int enqueue_deposit(pic1dp_ctx *c) {
+  c->state_version++;  // the wrap is stored back into x
   for (int s = 0; s < c->in.nspecies; ++s) {
     Species &S = c->sp[s];
     if (S.np <= 0) continue;
@@ -664,7 +672,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     if (S.set[1].w != S.set[0].w) (void)hipFree(S.set[1].w);
   }
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
-                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh};
+                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part};
   for (double *b : bufs) (void)hipFree(b);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);
@@ -686,6 +694,7 @@ int pic1dp_hip_local_sizes(pic1dp_ctx *c, int32_t isp, int64_t *nalloc, int64_t 
 int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
+  c->state_version++;
   const pic1dp_input &in = c->in;
   const int npe = c->lay.npe, ns = in.nspecies;
   const int nthreads = load_threads();
@@ -758,6 +767,7 @@ int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, con
   if (np < 0 || np > n) return fail(PIC1DP_ERR_ARG, "np out of range");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->st));
+  c->state_version++;
   // an upload (re)starts from set 0 for every species: slots beyond np live there
   if (c->cur != 0) {
     for (Species &T : c->sp) {
@@ -924,6 +934,7 @@ int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optim
     if (sum != c->sp[s].np) return fail(PIC1DP_ERR_STATE, "marker counts per block unknown (uploaded over several blocks)");
   }
   Span tm(c, PIC1DP_IWT_PARTICLE_OPTIMIZE, c->timers_on);
+  c->state_version++;
   HIP_TRY(hipStreamSynchronize(c->st));
   // host copy of every owned block, full allocation (valid markers + tail slots)
   struct Block {
@@ -1071,6 +1082,7 @@ static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
 
 // sub-step of the whole-step path: particle kernel(s), charge, field into Eout
 static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
+  if (full) c->state_version++;
   // x, v, w, p of all species against the 256 MiB Infinity Cache
   double state_bytes = 0.0;
   for (int s = 0; s < c->in.nspecies; ++s) state_bytes += 32.0 * static_cast<double>(c->sp[s].np);
@@ -1251,29 +1263,64 @@ int pic1dp_hip_energy_history_reset(pic1dp_ctx *c) {
   return 0;
 }
 
+// One fused pass over a species' markers for output_all: histograms of
+// output_ptcldist into d_dist[isp] and the kinetic sums of output_field; results
+// stay valid until the markers change (state_version).
+static size_t dist_len(const pic1dp_input &in) {
+  return 3 * static_cast<size_t>(in.nx_opd) * in.nv_opd + 3 * static_cast<size_t>(in.nv_opd);
+}
+
+static int ensure_diag(pic1dp_ctx *c, int isp) {
+  const pic1dp_input &in = c->in;
+  const int ns = in.nspecies;
+  if (in.nx_opd < 1 || in.nv_opd < 2) return fail(PIC1DP_ERR_ARG, "nx_opd >= 1 and nv_opd >= 2 required");
+  if (c->diag_version.empty()) {
+    c->diag_version.assign(ns, 0);
+    c->diag_sums.assign(3 * static_cast<size_t>(ns), 0.0);
+  }
+  if (c->diag_version[isp] == c->state_version) return 0;
+  const size_t ntot = dist_len(in);
+  // [nspecies] cached histograms + one buffer for the all-reduced copy handed out
+  if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * ntot * (ns + 1)));
+  const int max_blocks = 2 * c->num_cu;
+  if (!c->d_diag_part) HIP_TRY(hipMalloc(&c->d_diag_part, sizeof(double) * 3 * max_blocks));
+  Species &S = c->sp[isp];
+  const PSet &A = S.set[c->cur];
+  double *hist = c->d_dist + ntot * isp;
+  HIP_TRY(hipMemsetAsync(hist, 0, sizeof(double) * ntot, c->st));
+  double *sums = &c->diag_sums[3 * static_cast<size_t>(isp)];
+  sums[0] = sums[1] = sums[2] = 0.0;
+  std::vector<double> part(3 * static_cast<size_t>(std::max(max_blocks, kEnergyBlocks)));
+  if (S.np > 0) {
+    const int blocks = ptcldist_blocks(S.np, in.nx_opd, in.nv_opd, c->num_cu);
+    HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, in.lx, in.v_max, in.nx_opd, in.nv_opd, in.deltaf == 1, hist,
+                            c->d_diag_part, c->num_cu, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(part.data(), c->d_diag_part, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
+    for (int b = 0; b < blocks; ++b)
+      for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
+  }
+  // the reference sums the whole local vector (VecSum); slots beyond np live in set 0
+  const int64_t ntail = S.nalloc - S.np;
+  if (ntail > 0) {
+    const int blocks = static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256));
+    HIP_TRY(launch_energy_sums(S.set[0].v + S.np, S.p + S.np, in.deltaf ? S.set[0].w + S.np : nullptr, ntail,
+                               c->d_scratch, blocks, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(part.data(), c->d_scratch, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
+    for (int b = 0; b < blocks; ++b)
+      for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
+  }
+  c->diag_version[isp] = c->state_version;
+  return 0;
+}
+
 int pic1dp_hip_energy_sums(pic1dp_ctx *c, int32_t isp, double out[3]) {
   CHECK_CTX(c);
   if (isp < 0 || isp >= c->in.nspecies || !out) return fail(PIC1DP_ERR_ARG, "bad argument");
   if (int rc = require_loaded(c)) return rc;
-  Species &S = c->sp[isp];
-  const PSet &A = S.set[c->cur];
-  // the reference sums the whole local vector (VecSum); slots beyond np live in set 0
-  std::vector<double> part(kEnergyBlocks * 3);
-  out[0] = out[1] = out[2] = 0.0;
-  struct Seg {
-    const double *v, *p, *w;
-    int64_t n;
-  } segs[2] = {{A.v, S.p, c->in.deltaf ? A.w : nullptr, S.np},
-               {S.set[0].v + S.np, S.p + S.np, c->in.deltaf ? S.set[0].w + S.np : nullptr, S.nalloc - S.np}};
-  for (const Seg &g : segs) {
-    if (g.n <= 0) continue;
-    int blocks = static_cast<int>(std::min<int64_t>(kEnergyBlocks, (g.n + 255) / 256));
-    HIP_TRY(launch_energy_sums(g.v, g.p, g.w, g.n, c->d_scratch, blocks, c->st));
-    HIP_TRY(hipStreamSynchronize(c->st));
-    HIP_TRY(hipMemcpy(part.data(), c->d_scratch, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
-    for (int b = 0; b < blocks; ++b)
-      for (int k = 0; k < 3; ++k) out[k] += part[b * 3 + k];
-  }
+  if (int rc = ensure_diag(c, isp)) return rc;
+  for (int k = 0; k < 3; ++k) out[k] = c->diag_sums[3 * static_cast<size_t>(isp) + k];
   if (!c->in.deltaf) out[2] = out[1];
   return 0;
 }
@@ -1373,20 +1420,20 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *mark
   if (int rc = require_loaded(c)) return rc;
   const pic1dp_input &in = c->in;
   const int nxo = in.nx_opd, nvo = in.nv_opd;
-  if (nxo < 1 || nvo < 2) return fail(PIC1DP_ERR_ARG, "nx_opd >= 1 and nv_opd >= 2 required");
+  if (int rc = ensure_diag(c, isp)) return rc;
   const size_t nxv = static_cast<size_t>(nxo) * nvo, ntot = 3 * nxv + 3 * nvo;
-  if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * ntot));
-  HIP_TRY(hipMemsetAsync(c->d_dist, 0, sizeof(double) * ntot, c->st));
-  Species &S = c->sp[isp];
-  const PSet &A = S.set[c->cur];
-  if (S.np > 0)
-    HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, in.lx, in.v_max, nxo, nvo, in.deltaf == 1, c->d_dist,
-                            c->num_cu, c->st));
-  if (finish)
-    if (int rc = allreduce_doubles(c, c->d_dist, ntot)) return rc;
+  const double *hist = c->d_dist + ntot * isp;
+  if (finish && c->comm) {  // reduce a copy: the cached local histograms stay local
+    double *red = c->d_dist + ntot * in.nspecies;
+    HIP_TRY(hipMemcpyAsync(red, hist, sizeof(double) * ntot, hipMemcpyDeviceToDevice, c->st));
+    if (int rc = allreduce_doubles(c, red, ntot)) return rc;
+    hist = red;
+  } else if (finish) {
+    if (int rc = allreduce_doubles(c, nullptr, 0)) return rc;  // nranks > 1 without communicator: error
+  }
   std::vector<double> h(ntot);
   HIP_TRY(hipStreamSynchronize(c->st));
-  HIP_TRY(hipMemcpy(h.data(), c->d_dist, sizeof(double) * ntot, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(h.data(), hist, sizeof(double) * ntot, hipMemcpyDeviceToHost));
   double *mxv = h.data(), *txv = mxv + nxv, *pxv = txv + nxv, *mv = pxv + nxv, *tv = mv + nvo, *pv = tv + nvo;
   if (finish) {
     if (in.linear == 1) {  // :328-331

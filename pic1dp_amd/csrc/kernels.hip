@@ -1031,31 +1031,45 @@ __device__ __forceinline__ void bin_add(double *p, double v) {
   }
 }
 
-// (x,v) and v histograms of output_ptcldist, src/pic1dp_output.F90:239-315:
-// 4-point bilinear weights on an nx_opd x nv_opd grid, markers with
-// |v| >= v_max skipped (:241).  LDS = true keeps a private copy of all six
-// histograms per workgroup (3*(nxo*nvo)+3*nvo doubles) and flushes it with
-// global atomics; LDS = false (grids too large for 160 KiB) adds straight to
-// global memory.
+// One pass over a species for everything output_all needs from the markers:
+// * the (x,v) and v histograms of output_ptcldist, src/pic1dp_output.F90:239-315:
+//   4-point bilinear weights on an nx_opd x nv_opd grid, markers with
+//   |v| >= v_max skipped (:241);
+// * the kinetic sums of output_field, sum v^2, v^2 p, v^2 w over ALL markers
+//   (:126-151), as per-workgroup partials the host adds in workgroup order.
+// LDS = true keeps a private copy of the histograms per workgroup
+// (3*(nxo*nvo)+3*nvo doubles) and flushes it with global atomics.  There the v
+// histograms are not accumulated marker by marker (64 hot bins: the LDS atomics
+// of a wave collide) but formed once per workgroup as the row sums of its (x,v)
+// histograms -- the same numbers in exact arithmetic, (sx + (1-sx))*sv = sv, and
+// within rounding (<= 1e-15 relative per term) of the separate accumulation.
+// LDS = false (grids too large for 160 KiB) adds everything straight to memory.
 template <bool LDS, bool DELTAF>
 __global__ void __launch_bounds__(1024)
 k_ptcldist(const double *x, const double *v, const double *p, const double *w, int64_t np, double lx,
-           double vmax, int nxo, int nvo, double *out) {
+           double vmax, int nxo, int nvo, double *out, double *partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nxv = nxo * nvo;
   const int ntot = 3 * nxv + 3 * nvo;
   DistBins b{LDS ? reinterpret_cast<double *>(smem) : out, nxv, nvo};
+  double *scr = reinterpret_cast<double *>(smem) + (LDS ? ntot : 0);  // [16]
   if constexpr (LDS) {
     for (int i = threadIdx.x; i < ntot; i += blockDim.x) b.h[i] = 0.0;
     __syncthreads();
   }
   const double dnxo = static_cast<double>(nxo), dnv1 = static_cast<double>(nvo - 1);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < np; i += stride) {
     const double pv = v[i];
-    if (fabs(pv) >= vmax) continue;                       // :241
-    const double px = x[i], pp = p[i];
+    const double pp = p[i];
     const double pw = DELTAF ? w[i] : 0.0;
+    const double v2 = pv * pv;
+    s0 += v2;
+    s1 += v2 * pp;
+    if constexpr (DELTAF) s2 += v2 * pw;
+    if (fabs(pv) >= vmax) continue;                       // :241
+    const double px = x[i];
     double sx = px / lx * dnxo;                           // :243
     const double fx = floor(sx);
     int ix = static_cast<int>(fx);
@@ -1079,14 +1093,35 @@ k_ptcldist(const double *x, const double *v, const double *p, const double *w, i
       if (ix > nxo - 1) ix = 0;
       sx = 1.0 - sx;
     }
-    bin_add<LDS>(&b.vv(0)[iv], sv);                       // :300-314
-    bin_add<LDS>(&b.vv(1)[iv], sv * pp);
-    if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv], sv * pw);
-    bin_add<LDS>(&b.vv(0)[iv + 1], 1.0 - sv);
-    bin_add<LDS>(&b.vv(1)[iv + 1], (1.0 - sv) * pp);
-    if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv + 1], (1.0 - sv) * pw);
+    if constexpr (!LDS) {                                 // :300-314
+      bin_add<LDS>(&b.vv(0)[iv], sv);
+      bin_add<LDS>(&b.vv(1)[iv], sv * pp);
+      if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv], sv * pw);
+      bin_add<LDS>(&b.vv(0)[iv + 1], 1.0 - sv);
+      bin_add<LDS>(&b.vv(1)[iv + 1], (1.0 - sv) * pp);
+      if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv + 1], (1.0 - sv) * pw);
+    }
+  }
+  if (partial) {
+    const double t0 = block_sum(s0, scr);
+    const double t1 = block_sum(s1, scr);
+    const double t2 = block_sum(s2, scr);
+    if (threadIdx.x == 0) {
+      partial[blockIdx.x * 3 + 0] = t0;
+      partial[blockIdx.x * 3 + 1] = t1;
+      partial[blockIdx.x * 3 + 2] = t2;
+    }
   }
   if constexpr (LDS) {
+    __syncthreads();
+    // v histograms = row sums of the (x,v) histograms, one thread per (k, iv)
+    for (int t = threadIdx.x; t < (DELTAF ? 3 : 2) * nvo; t += blockDim.x) {
+      const int k = t / nvo, iv = t - k * nvo;
+      const double *row = b.xv(k) + static_cast<size_t>(iv) * nxo;
+      double acc = 0.0;
+      for (int ix = 0; ix < nxo; ++ix) acc += row[ix];
+      b.vv(k)[iv] = acc;
+    }
     __syncthreads();
     const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * ntot) / gridDim.x);
     for (int i = threadIdx.x; i < ntot; i += blockDim.x) {
@@ -1100,24 +1135,32 @@ k_ptcldist(const double *x, const double *v, const double *p, const double *w, i
 
 }  // namespace
 
-hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
-                           int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
-                           double *out, int num_cu, hipStream_t st) {
+int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu) {
   const size_t bytes = sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo));
   const bool lds = bytes <= 150 * 1024;
-  const int threads = 1024;
   int64_t blocks = lds ? num_cu : static_cast<int64_t>(num_cu) * 2;
-  const int64_t need = (np + threads - 1) / threads;
+  const int64_t need = (np + 1023) / 1024;
   if (blocks > need) blocks = need;
   if (blocks < 1) blocks = 1;
+  return static_cast<int>(blocks);
+}
+
+hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
+                           int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
+                           double *out, double *partial, int num_cu, hipStream_t st) {
+  const size_t hist = sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo));
+  const bool lds = hist <= 150 * 1024;
+  const size_t bytes = (lds ? hist : 0) + 16 * sizeof(double);  // + block_sum scratch
+  const int threads = 1024;
+  const int blocks = ptcldist_blocks(np, nxo, nvo, num_cu);
   auto go = [&](auto kern) -> hipError_t {
     if (lds && bytes > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), lds ? bytes : 0, st, x, v,
-                       p, w, np, lx, vmax, nxo, nvo, out);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), bytes, st, x, v, p, w, np, lx,
+                       vmax, nxo, nvo, out, partial);
     return hipGetLastError();
   };
   if (lds) return deltaf ? go(k_ptcldist<true, true>) : go(k_ptcldist<true, false>);

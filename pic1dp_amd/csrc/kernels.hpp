@@ -114,9 +114,12 @@ hipError_t launch_energy_sums(const double *v, const double *p, const double *w,
                               double *partial, int blocks, hipStream_t st);
 // raw (x,v) and v histograms of output_ptcldist into out =
 // [markr_xv | total_xv | pertb_xv | markr_v | total_v | pertb_v] (accumulated)
+// In the same pass: partial[blocks][3] = per-workgroup sums of v^2, v^2 p, v^2 w
+// over all np markers (nullptr: not wanted); blocks = ptcldist_blocks(...)
 hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
                            int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
-                           double *out, int num_cu, hipStream_t st);
+                           double *out, double *partial, int num_cu, hipStream_t st);
+int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu);
 // streaming-bandwidth probe with the particle kernels' access pattern:
 // (nr, nw) in {1,4,7} x {0,1,3} arrays of n doubles read / written
 hipError_t launch_stream_probe(double *const *in, int nr, double *const *out, int nw, int64_t n,

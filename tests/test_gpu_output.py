@@ -73,6 +73,40 @@ def test_ptcldist_and_output_scalars(oracle_mod, amd, kw):
     assert np.max(np.abs(s_g[1:] - s_o[1:]) / (np.abs(s_o[1:]) + 1e-300)) < 1e-10
 
 
+def test_diagnostics_follow_the_markers(oracle_mod, amd):
+    """histograms and kinetic sums come from one fused pass whose results are kept
+    until the markers change: every way of changing them must be noticed"""
+    sim, eng = started(oracle_mod, amd)
+
+    def check(tag):
+        g = eng.particles_download()
+        for k in "xvpw":
+            sim.array(0, 0, k)[:] = g[k]
+        d_g, d_o = eng.ptcldist(0, finish=True), sim.ptcldist(0, finish=True)
+        for k in DIST_KEYS:
+            scale = np.max(np.abs(d_o[k])) or 1.0
+            assert np.max(np.abs(d_g[k] - d_o[k])) < 1e-11 * scale, (tag, k)
+        s_g, s_o = np.array(eng.energy_sums(0)), np.array(sim.energy_sums(0))
+        assert np.max(np.abs(s_g - s_o) / np.abs(s_o)) < 1e-10, tag
+        return d_g["pertb_xv"].copy()
+
+    first = check("start")
+    assert np.array_equal(check("cached"), first)
+    eng.step(1)
+    assert not np.array_equal(check("step"), first)
+    eng.substep(1)
+    check("substep 1")
+    eng.substep(2)
+    check("substep 2")
+    eng.interaction_push_particle(1)
+    check("push")
+    g = eng.particles_download()
+    g["w"] = g["w"] * 0.5
+    eng.particles_upload(g["x"], g["v"], g["p"], g["w"])
+    second = check("upload")
+    assert not np.array_equal(second, first)
+
+
 def test_ptcldist_conservation(amd):
     """bilinear weights sum to one: the marker histogram integrates to the
     number of markers with |v| < v_max, in (x,v) and in v"""
