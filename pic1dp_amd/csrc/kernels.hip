@@ -598,6 +598,10 @@ hipError_t launch_deposit(double *x, const double *q, double *rho, int64_t np, c
 namespace {
 
 constexpr int FIELD_THREADS = 256;
+#ifndef PIC1DP_CHAIN_W
+#define PIC1DP_CHAIN_W 16
+#endif
+constexpr int CHAIN_W = PIC1DP_CHAIN_W;  // prefetch depth of the serial mode sums
 
 // charge2(:) = charge2(:) + charge1(:)*Z over species, from 0
 // (src/pic1dp_interaction.F90:81,126-127); accumulators are re-zeroed
@@ -656,15 +660,41 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
   double *sTab = sScr + 16;                             // [2][nmode][nx] when tab_lds
   const int nx = f.nx, nm = f.nmode;
 
-  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
-    double cd;
-    if constexpr (FROM_CD) {
-      cd = f.chargeden[ix];
-    } else {
-      cd = chargeden_from(f, WITH_LOCAL ? charge_local_one(f, ix) : f.charge[ix]);
-      f.chargeden[ix] = cd;
+  // four grid points per thread per trip, all loads issued before the first use
+  // (one memory round trip instead of four for nx = 1024)
+  constexpr int U = 4;
+  for (int base = threadIdx.x; base < nx; base += U * FIELD_THREADS) {
+    double c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ix = base + u * FIELD_THREADS;
+      c[u] = 0.0;
+      if (ix < nx) {
+        if constexpr (FROM_CD) {
+          c[u] = f.chargeden[ix];
+        } else if constexpr (WITH_LOCAL) {  // src/pic1dp_interaction.F90:126-127
+          for (int sp = 0; sp < f.nspecies; ++sp) c[u] = c[u] + f.rho_sp[static_cast<size_t>(sp) * nx + ix] * f.Z[sp];
+        } else {
+          c[u] = f.charge[ix];
+        }
+      }
     }
-    sCD[ix] = cd;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ix = base + u * FIELD_THREADS;
+      if (ix < nx) {
+        double cd = c[u];
+        if constexpr (!FROM_CD) {
+          if constexpr (WITH_LOCAL) {
+            for (int sp = 0; sp < f.nspecies; ++sp) f.rho_sp[static_cast<size_t>(sp) * nx + ix] = 0.0;
+            f.charge[ix] = c[u];
+          }
+          cd = chargeden_from(f, c[u]);
+          f.chargeden[ix] = cd;
+        }
+        sCD[ix] = cd;
+      }
+    }
   }
   __syncthreads();
 
@@ -689,23 +719,38 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
     int ix = 0;
     if (f.tab_lds) {
       const double *prod = sTab + (use_cos ? 0 : nm * nx) + m * nx;
-      double cur[8], nxt[8];
-      if (nx >= 8) {
+      // One wave issues this whole chain, so every instruction counts (a wave64
+      // VALU or LDS instruction occupies its SIMD for 4 cycles whatever the exec
+      // mask): two register batches in ping-pong, no copies between them, and
+      // 16-byte LDS loads when the row is aligned.  16 dependent adds per batch
+      // cover the LDS round trip of the next one.
+      constexpr int W = CHAIN_W;
+      if ((reinterpret_cast<uintptr_t>(prod) & 15) == 0) {
+        double A[W], B[W];
+        const int nb = nx / W;
+        auto load = [](double (&r)[W], const double *q) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) cur[k] = prod[k];
-      }
-      for (; ix + 8 <= nx; ix += 8) {
-        const bool more = ix + 16 <= nx;
-        if (more) {  // fetch the next eight terms while the current ones are added
+          for (int k = 0; k < W; k += 2) {
+            const double2 t = *reinterpret_cast<const double2 *>(q + k);
+            r[k] = t.x;
+            r[k + 1] = t.y;
+          }
+        };
+        if (nb > 0) load(A, prod);
+        int b = 0;
+        for (; b + 2 <= nb; b += 2) {
+          load(B, prod + (b + 1) * W);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) nxt[k] = prod[ix + 8 + k];
+          for (int k = 0; k < W; ++k) acc = acc + A[k];
+          if (b + 2 < nb) load(A, prod + (b + 2) * W);
+#pragma unroll
+          for (int k = 0; k < W; ++k) acc = acc + B[k];
         }
+        if (b < nb) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc = acc + cur[k];
-        if (more) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+          for (int k = 0; k < W; ++k) acc = acc + A[k];
         }
+        ix = nb * W;
       }
       for (; ix < nx; ++ix) acc = acc + prod[ix];
     } else {
@@ -737,13 +782,37 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
 
   // inverse: E = 2*(Fre*mode_re + Fim*mode_im), ascending mode order :251-256
   double e2 = 0.0;
-  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
-    double s = 0.0;
-    for (int m = 0; m < nm; ++m) s = s + f.fre[static_cast<size_t>(m) * nx + ix] * sMode[m];
-    for (int m = 0; m < nm; ++m) s = s + f.fim[static_cast<size_t>(m) * nx + ix] * sMode[nm + m];
-    const double e = s * 2.0;
-    f.E[ix] = e;
-    e2 += e * e;
+  if (nm == 1) {  // the usual case: both table reads of four grid points in flight together
+    for (int base = threadIdx.x; base < nx; base += U * FIELD_THREADS) {
+      double tr[U], ti[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ix = base + u * FIELD_THREADS;
+        tr[u] = ix < nx ? f.fre[ix] : 0.0;
+        ti[u] = ix < nx ? f.fim[ix] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ix = base + u * FIELD_THREADS;
+        if (ix < nx) {
+          double s = 0.0;
+          s = s + tr[u] * sMode[0];
+          s = s + ti[u] * sMode[1];
+          const double e = s * 2.0;
+          f.E[ix] = e;
+          e2 += e * e;
+        }
+      }
+    }
+  } else {
+    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+      double s = 0.0;
+      for (int m = 0; m < nm; ++m) s = s + f.fre[static_cast<size_t>(m) * nx + ix] * sMode[m];
+      for (int m = 0; m < nm; ++m) s = s + f.fim[static_cast<size_t>(m) * nx + ix] * sMode[nm + m];
+      const double e = s * 2.0;
+      f.E[ix] = e;
+      e2 += e * e;
+    }
   }
   if (f.history) {  // int E^2 dx, src/pic1dp_output.F90:120-124
     const double tot = block_sum(e2, sScr);
