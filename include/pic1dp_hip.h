@@ -183,6 +183,12 @@ int pic1dp_hip_host_multirand_int64(int32_t al_int, int32_t seed_type, int32_t m
  * the host's fma(); debug_: on the device, against the hardware division. */
 int pic1dp_hip_host_div_check(double lx, int32_t nx, int64_t n, uint64_t seed,
                               int64_t *mismatches);
+/* the same for the division by a species constant (m, T, T/m, T2/m, 2T/m, 2T2/m,
+ * sqrt(T/m), sqrt(T2/m); kernels.hip div_const), used when the constants are not
+ * all powers of two: n generated dividends (random significands, edge patterns,
+ * exponents in [-300, 300]) against the IEEE quotient. */
+int pic1dp_hip_host_divc_check(double divisor, int64_t n, uint64_t seed,
+                               int64_t *mismatches);
 
 /* ---- life cycle -------------------------------------------------------
  * create  <-> input_init + particle_init + field_init
@@ -327,6 +333,10 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *ctx, int32_t ispecies, int32_t finish,
 
 int pic1dp_hip_debug_div_check(pic1dp_ctx *ctx, int64_t n, uint64_t seed,
                                int64_t *mismatches);
+/* device-side check of div_const on all eight divisor constants of a species,
+ * n dividends each */
+int pic1dp_hip_debug_divc_check(pic1dp_ctx *ctx, int32_t ispecies, int64_t n,
+                                uint64_t seed, int64_t *mismatches);
 /* measured streaming bandwidth of this GPU with the particle kernels' access
  * pattern (16 B per lane, grid-stride, the context's launch shape): nread
  * (1, 4 or 7) arrays of n doubles read and nwrite (0, 1 or 3) written per pass,

@@ -83,6 +83,8 @@ SIGNATURES = {
     "pic1dp_hip_host_multirand_int64": [C.c_int32] * 5 + [_P, C.c_int64],
     "pic1dp_hip_host_div_check": [C.c_double, C.c_int32, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
     "pic1dp_hip_debug_div_check": [_P, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
+    "pic1dp_hip_host_divc_check": [C.c_double, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
+    "pic1dp_hip_debug_divc_check": [_P, C.c_int32, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
     "pic1dp_hip_stream_probe": [_P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _D],
     "pic1dp_hip_create": [_INP, C.POINTER(Layout), C.POINTER(_P)],
     "pic1dp_hip_destroy": [_P],

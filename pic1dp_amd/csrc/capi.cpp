@@ -221,6 +221,21 @@ SpeciesConst make_species_const(const pic1dp_input &in, int s) {
   c.unit = c.m == 1.0 && T == 1.0 && T2 == 1.0 && c.tm == 1.0 && c.tm2 == 1.0 && c.stm == 1.0 &&
            c.stm2 == 1.0 && c.two_tm == 2.0 && c.two_tm2 == 2.0;
   if (const char *e = std::getenv("PIC1DP_UNIT_SPECIALISATION")) c.unit = c.unit && std::atoi(e) != 0;
+  // general divisors: a/c through div_const (kernels.hip) if every one of the
+  // eight is in a sane range and a randomised host comparison with the true
+  // quotient finds no difference (the theorem behind it holds for every finite
+  // c; this guards the implementation, not the mathematics)
+  c.fastc = 0;
+  if (!c.pow2) {
+    const double divisors[8] = {c.m, T, c.tm, c.tm2, c.two_tm, c.two_tm2, c.stm, c.stm2};
+    bool ok = true;
+    for (double d : divisors) {
+      const double ad = std::fabs(d);
+      ok = ok && ad > 0x1p-200 && ad < 0x1p+200 && host_divc_check(d, 0x5EEDull + static_cast<uint64_t>(s), 50000) == 0;
+    }
+    c.fastc = ok ? 1 : 0;
+  }
+  if (const char *e = std::getenv("PIC1DP_FAST_DIVC")) c.fastc = c.fastc && std::atoi(e) != 0;
   return c;
 }
 
@@ -1516,6 +1531,29 @@ int pic1dp_hip_stream_probe(pic1dp_ctx *c, int32_t nread, int32_t nwrite, int64_
   if (e1) (void)hipEventDestroy(e1);
   (void)hipFree(base);
   return rc;
+}
+
+int pic1dp_hip_debug_divc_check(pic1dp_ctx *c, int32_t isp, int64_t n, uint64_t seed, int64_t *mismatches) {
+  CHECK_CTX(c);
+  if (!mismatches || n < 0) return fail(PIC1DP_ERR_ARG, "bad argument");
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  HIP_TRY(hipSetDevice(c->device));
+  const SpeciesConst &k = c->sp[isp].sc;
+  const double divisors[8] = {k.m, k.T, k.tm, k.tm2, k.two_tm, k.two_tm2, k.stm, k.stm2};
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(c->d_scratch);
+  HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->st));
+  for (int i = 0; i < 8; ++i) HIP_TRY(launch_divc_check(divisors[i], seed + i, n, d, c->st));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  unsigned long long h = 0;
+  HIP_TRY(hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost));
+  *mismatches = static_cast<int64_t>(h);
+  return 0;
+}
+
+int pic1dp_hip_host_divc_check(double divisor, int64_t n, uint64_t seed, int64_t *mismatches) {
+  if (!mismatches || n < 0 || !(divisor != 0.0)) return fail(PIC1DP_ERR_ARG, "bad argument");
+  *mismatches = host_divc_check(divisor, seed, n);
+  return 0;
 }
 
 int pic1dp_hip_debug_div_check(pic1dp_ctx *c, int64_t n, uint64_t seed, int64_t *mismatches) {

@@ -77,30 +77,50 @@ __device__ __forceinline__ void st2t(double2 *p, double a, double b) {
 __device__ __forceinline__ double2 ld2(const double2 *p) { return ld2t<PIC1DP_NT != 0>(p); }
 __device__ __forceinline__ void st2(double2 *p, double a, double b) { st2t<PIC1DP_NT != 0>(p, a, b); }
 
+// a / c for a run-time constant c, correctly rounded, without the hardware
+// division sequence: rc = RN(1/c) from the host, q0 = RN(a*rc) is within 2 ulp,
+// one FMA correction (r0 = a - c*q0 exact, q1 = RN(q0 + r0*rc)) makes it
+// faithful, and by Markstein's theorem (faithful q, correctly rounded
+// reciprocal, exact residual) the second correction returns exactly RN(a/c), the
+// reference's quotient.  5 full-rate FP64 ops instead of ~14 issue slots.  Zero /
+// tiny / huge dividends (outside the theorem's no-underflow premise) and
+// constants the host could not vouch for (fast = 0) take the hardware division.
+__device__ __forceinline__ double div_const(double a, double c, double rc, int fast) {
+  const double aa = fabs(a);
+  if (fast && aa > 0x1p-500 && aa < 0x1p+500) {
+    const double q0 = a * rc;
+    const double r0 = fma(-c, q0, a);
+    const double q1 = fma(r0, rc, q0);
+    const double r1 = fma(-c, q1, a);
+    return fma(r1, rc, q1);
+  }
+  return a / c;
+}
+
 // Division by a species constant c, bit-identical to a / c in all three forms:
-//   POW2 = 0  a / c             (general)
+//   POW2 = 0  div_const         (general)
 //   POW2 = 1  a * (1/c)         (every divisor constant is a power of two)
 //   POW2 = 2  a                 (unit species: m = T = T2 = 1, so T/m = sqrt(T/m) = 1
 //                                and 2T/m = 2 -- the reference's default input)
 template <int POW2>
-__device__ __forceinline__ double divc(double a, double c, double rc) {
+__device__ __forceinline__ double divc(double a, double c, double rc, int fast) {
   if constexpr (POW2 == 2) {
     return a;
   } else if constexpr (POW2 == 1) {
     return a * rc;
   } else {
-    return a / c;
+    return div_const(a, c, rc, fast);
   }
 }
 // the same for the constants 2T/m, 2T2/m (= 2 for a unit species)
 template <int POW2>
-__device__ __forceinline__ double divh(double a, double c, double rc) {
+__device__ __forceinline__ double divh(double a, double c, double rc, int fast) {
   if constexpr (POW2 == 2) {
     return a * 0.5;
   } else if constexpr (POW2 == 1) {
     return a * rc;
   } else {
-    return a / c;
+    return div_const(a, c, rc, fast);
   }
 }
 
@@ -159,21 +179,21 @@ __device__ __forceinline__ double dlnf0(double v, const SpeciesConst &c) {
     return v - 2.0 / v;
   } else if constexpr (DIST == 2) {  // two-stream2 :278-292
     const double vp = v + c.v0, vm = v - c.v0;
-    const double ep = exp(-divh<POW2>(vp * vp, c.two_tm, c.r_two_tm));
-    const double em = exp(-divh<POW2>(vm * vm, c.two_tm, c.r_two_tm));
+    const double ep = exp(-divh<POW2>(vp * vp, c.two_tm, c.r_two_tm, c.fastc));
+    const double em = exp(-divh<POW2>(vm * vm, c.two_tm, c.r_two_tm, c.fastc));
     const double q = (vp * ep + vm * em) / (ep + em);
-    return divc<POW2>(q * c.m, c.T, c.r_T);
+    return divc<POW2>(q * c.m, c.T, c.r_T, c.fastc);
   } else if constexpr (DIST == 3) {  // bump-on-tail :294-321
     const double vm = v - c.v0;
-    const double e1 = exp(-divh<POW2>(v * v, c.two_tm, c.r_two_tm));
-    const double e2 = exp(-divh<POW2>(vm * vm, c.two_tm2, c.r_two_tm2));
-    const double a = divc<POW2>(divc<POW2>(c.den * v, c.tm, c.r_tm) * e1, c.stm, c.r_stm);
-    const double b = divc<POW2>(divc<POW2>(c.beam * vm, c.tm2, c.r_tm2) * e2, c.stm2, c.r_stm2);
-    const double cc = divc<POW2>(c.den * e1, c.stm, c.r_stm);
-    const double d = divc<POW2>(c.beam * e2, c.stm2, c.r_stm2);
+    const double e1 = exp(-divh<POW2>(v * v, c.two_tm, c.r_two_tm, c.fastc));
+    const double e2 = exp(-divh<POW2>(vm * vm, c.two_tm2, c.r_two_tm2, c.fastc));
+    const double a = divc<POW2>(divc<POW2>(c.den * v, c.tm, c.r_tm, c.fastc) * e1, c.stm, c.r_stm, c.fastc);
+    const double b = divc<POW2>(divc<POW2>(c.beam * vm, c.tm2, c.r_tm2, c.fastc) * e2, c.stm2, c.r_stm2, c.fastc);
+    const double cc = divc<POW2>(c.den * e1, c.stm, c.r_stm, c.fastc);
+    const double d = divc<POW2>(c.beam * e2, c.stm2, c.r_stm2, c.fastc);
     return (a + b) / (cc + d);
   } else {  // (shifted) Maxwellian :323-325
-    return divc<POW2>(v - c.v0, c.tm, c.r_tm);
+    return divc<POW2>(v - c.v0, c.tm, c.r_tm, c.fastc);
   }
 }
 
@@ -198,12 +218,12 @@ __device__ __forceinline__ One push_one(double x, double v, double w, double p, 
   if constexpr (MODE != MODE_FULLF) {
     const double tmp1 = (MODE == MODE_DF_LIN) ? p * e : (p - w) * e;   // :268-272
     const double tmp2 = dlnf0<DIST, POW2>(v, s);
-    o.w = wb + divc<POW2>(dt * tmp1 * tmp2 * s.Z, s.m, s.r_m);  // :329
+    o.w = wb + divc<POW2>(dt * tmp1 * tmp2 * s.Z, s.m, s.r_m, s.fastc);  // :329
   }
   if constexpr (MODE == MODE_DF_LIN) {
     o.v = v;
   } else {
-    o.v = vb + divc<POW2>(dt * e * s.Z, s.m, s.r_m);  // :336
+    o.v = vb + divc<POW2>(dt * e * s.Z, s.m, s.r_m, s.fastc);  // :336
   }
   return o;
 }
@@ -1377,6 +1397,60 @@ hipError_t launch_stream_probe(double *const *in, int nr, double *const *out, in
     case 7: return launch_probe_nr<7>(a, nw, variant, blocks, threads, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+namespace {
+
+// dividends for the div_const check: random sign, exponent in [-300, 300],
+// random significand -- every 16th one from the edges (0...0k, 1...1k) where
+// rounding decisions are closest
+__host__ __device__ inline double divc_check_value(uint64_t seed, int64_t i) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(i + 1);  // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  uint64_t mant = z & 0xFFFFFFFFFFFFFull;
+  if ((i & 15) == 0) mant = (z & 0x3FF) | ((z >> 10) & 1 ? 0xFFFFFFFFFFC00ull : 0ull);
+  const uint64_t expo = 1023 - 300 + (z >> 52) % 601;
+  const uint64_t bits = (z & 0x8000000000000000ull) | (expo << 52) | mant;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __longlong_as_double(static_cast<long long>(bits));
+#else
+  double d;
+  std::memcpy(&d, &bits, 8);
+  return d;
+#endif
+}
+
+__global__ void k_divc_check(double c, double rc, uint64_t seed, int64_t n, unsigned long long *bad) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double a = divc_check_value(seed, i);
+    const double q = div_const(a, c, rc, 1), b = a / c;
+    if (__double_as_longlong(q) != __double_as_longlong(b)) atomicAdd(bad, 1ULL);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_divc_check(double c, uint64_t seed, int64_t n, unsigned long long *bad, hipStream_t st) {
+  hipLaunchKernelGGL(k_divc_check, dim3(2048), dim3(256), 0, st, c, 1.0 / c, seed, n, bad);
+  return hipGetLastError();
+}
+
+// div_const's algorithm with the host's FMA (libm fma is exact)
+int64_t host_divc_check(double c, uint64_t seed, int64_t n) {
+  const double rc = 1.0 / c;
+  int64_t bad = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double a = divc_check_value(seed, i);
+    const double q0 = a * rc;
+    const double q1 = fma(fma(-c, q0, a), rc, q0);
+    const double q = fma(fma(-c, q1, a), rc, q1);
+    const double b = a / c;
+    if (std::memcmp(&q, &b, 8) != 0) ++bad;
+  }
+  return bad;
 }
 
 hipError_t launch_div_check(const GridConst &g, uint64_t seed, int64_t n, unsigned long long *bad,

@@ -16,10 +16,11 @@ struct SpeciesConst {
   double tm, tm2;       // T/m, T2/m
   double two_tm, two_tm2;  // 2*T/m, 2*T2/m
   double stm, stm2;     // sqrt(T/m), sqrt(T2/m)
-  // reciprocals, used only when every divisor is a power of two (exact)
+  // reciprocals RN(1/c): exact products when every divisor is a power of two, else div_const
   double r_m, r_T, r_tm, r_tm2, r_two_tm, r_two_tm2, r_stm, r_stm2;
   int pow2;             // 1: all divisors above are powers of two
   int unit;             // 1: m = T = T2 = 1 (T/m = sqrt(T/m) = 1, 2T/m = 2): divisions vanish
+  int fastc;            // 1: a/c by reciprocal + two FMA corrections for all eight divisors (host-verified)
 };
 
 struct GridConst {
@@ -129,6 +130,10 @@ hipError_t launch_stream_probe(double *const *in, int nr, double *const *out, in
 hipError_t launch_div_check(const GridConst &g, uint64_t seed, int64_t n, unsigned long long *bad,
                             hipStream_t st);
 int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n);
+// div_const (a / c for a species constant c) against the true quotient on n
+// generated dividends, on the device and with the host's fma
+hipError_t launch_divc_check(double c, uint64_t seed, int64_t n, unsigned long long *bad, hipStream_t st);
+int64_t host_divc_check(double c, uint64_t seed, int64_t n);
 // cell index per marker and per-cell counts from (wrapped) x
 hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
                                unsigned long long *count, hipStream_t st);

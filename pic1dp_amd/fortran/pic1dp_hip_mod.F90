@@ -126,6 +126,23 @@ interface
     integer(c_int64_t), intent(out) :: mismatches
     integer(c_int) :: ierr
   end function pic1dp_hip_debug_div_check
+  function pic1dp_hip_host_divc_check(divisor, n, seed, mismatches) bind(C, name="pic1dp_hip_host_divc_check") result(ierr)
+    import
+    real(c_double), value :: divisor
+    integer(c_int64_t), value :: n
+    integer(c_int64_t), value :: seed
+    integer(c_int64_t), intent(out) :: mismatches
+    integer(c_int) :: ierr
+  end function pic1dp_hip_host_divc_check
+  function pic1dp_hip_debug_divc_check(ctx, ispecies, n, seed, mismatches) bind(C, name="pic1dp_hip_debug_divc_check") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: ispecies
+    integer(c_int64_t), value :: n
+    integer(c_int64_t), value :: seed
+    integer(c_int64_t), intent(out) :: mismatches
+    integer(c_int) :: ierr
+  end function pic1dp_hip_debug_divc_check
   function pic1dp_hip_stream_probe(ctx, nread, nwrite, n, reps, gbytes_per_s) bind(C, name="pic1dp_hip_stream_probe") result(ierr)
     import
     type(c_ptr), value :: ctx

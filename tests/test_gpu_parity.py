@@ -581,6 +581,53 @@ def test_exact_division_by_lx_device(amd, kw):
     assert m.value == 0
 
 
+@pytest.mark.parametrize("kw", [
+    dict(species_temperature=[1.3], species_temperature2=[0.7], species_mass=[1.1]),
+    dict(species_temperature=[2.0], species_temperature2=[0.5]),
+    dict(species_temperature=[0.013], species_temperature2=[37.0], species_mass=[1836.15267343]),
+], ids=["T1.3", "T2", "m1836"])
+def test_exact_division_by_species_constant_device(amd, kw):
+    """div_const on the device against the hardware IEEE division: 1e8 dividends
+    for each of the eight divisor constants of the species"""
+    eng = amd.Pic1dp(amd.make_input(nparticle_max=16, **kw))
+    m = C.c_int64(-1)
+    amd._lib.check(eng.L.pic1dp_hip_debug_divc_check(eng._ctx, 0, 100_000_000, 99, C.byref(m)))
+    assert m.value == 0
+
+
+@pytest.mark.parametrize("fast", ["0", "1"])
+def test_non_unit_species_fast_and_hardware_division_agree(oracle_mod, amd, monkeypatch, fast):
+    """a bump-on-tail species with T, T2, m that are not powers of two: x and v
+    bit-exact against the oracle's true divisions with div_const on and off, and
+    the two settings give bit-identical weights"""
+    kw = dict(iptcldist=3, species_temperature=[1.3], species_temperature2=[0.7], species_mass=[1.1],
+              species_density=[0.85], species_v0=[4.5])
+    monkeypatch.setenv("PIC1DP_FAST_DIVC", fast)
+    sim, eng = pair(oracle_mod, amd, **kw)
+    monkeypatch.setenv("PIC1DP_FAST_DIVC", "0")
+    ref = amd.Pic1dp(eng.inp)
+    ref.particle_load()
+    nx = sim.inp.nx
+    for irk, seed in ((1, 21), (2, 22)):
+        E = smooth_field(nx, seed)
+        sim.set_field(E)
+        wb = sim.gather("w") if irk == 1 else sim.gather("wb")
+        sim.push(irk)
+        out = []
+        for e in (eng, ref):
+            e.set_electric(E)
+            e.interaction_push_particle(irk)
+            g = e.particles_download()
+            assert np.array_equal(g["x"], sim.gather("x")), irk
+            assert np.array_equal(g["v"], sim.gather("v")), irk
+            assert_w_close(g["w"], sim.gather("w"), wb, False)
+            out.append(g["w"])
+            e.interaction_collect_charge()
+        assert np.array_equal(out[0], out[1]), irk
+        sim.array(0, 0, "w")[:] = out[0]
+        sim.collect_charge()
+
+
 @pytest.mark.parametrize("mass", [1.0, 4.0, 1.3])
 def test_full_f_mass_division(oracle_mod, amd, mass):
     """full-f still divides by the species mass in the v push

@@ -220,6 +220,19 @@ def test_exact_division_by_lx_host(amd, lx, nx):
     assert m.value == 0
 
 
+@pytest.mark.parametrize("divisor", [1.3, 0.7, 1.1, 1.3 / 1.1, 2 * 0.7 / 1.1, (1.3 / 1.1) ** 0.5, 3.0, 1.0 / 3.0,
+                                     float.fromhex("0x1.fffffffffffffp+0"), float.fromhex("0x1.0000000000001p-3"),
+                                     25.0, 1836.15267343, 2.0 ** 0.5, -1.7])
+def test_exact_division_by_species_constant_host(amd, divisor):
+    """species constants that are not powers of two (T = 1.3, m = 1836, ...) divide
+    through the same reciprocal + two-FMA-correction sequence; it must return the
+    IEEE quotient bit for bit for every dividend (v and w pushes depend on it)"""
+    L = amd._lib.load()
+    m = C.c_int64(-1)
+    assert L.pic1dp_hip_host_divc_check(divisor, 3_000_000, 424242, C.byref(m)) == 0
+    assert m.value == 0
+
+
 def test_product_never_touches_the_oracle(amd):
     """the oracle is test infrastructure: nothing under pic1dp_amd/ or include/
     may import, link or mention it, and the built library must not depend on it"""
