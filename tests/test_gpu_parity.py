@@ -159,6 +159,7 @@ def test_tiny_particle_counts(oracle_mod, amd, n):
 # field solve
 # --------------------------------------------------------------------------
 @pytest.mark.parametrize("nx,modes", [(64, [1]), (192, [1]), (192, [1, 2, 5]), (1024, [1]), (4096, [1, 3]),
+                                      (77, [1, 2]), (1023, [1]), (9, [1, 3]), (31, [2]),   # odd: unaligned LDS rows
                                       (250, list(range(1, 65))), (250, list(range(1, 126))),
                                       (256, list(range(1, 129))), (1000, list(range(1, 500))),
                                       (2048, list(range(1, 1025)))],
