@@ -318,7 +318,10 @@ int pic1dp_hip_cell_indices(pic1dp_ctx *ctx, int32_t ispecies, int32_t *ix,
  * out[1] = int E^2 dx, then per species s: out[2+3s] = sum v^2,
  * out[3+3s] = total kinetic sum, out[4+3s] = perturbed kinetic sum (the linear /
  * full-f adjustments of :152-170 applied).  n must be 2 + 3*nspecies.  Sums are
- * all-reduced over ranks when a communicator exists. */
+ * all-reduced over ranks when a communicator exists.
+ * energy_sums, output_scalars and ptcldist share one pass over a species'
+ * markers (histograms and kinetic sums together); its results are kept until a
+ * call changes the markers, so the sequence of output_all costs one pass. */
 int pic1dp_hip_output_scalars(pic1dp_ctx *ctx, double *out, int32_t n);
 /* (x,v) and v distributions of output_ptcldist (src/pic1dp_output.F90:196-477)
  * of one species, computed on the GPU: markr/total/pertb_xv hold
