@@ -100,17 +100,28 @@ def test_long_run_through_saturation(oracle_mod, amd):
     assert x.min() >= 0.0 and x.max() <= eng.inp.lx
 
 
-@pytest.mark.parametrize("n,nx,nsteps", [(10**7, 256, 200), (10**8, 1024, 24)], ids=["C2_1e7", "C3_1e8"])
-def test_baseline_sizes_against_oracle(oracle_mod, amd, n, nx, nsteps):
-    """BASELINE configs[1] and configs[2] at their real sizes (bump-on-tail, 10^7
-    markers / nx 256 and 10^8 markers / nx 1024) on the GPU and in the oracle (16
-    reference ranks on 16 threads, the GPU holding the same 16 blocks as virtual
-    ranks): int E^2 dx within 1e-10 at every step, the fitted growth rate within
-    1e-10, every marker's cell the reference expression of its position"""
-    kw = dict(nparticle_max=n, nx=nx)
-    sim = oracle_mod.Sim(oracle_mod.make_input(**kw), npe=16, nthreads=16)
+BASELINE_CASES = [
+    # id, input, reference ranks (virtual ranks on the one GPU), steps, per-marker checks
+    ("C2_bump_1e7", dict(nparticle_max=10**7, nx=256), 16, 200, True),
+    ("C3_bump_1e8", dict(nparticle_max=10**8, nx=1024), 16, 24, True),
+    ("C4_two_stream_1e8_4ranks", dict(nparticle_max=10**8, nx=512, iptcldist=2, species_density=[1.0],
+                                      species_v0=[3.0]), 4, 24, True),
+    ("C5_landau_8e8_8ranks", dict(nparticle_max=8 * 10**8, nx=4096, iptcldist=0, species_density=[1.0],
+                                  species_v0=[0.0], lx=4 * np.pi), 8, 4, False),
+]
+
+
+@pytest.mark.parametrize("name,kw,npe,nsteps,per_marker", BASELINE_CASES, ids=[c[0] for c in BASELINE_CASES])
+def test_baseline_sizes_against_oracle(oracle_mod, amd, name, kw, npe, nsteps, per_marker):
+    """BASELINE configs[1..4] at their real sizes on the GPU and in the oracle: the
+    GPU holds the reference's rank blocks as virtual ranks (16 for the one-GPU
+    configs, 4 and 8 for the 4- and 8-GPU ones), the oracle runs one reference rank
+    per host thread.  int E^2 dx within 1e-10 at every step, the fitted rate within
+    1e-10, every marker's cell the reference expression of its position."""
+    nx = kw["nx"]
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw), npe=npe, nthreads=npe)
     assert sim.load() == 0
-    eng = amd.Pic1dp(amd.make_input(**kw), npe=16)
+    eng = amd.Pic1dp(amd.make_input(**kw), npe=npe)
     eng.particle_load()
     sim.collect_charge()
     sim.solve_field()
@@ -127,8 +138,10 @@ def test_baseline_sizes_against_oracle(oracle_mod, amd, n, nx, nsteps):
     eg[1:] = eng.energy_history()
     assert np.max(np.abs(eg / eo - 1.0)) < 1e-10
     t = np.arange(nsteps + 1) * eng.inp.dt
-    go, gg = fit_rate(t, eo, 0.2, t[-1] + 1e-9), fit_rate(t, eg, 0.2, t[-1] + 1e-9)
-    assert abs(gg / go - 1.0) < 1e-10, (gg, go)
+    go, gg = fit_rate(t, eo, 0.05, t[-1] + 1e-9), fit_rate(t, eg, 0.05, t[-1] + 1e-9)
+    assert abs(gg - go) < 1e-10 * max(abs(go), 1e-3), (gg, go)
+    if not per_marker:          # 8e8 markers: no 6.4 GB host copies of x
+        return
     # particle indices / counts (north_star): the kernel's cell of every marker is
     # the reference expression floor(x/lx*nx) on the same x, bit for bit; against
     # the oracle's own markers (x differs by ~1e-13 after 200 steps: exp rounding
