@@ -1443,8 +1443,8 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *mark
     HIP_TRY(hipMemcpyAsync(red, hist, sizeof(double) * ntot, hipMemcpyDeviceToDevice, c->st));
     if (int rc = allreduce_doubles(c, red, ntot)) return rc;
     hist = red;
-  } else if (finish) {
-    if (int rc = allreduce_doubles(c, nullptr, 0)) return rc;  // nranks > 1 without communicator: error
+  } else if (finish && c->lay.nranks > 1) {
+    return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: take finish = 0 and reduce the local sums on the host");
   }
   std::vector<double> h(ntot);
   HIP_TRY(hipStreamSynchronize(c->st));
