@@ -61,7 +61,7 @@ def parse():
                     help="testing only: skip RCCL, reduce the charge on the host with gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles-per-core", type=int, default=2 * 10**6)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=40)
     return ap.parse_args()
 
 
