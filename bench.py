@@ -54,7 +54,9 @@ def parse():
     ap.add_argument("--nx", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0, help="workgroup size of the particle kernels")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--unfused", action="store_true", help="time separate push / deposit kernels")
+    ap.add_argument("--unfused", action="store_true",
+                    help="time the three reference call sites per sub-step instead of step() "
+                         "(PIC1DP_LAZY_CALLS=0 in the environment: one kernel per call)")
     ap.add_argument("--step-mode", type=int, default=0, choices=[0, 1],
                     help="0: whole-step kernels (half-step state recomputed); 1: two fused sub-steps")
     ap.add_argument("--force-host-allreduce", action="store_true",
@@ -237,15 +239,42 @@ def main():
     energy = eng.field_energy()
     _, np_local = eng.local_sizes()
 
+    # the same work through the reference's own three call sites per sub-step
+    # (push, collect_charge, solve_field -- src/pic1dp.F90:80-89), which the
+    # library serves lazily with the same whole-step kernels; reported beside
+    # `value`, never instead of it
+    calls_elapsed = None
+    if not a.unfused and not host_staged:
+        eng.kernel_stats_enable(False)
+        barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            for irk in (1, 2):
+                eng.interaction_push_particle(irk)
+                eng.particle_optimize(irk)
+                eng.interaction_collect_charge()
+                eng.field_solve_electric()
+        device_sync()
+        barrier()
+        calls_elapsed = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([calls_elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            calls_elapsed = float(t.item())
+
     if rank == 0:
         value = total * 2.0 * a.steps / elapsed
         # dominant kernel of the path that ran; one launch = np_local particle-updates,
         # algorithmic bytes 80 B per update whatever the kernel really moves
-        if a.unfused or host_staged:
-            kname, kms, kn, path = "k_push (separate gather+push)", push_ms, push_n, "separate push / deposit kernels"
-        elif full_n:
+        if full_n:
             kname, kms, kn = "k_step_full (2nd sub-step: recompute half-step state, push+gather, deposit)", full_ms, full_n
             path = "whole-step kernels k_step_half + k_step_full (half-step state recomputed, not stored)"
+            if a.unfused:
+                path += ", reached through the three reference call sites per sub-step (lazy call sites)"
+        elif push_n:
+            kname, kms, kn, path = "k_push (separate gather+push)", push_ms, push_n, "separate push / deposit kernels"
         else:
             kname, kms, kn, path = "k_push<fused push+gather+deposit>", fused_ms, fused_n, "two fused push+gather+deposit sub-steps"
         kbytes = ALG_BYTES_PER_UPDATE
@@ -260,7 +289,7 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("particles_per_gpu") == per_gpu and tj.get("nx") == cfg["nx"]:
-                    key = "k_push" if (a.unfused or not full_n) else "k_step_full"
+                    key = "k_step_full" if full_n else "k_push"
                     traffic = tj.get("hbm_bytes_per_launch_by_kernel", {}).get(key)
             except (OSError, ValueError):
                 pass
@@ -297,6 +326,14 @@ def main():
             },
             "field_energy_end": energy,
         }
+        if calls_elapsed:
+            out["drop_in_call_sites"] = {
+                "value": total * 2.0 * a.steps / calls_elapsed, "unit": "updates/s",
+                "ms_per_step": calls_elapsed / a.steps * 1e3,
+                "what": "the same %d steps through pic1dp_hip_push / particle_optimize / collect_charge / "
+                        "solve_field, the three call sites of src/pic1dp.F90:80-89 (served lazily by the "
+                        "whole-step kernels)" % a.steps,
+            }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_particles_per_core, a.cpu_steps)
         print(json.dumps(out), flush=True)

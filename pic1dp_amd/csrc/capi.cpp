@@ -54,6 +54,8 @@ constexpr int kTagFused = 100, kTagPush = 101, kTagDeposit = 102, kTagStepHalf =
               kNumTags = 128;
 constexpr int64_t kHistCap = 1 << 20;
 constexpr int kEnergyBlocks = 1024;
+// states of the lazy call sites (pic1dp_ctx::lz)
+enum { LZ_CLEAN = 0, LZ_PUSH1, LZ_HALF, LZ_PUSH2 };
 
 bool is_pow2(double c) {
   if (!(c > 0.0) || !std::isfinite(c)) return false;
@@ -96,6 +98,13 @@ struct pic1dp_ctx {
   double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
   double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
   double *d_Eh = nullptr;  // field after the first sub-step of the last whole-step call
+  // The reference's three call sites at whole-step cost (see "lazy call sites"
+  // below): a push is only noted; the collect_charge that follows runs the
+  // whole-step kernel instead of push + deposit.
+  int lazy_calls = 1;            // PIC1DP_LAZY_CALLS=0: every call launches its own kernel at once
+  int lz = 0;                    // LZ_CLEAN / LZ_PUSH1 / LZ_HALF / LZ_PUSH2
+  double *d_E0 = nullptr;        // field the noted push(1) saw
+  double *d_rho_dummy = nullptr; // accumulator of a wrap-only deposit
   int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
   int field_solver = 0;    // 0 the reference's mode-filter DFT solve, 1 finite-difference tridiagonal (opt-in)
   // marker state (bytes) above which k_step_half / k_step_full stream non-temporally
@@ -292,14 +301,14 @@ int allreduce_charge(pic1dp_ctx *c) {
   return sp.end();
 }
 
-PushArgs make_push_args(pic1dp_ctx *c, int isp, int irk) {
+PushArgs make_push_args(pic1dp_ctx *c, int isp, int irk, const double *E) {
   Species &S = c->sp[isp];
   PushArgs a{};
   a.src = S.set[c->cur];
   a.base = irk == 2 ? S.set[1 - c->cur] : S.set[c->cur];
   a.dst = S.set[1 - c->cur];
   a.p = S.p;
-  a.E = c->d_E;
+  a.E = E ? E : c->d_E;
   a.rho = S.rho;
   a.np = S.np;
   a.dt = irk == 1 ? 0.5 * c->in.dt : c->in.dt;  // src/pic1dp_interaction.F90:179,192
@@ -332,11 +341,11 @@ int ensure_second_set(pic1dp_ctx *c) {
   return 0;
 }
 
-int enqueue_push(pic1dp_ctx *c, int irk, bool fused) {
+int enqueue_push(pic1dp_ctx *c, int irk, bool fused, const double *E = nullptr) {
   if (int rc = ensure_second_set(c)) return rc;
   c->state_version++;
   for (int s = 0; s < c->in.nspecies; ++s) {
-    PushArgs a = make_push_args(c, s, irk);
+    PushArgs a = make_push_args(c, s, irk, E);
     if (a.np <= 0) continue;
     LaunchCfg lc = particle_launch(c, a.np, true, fused);
     Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
@@ -605,6 +614,9 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMalloc(&c->d_E, sizeof(double) * nx));
   HIP_TRY_C(hipMalloc(&c->d_Eh, sizeof(double) * nx));
   HIP_TRY_C(hipMemsetAsync(c->d_Eh, 0, sizeof(double) * nx, c->st));
+  HIP_TRY_C(hipMalloc(&c->d_E0, sizeof(double) * nx));
+  HIP_TRY_C(hipMalloc(&c->d_rho_dummy, sizeof(double) * nx));
+  if (const char *e = std::getenv("PIC1DP_LAZY_CALLS")) c->lazy_calls = std::atoi(e) != 0;
   HIP_TRY_C(hipMalloc(&c->d_mode_re, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_mode_im, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_fre, sizeof(double) * nm * nx));
@@ -687,7 +699,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     if (S.set[1].w != S.set[0].w) (void)hipFree(S.set[1].w);
   }
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
-                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part};
+                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy};
   for (double *b : bufs) (void)hipFree(b);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);
@@ -706,9 +718,12 @@ int pic1dp_hip_local_sizes(pic1dp_ctx *c, int32_t isp, int64_t *nalloc, int64_t 
   return 0;
 }
 
+static int materialize(pic1dp_ctx *c);  // lazy call sites, see below
+
 int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
+  c->lz = LZ_CLEAN;  // a noted push of markers that are about to be replaced is void
   c->state_version++;
   const pic1dp_input &in = c->in;
   const int npe = c->lay.npe, ns = in.nspecies;
@@ -781,6 +796,8 @@ int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, con
   if (n != S.nalloc) return fail(PIC1DP_ERR_ARG, "n = %lld but this process owns %lld slots", (long long)n, (long long)S.nalloc);
   if (np < 0 || np > n) return fail(PIC1DP_ERR_ARG, "np out of range");
   HIP_TRY(hipSetDevice(c->device));
+  if (c->loaded)
+    if (int rc = materialize(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   c->state_version++;
   // an upload (re)starts from set 0 for every species: slots beyond np live there
@@ -814,6 +831,7 @@ int pic1dp_hip_particles_download(pic1dp_ctx *c, int32_t isp, double *x, double 
   Species &S = c->sp[isp];
   if (n != S.nalloc) return fail(PIC1DP_ERR_ARG, "n = %lld but this process owns %lld slots", (long long)n, (long long)S.nalloc);
   HIP_TRY(hipSetDevice(c->device));
+  if (int rc = materialize(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   const PSet &A = S.set[c->cur];
   const int64_t np = S.np;
@@ -838,6 +856,8 @@ int pic1dp_hip_particles_download_bak(pic1dp_ctx *c, int32_t isp, double *xb, do
   if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
   Species &S = c->sp[isp];
   if (n != S.nalloc) return fail(PIC1DP_ERR_ARG, "n does not match the owned slots");
+  HIP_TRY(hipSetDevice(c->device));
+  if (int rc = materialize(c)) return rc;
   if (!S.set[1].x) return fail(PIC1DP_ERR_STATE, "no RK backup exists before the first push / substep call");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->st));
@@ -851,7 +871,8 @@ int pic1dp_hip_particles_download_bak(pic1dp_ctx *c, int32_t isp, double *xb, do
 // ---------------------------------------------------------------------------
 // hot path
 // ---------------------------------------------------------------------------
-static int require_loaded(pic1dp_ctx *c) {
+// checks only: for the call sites that take part in the lazy scheme themselves
+static int require_loaded_keep_lazy(pic1dp_ctx *c) {
   if (!c->loaded) return fail(PIC1DP_ERR_STATE, "no particles: call particle_load or particles_upload first");
   if (c->charge_pending) return fail(PIC1DP_ERR_STATE, "charge_local is waiting for charge_reduced");
   hipError_t e = hipSetDevice(c->device);
@@ -859,11 +880,76 @@ static int require_loaded(pic1dp_ctx *c) {
   return 0;
 }
 
+// every other entry point that reads or writes markers or charge accumulators:
+// memory first becomes what the eager calls would have left
+static int require_loaded(pic1dp_ctx *c) {
+  if (int rc = require_loaded_keep_lazy(c)) return rc;
+  return materialize(c);
+}
+
+// ---------------------------------------------------------------------------
+// Lazy call sites.  The reference driver calls push(irk), collect_charge,
+// solve_field per sub-step (src/pic1dp.F90:80-89).  Run one kernel per call, that
+// sequence streams 136 B + 2 x 24 B per marker and step; the whole-step kernels
+// need 88 B.  So push() only notes the request and the collect_charge() that
+// follows runs k_step_half (after push(1): deposit of the half-step state,
+// nothing stored) or k_step_full (after push(2): the whole RK2 step in place).
+//   LZ_CLEAN --push(1)--> LZ_PUSH1 --collect--> LZ_HALF --push(2)--> LZ_PUSH2 --collect--> LZ_CLEAN
+// Memory then lags behind what the reference would hold (the half-step state is
+// never written).  Every other entry point that looks at or changes markers,
+// accumulators or the field a noted push depends on first calls materialize(),
+// which runs the ordinary kernels (k_push with the right field, wrap) so that
+// memory is bit for bit what the eager calls would have left; results of the lazy
+// path itself are the whole-step path's (tests: test_lazy_call_sites_*).
+// ---------------------------------------------------------------------------
+static bool step_recompute_ok(const pic1dp_ctx *c);
+static bool optimize_due_any(const pic1dp_ctx *c);
+static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh);
+
+static bool lazy_ok(const pic1dp_ctx *c) {
+  return c->lazy_calls && step_recompute_ok(c) && !optimize_due_any(c);
+}
+
+// wrap of x stored back, as the deposit of collect_charge does, charge discarded
+static int enqueue_wrap_only(pic1dp_ctx *c) {
+  for (int s = 0; s < c->in.nspecies; ++s) {
+    Species &S = c->sp[s];
+    if (S.np <= 0) continue;
+    const double *q = c->in.deltaf ? S.set[c->cur].w : S.p;
+    LaunchCfg lc = particle_launch(c, S.np, false, true);
+    HIP_TRY(launch_deposit(S.set[c->cur].x, q, c->d_rho_dummy, S.np, c->grid, lc, c->st));
+  }
+  return 0;
+}
+
+static int materialize(pic1dp_ctx *c) {
+  const int lz = c->lz;
+  c->lz = LZ_CLEAN;
+  if (lz == LZ_CLEAN) return 0;
+  if (lz == LZ_PUSH1) return enqueue_push(c, 1, false);           // the field has not changed since
+  // LZ_HALF / LZ_PUSH2: push(1) saw d_E0; its deposit wrapped x
+  if (int rc = enqueue_push(c, 1, false, c->d_E0)) return rc;
+  if (int rc = enqueue_wrap_only(c)) return rc;
+  if (lz == LZ_PUSH2) return enqueue_push(c, 2, false);
+  return 0;
+}
+
 int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   CHECK_CTX(c);
-  if (int rc = require_loaded(c)) return rc;
+  if (int rc = require_loaded_keep_lazy(c)) return rc;
   Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
-  if (int rc = enqueue_deposit(c)) return rc;
+  if (c->lz == LZ_PUSH1) {
+    HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
+    if (int rc = step_particles(c, false, c->d_E, c->d_Eh)) return rc;
+    c->lz = LZ_HALF;
+  } else if (c->lz == LZ_PUSH2) {
+    if (int rc = step_particles(c, true, c->d_E0, c->d_E)) return rc;
+    c->state_version++;
+    c->lz = LZ_CLEAN;
+  } else {
+    if (int rc = materialize(c)) return rc;
+    if (int rc = enqueue_deposit(c)) return rc;
+  }
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (multi) {
     HIP_TRY(launch_charge_local(c->fa, c->st));
@@ -896,6 +982,9 @@ int pic1dp_hip_set_field_solver(pic1dp_ctx *c, int32_t kind) {
 int pic1dp_hip_solve_field(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
+  // a noted push has to see the field of its own moment
+  if (c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2)
+    if (int rc = materialize(c)) return rc;
   Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
   if (int rc = enqueue_field_solve(c, f, false, true)) return rc;
@@ -905,7 +994,16 @@ int pic1dp_hip_solve_field(pic1dp_ctx *c) {
 int pic1dp_hip_push(pic1dp_ctx *c, int32_t irk) {
   CHECK_CTX(c);
   if (irk != 1 && irk != 2) return fail(PIC1DP_ERR_ARG, "irk must be 1 or 2");
-  if (int rc = require_loaded(c)) return rc;
+  if (int rc = require_loaded_keep_lazy(c)) return rc;
+  if (irk == 1 && c->lz == LZ_CLEAN && lazy_ok(c)) {
+    c->lz = LZ_PUSH1;
+    return 0;
+  }
+  if (irk == 2 && c->lz == LZ_HALF) {
+    c->lz = LZ_PUSH2;
+    return 0;
+  }
+  if (int rc = materialize(c)) return rc;
   return enqueue_push(c, irk, false);
 }
 
@@ -1095,9 +1193,9 @@ static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
   return lc;
 }
 
-// sub-step of the whole-step path: particle kernel(s), charge, field into Eout
-static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
-  if (full) c->state_version++;
+// the particle kernel(s) of one sub-step of the whole-step path: E0 = field at
+// the start of the step, Eh = field after the first sub-step (full only)
+static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh) {
   // x, v, w, p of all species against the 256 MiB Infinity Cache
   double state_bytes = 0.0;
   for (int s = 0; s < c->in.nspecies; ++s) state_bytes += 32.0 * static_cast<double>(c->sp[s].np);
@@ -1110,8 +1208,8 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
     a.v = S.set[c->cur].v;
     a.w = S.set[c->cur].w;
     a.p = S.p;
-    a.E0 = c->d_E;
-    a.Eh = c->d_Eh;
+    a.E0 = E0;
+    a.Eh = Eh;
     a.rho = S.rho;
     a.np = S.np;
     a.dt_half = 0.5 * c->in.dt;  // src/pic1dp_interaction.F90:179
@@ -1129,6 +1227,13 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
     if (int rc = ks.end()) return rc;
     if (int rc = tm.end()) return rc;
   }
+  return 0;
+}
+
+// sub-step of the whole-step path: particle kernel(s), charge, field into Eout
+static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
+  if (full) c->state_version++;
+  if (int rc = step_particles(c, full, c->d_E, c->d_Eh)) return rc;
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (multi) {
     HIP_TRY(launch_charge_local(c->fa, c->st));
@@ -1236,6 +1341,8 @@ int pic1dp_hip_set_electric(pic1dp_ctx *c, const double *E) {
   CHECK_CTX(c);
   if (!E) return fail(PIC1DP_ERR_ARG, "null array");
   HIP_TRY(hipSetDevice(c->device));
+  if (c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2)
+    if (int rc = materialize(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(c->d_E, E, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
   return 0;

@@ -674,3 +674,103 @@ def test_upload_between_substeps_restarts_cleanly(oracle_mod, amd):
     eng.step(2)
     assert abs(eng.field_energy() / sim.field_energy() - 1.0) < ENERGY_RTOL
     assert relerr(eng.energy_sums(), sim.energy_sums()) < 1e-11
+
+
+# --------------------------------------------------------------------------
+# lazy call sites: the reference's push / collect_charge / solve_field sequence
+# runs the whole-step kernels; anything that looks in between gets eager memory
+# --------------------------------------------------------------------------
+def _fresh(amd, monkeypatch, lazy, **kw):
+    monkeypatch.setenv("PIC1DP_LAZY_CALLS", "1" if lazy else "0")
+    eng = amd.Pic1dp(amd.make_input(**kw))
+    eng.particle_load()
+    eng.interaction_collect_charge()
+    eng.field_solve_electric()
+    return eng
+
+
+@pytest.mark.parametrize("name,kw,linear", STEP_CASES, ids=lambda v: str(v) if not isinstance(v, dict) else "")
+def test_lazy_call_sites_equal_eager_calls(amd, monkeypatch, name, kw, linear):
+    """three call sites per sub-step, never looking in between: the lazy engine
+    (whole-step kernels) and the eager one (k_push + k_deposit per call) hold
+    bit-identical markers after every step when fed the same fields"""
+    kw = dict(kw, nparticle_max=N_SMALL, nx=96, linear=linear)
+    a = _fresh(amd, monkeypatch, True, **kw)
+    b = _fresh(amd, monkeypatch, False, **kw)
+    b.set_electric(a.get_field()["electric"])
+    a.kernel_stats_enable(True)
+    for it in range(3):
+        for irk in (1, 2):
+            for e in (a, b):
+                e.interaction_push_particle(irk)
+                e.particle_optimize(irk)
+                e.interaction_collect_charge()
+                e.field_solve_electric()
+            assert relerr(b.get_field()["electric"], a.get_field()["electric"]) < 1e-10
+            b.set_electric(a.get_field()["electric"])
+        ga, gb = a.particles_download(), b.particles_download()
+        for k in "xvw":
+            assert np.array_equal(ga[k], gb[k]), (k, it)
+    # the lazy engine never ran the per-call kernels
+    assert a.kernel_stats(1)[1] == 0 and a.kernel_stats(2)[1] == 0
+    assert a.kernel_stats(3)[1] == 3 and a.kernel_stats(4)[1] == 3
+
+
+@pytest.mark.parametrize("where", ["after_push1", "after_collect1", "after_solve1", "after_push2"])
+def test_lazy_call_sites_materialise_on_inspection(amd, monkeypatch, where):
+    """stop the lazy sequence at every point and look: markers, RK backup and what
+    follows are exactly the eager engine's"""
+    kw = dict(nparticle_max=N_SMALL, nx=96)
+    a = _fresh(amd, monkeypatch, True, **kw)
+    b = _fresh(amd, monkeypatch, False, **kw)
+    b.set_electric(a.get_field()["electric"])
+    seq = [("after_push1", lambda e: e.interaction_push_particle(1)),
+           ("after_collect1", lambda e: e.interaction_collect_charge()),
+           ("after_solve1", lambda e: e.field_solve_electric()),
+           ("after_push2", lambda e: e.interaction_push_particle(2))]
+    for tag, fn in seq:
+        fn(a)
+        fn(b)
+        if tag == "after_solve1":
+            b.set_electric(a.get_field()["electric"])
+        if tag == where:
+            break
+    ga, gb = a.particles_download(), b.particles_download()
+    ba, bb = a.particles_download_bak(), b.particles_download_bak()
+    for k in "xvw":
+        assert np.array_equal(ga[k], gb[k]), k
+        assert np.array_equal(ba[k + "b"], bb[k + "b"]), k
+    # carry on to the end of the step (a is eager now) and compare again
+    rest = [t for t, _ in seq]
+    for tag, fn in seq[rest.index(where) + 1:]:
+        fn(a)
+        fn(b)
+        if tag == "after_solve1":
+            b.set_electric(a.get_field()["electric"])
+    for e in (a, b):
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.array_equal(ga[k], gb[k]), k
+    assert relerr(a.get_field()["electric"], b.get_field()["electric"]) < 1e-10
+
+
+def test_lazy_call_sites_field_changes_between_calls(amd, monkeypatch):
+    """a field set between push and collect_charge must not leak into the noted
+    push: push(irk) uses the field of its own moment, as an eager call does"""
+    kw = dict(nparticle_max=N_SMALL, nx=96)
+    a = _fresh(amd, monkeypatch, True, **kw)
+    b = _fresh(amd, monkeypatch, False, **kw)
+    E1, E2 = smooth_field(96, 5), smooth_field(96, 6)
+    for e in (a, b):
+        e.set_electric(E1)
+        e.interaction_push_particle(1)
+        e.set_electric(E2)                    # after the push: must not affect it
+        e.interaction_collect_charge()
+        e.interaction_push_particle(2)        # sees E2
+        e.set_electric(E1)
+        e.interaction_collect_charge()
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.array_equal(ga[k], gb[k]), k

@@ -38,3 +38,22 @@ for mode in (0, 1):
     parts = ["%s %.4f ms" % (nm, ms / cnt) for nm, (ms, cnt) in zip(names, ks) if cnt]
     print("mode %d: %.4e updates/s  %.4f ms/step  | %s" % (mode, n * 2 * steps / dt, dt / steps * 1e3, ", ".join(parts)), flush=True)
     eng.kernel_stats_enable(False)
+
+# the reference's own call sequence (src/pic1dp.F90:79-93): three call sites per
+# sub-step, served lazily by the whole-step kernels unless PIC1DP_LAZY_CALLS=0
+eng.set_step_mode(0)
+eng.sync()
+eng.kernel_stats_enable(True)
+eng.timers_reset()
+t0 = time.perf_counter()
+for _ in range(steps):
+    for irk in (1, 2):
+        eng.interaction_push_particle(irk)
+        eng.particle_optimize(irk)
+        eng.interaction_collect_charge()
+        eng.field_solve_electric()
+eng.sync()
+dt = time.perf_counter() - t0
+ks = [eng.kernel_stats(k) for k in range(5)]
+parts = ["%s %.4f ms" % (nm, ms / cnt) for nm, (ms, cnt) in zip(names, ks) if cnt]
+print("calls : %.4e updates/s  %.4f ms/step  | %s" % (n * 2 * steps / dt, dt / steps * 1e3, ", ".join(parts)), flush=True)
