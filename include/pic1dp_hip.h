@@ -239,7 +239,13 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *ctx);
  * into field_electric, field_mode_re, field_mode_im */
 int pic1dp_hip_solve_field(pic1dp_ctx *ctx);
 /* interaction_push_particle (src/pic1dp_interaction.F90:161-370, call site
- * src/pic1dp.F90:80); irk = global_irk = 1 or 2 */
+ * src/pic1dp.F90:80); irk = global_irk = 1 or 2.
+ * In the reference's sequence push(1), collect_charge, solve_field, push(2),
+ * collect_charge, solve_field the push is only noted and the collect_charge
+ * that follows runs one whole-step kernel for both (88 instead of 184 bytes per
+ * marker and step).  Whatever looks at the markers in between first gets the
+ * ordinary kernels run, so every observable state is the eager one, bit for
+ * bit.  PIC1DP_LAZY_CALLS=0 in the environment: one kernel per call, at once. */
 int pic1dp_hip_push(pic1dp_ctx *ctx, int32_t irk);
 /* particle_optimize (src/pic1dp_particle.F90:724-783; call site src/pic1dp.F90:82,
  * right after the push of sub-step irk): when global_time + dt has reached the

@@ -934,22 +934,30 @@ static int materialize(pic1dp_ctx *c) {
   return 0;
 }
 
-int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
-  CHECK_CTX(c);
-  if (int rc = require_loaded_keep_lazy(c)) return rc;
-  Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
+// the deposit of collect_charge / charge_local into the species accumulators:
+// the whole-step kernel of a noted push, or the plain wrap + deposit
+static int deposit_or_step(pic1dp_ctx *c) {
   if (c->lz == LZ_PUSH1) {
     HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
     if (int rc = step_particles(c, false, c->d_E, c->d_Eh)) return rc;
     c->lz = LZ_HALF;
-  } else if (c->lz == LZ_PUSH2) {
+    return 0;
+  }
+  if (c->lz == LZ_PUSH2) {
     if (int rc = step_particles(c, true, c->d_E0, c->d_E)) return rc;
     c->state_version++;
     c->lz = LZ_CLEAN;
-  } else {
-    if (int rc = materialize(c)) return rc;
-    if (int rc = enqueue_deposit(c)) return rc;
+    return 0;
   }
+  if (int rc = materialize(c)) return rc;
+  return enqueue_deposit(c);
+}
+
+int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
+  CHECK_CTX(c);
+  if (int rc = require_loaded_keep_lazy(c)) return rc;
+  Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
+  if (int rc = deposit_or_step(c)) return rc;
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (multi) {
     HIP_TRY(launch_charge_local(c->fa, c->st));
@@ -1683,8 +1691,8 @@ int pic1dp_hip_debug_div_check(pic1dp_ctx *c, int64_t n, uint64_t seed, int64_t 
 int pic1dp_hip_charge_local(pic1dp_ctx *c, double *charge2) {
   CHECK_CTX(c);
   if (!charge2) return fail(PIC1DP_ERR_ARG, "null array");
-  if (int rc = require_loaded(c)) return rc;
-  if (int rc = enqueue_deposit(c)) return rc;
+  if (int rc = require_loaded_keep_lazy(c)) return rc;
+  if (int rc = deposit_or_step(c)) return rc;
   HIP_TRY(launch_charge_local(c->fa, c->st));
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(charge2, c->d_charge, sizeof(double) * c->in.nx, hipMemcpyDeviceToHost));

@@ -469,6 +469,34 @@ def test_split_phase_charge(amd):
     assert np.array_equal(a.particles_download()["x"], b.particles_download()["x"])
 
 
+def test_split_phase_charge_time_loop(amd):
+    """a host that keeps its own MPI_Allreduce: push / charge_local / [reduce] /
+    charge_reduced / solve_field for whole steps gives the markers of the
+    collect_charge loop (both served by the whole-step kernels)"""
+    inp = amd.make_input(nparticle_max=N_SMALL, nx=64)
+    a, b = amd.Pic1dp(inp), amd.Pic1dp(inp)
+    for e in (a, b):
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+    b.set_electric(a.get_field()["electric"])
+    b.kernel_stats_enable(True)
+    for it in range(3):
+        for irk in (1, 2):
+            a.interaction_push_particle(irk)
+            a.interaction_collect_charge()
+            a.field_solve_electric()
+            b.interaction_push_particle(irk)
+            b.charge_reduced(b.charge_local())
+            b.field_solve_electric()
+            assert relerr(b.get_field()["electric"], a.get_field()["electric"]) < 1e-10
+            b.set_electric(a.get_field()["electric"])
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.array_equal(ga[k], gb[k]), k
+    assert b.kernel_stats(1)[1] == 0 and b.kernel_stats(4)[1] == 3
+
+
 def test_rccl_allreduce_path_single_rank(oracle_mod, amd):
     """a 1-rank RCCL communicator: exercises the run-time RCCL binding, the
     unique-id hand-off and the split kernels (charge_local -> ncclAllReduce on
