@@ -956,8 +956,14 @@ static int deposit_or_step(pic1dp_ctx *c) {
 int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   CHECK_CTX(c);
   if (int rc = require_loaded_keep_lazy(c)) return rc;
+  // a whole-step kernel run for a noted push is booked under "push particle"
+  // (step_particles); "collect charge" then covers the reduction and scaling only
+  const bool noted = c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2;
+  if (noted)
+    if (int rc = deposit_or_step(c)) return rc;
   Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
-  if (int rc = deposit_or_step(c)) return rc;
+  if (!noted)
+    if (int rc = deposit_or_step(c)) return rc;
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (multi) {
     HIP_TRY(launch_charge_local(c->fa, c->st));
