@@ -47,8 +47,8 @@ CONFIGS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--particles", type=int, default=0, help="markers per GPU (override)")
     ap.add_argument("--nx", type=int, default=0)

@@ -1192,9 +1192,13 @@ static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
   lc.lds = step_lds_bytes(c->in.nx, full);
   int by_lds = static_cast<int>((160 * 1024) / lc.lds);
   if (by_lds < 1) by_lds = 1;
-  int threads = c->threads_req > 0 ? c->threads_req : 512;
-  if (c->threads_req <= 0 && by_lds * threads < 2048) threads = 1024;
-  int bpc = 2048 / threads;
+  // two workgroups of 768 threads per CU (24 waves): measured inside one process
+  // (tools/ab_launch.py) best or within 1 % of best from 6.4e6 to 1e8 markers --
+  // fewer workgroups mean fewer LDS stagings and half as many global flush atomics
+  // as four workgroups of 512, which cost k_step_half 25 % at 6.4e6 and 15 % at 2e7
+  int threads = c->threads_req > 0 ? c->threads_req : 768;
+  if (c->threads_req <= 0 && by_lds < 2) threads = 1024;
+  int bpc = c->threads_req > 0 ? 2048 / threads : (threads == 768 ? 2 : 1);
   if (bpc > by_lds) bpc = by_lds;
   if (c->bpc_req > 0) bpc = c->bpc_req < by_lds ? c->bpc_req : by_lds;
   if (bpc < 1) bpc = 1;

@@ -17,7 +17,7 @@ cat "$OUT/bench_c3_wholestep.json"
 
 echo "[2/4] kernel trace + stats" && date
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \
-  python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline \
+  python3 "$R/bench.py" --steps 50 --warmup 40 --no-cpu-baseline \
   > "$OUT/bench_c3_wholestep_under_rocprof.json" 2> "$OUT/stats.err"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -n 1)" "$OUT/bench_c3_wholestep_kernel_stats.csv"
 
