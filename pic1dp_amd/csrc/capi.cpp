@@ -108,9 +108,18 @@ struct pic1dp_ctx {
   int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
   int field_solver = 0;    // 0 the reference's mode-filter DFT solve, 1 finite-difference tridiagonal (opt-in)
   // marker state (bytes) above which k_step_half / k_step_full stream non-temporally
-  // (measured crossovers at nx = 1024: 0.9e7 markers for the read-only half kernel, ~3e7 for the
-  // read-modify-write full kernel, whose plain stores stay ahead for longer)
-  double nt_threshold_half = 288.0 * 1048576.0, nt_threshold_full = 768.0 * 1048576.0;
+  // The two kernels leave the caches to each other, so the pairs were compared inside
+  // one process on the same arrays (tools/ab_nt.py, nx = 1024, half + full in ms):
+  //   markers   plain/plain   nt/nt    half nt, full plain   half plain, full nt
+  //   6.4e6       0.102*      0.114         0.105                 0.106
+  //   1e7         0.159       0.169         0.158*                0.158*
+  //   2e7         0.372       0.332         0.326                 0.319*
+  //   3e7         0.539       0.497         0.492                 0.483*
+  //   5e7         0.886       0.829*        0.835                 0.828*
+  //   1e8         1.745       1.657*        1.676                 1.678
+  // => both plain below 288 MiB of marker state, the full kernel non-temporal above
+  //    it, the half kernel only above 2 GiB
+  double nt_threshold_half = 2048.0 * 1048576.0, nt_threshold_full = 288.0 * 1048576.0;
   int64_t hist_count = 0;
   // marker diagnostics of output_all: one fused pass per species (histograms +
   // kinetic sums), kept until the markers change
@@ -1217,7 +1226,14 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
   // x, v, w, p of all species against the 256 MiB Infinity Cache
   double state_bytes = 0.0;
   for (int s = 0; s < c->in.nspecies; ++s) state_bytes += 32.0 * static_cast<double>(c->sp[s].np);
-  const int stream_nt = state_bytes > (full ? c->nt_threshold_full : c->nt_threshold_half) ? 1 : 0;
+  int stream_nt = state_bytes > (full ? c->nt_threshold_full : c->nt_threshold_half) ? 1 : 0;
+  if (const char *e = std::getenv("PIC1DP_NT_FORCE")) {  // tuning only, read per launch (tools/ab_nt.py)
+    const int f = std::atoi(e);
+    if (f == 0) stream_nt = 0;
+    if (f == 1) stream_nt = 1;
+    if (f == 2) stream_nt = full ? 0 : 1;
+    if (f == 3) stream_nt = full ? 1 : 0;
+  }
   for (int s = 0; s < c->in.nspecies; ++s) {
     Species &S = c->sp[s];
     if (S.np <= 0) continue;
