@@ -1486,6 +1486,32 @@ hipError_t launch_energy_sums(const double *v, const double *p, const double *w,
   return hipGetLastError();
 }
 
+namespace {
+
+// harmless synthetic markers for timing runs on not yet loaded arrays: x spread
+// over [0, lx), |v| < 4, tiny weights
+__global__ void __launch_bounds__(256)
+k_fill_markers(double *x, double *v, double *w, double *p, int64_t n, double lx) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint64_t z = 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    const double u1 = static_cast<double>(z >> 11) * 0x1p-53, u2 = static_cast<double>((z * 0x94D049BB133111EBull) >> 11) * 0x1p-53;
+    x[i] = lx * u1;
+    v[i] = 8.0 * u2 - 4.0;
+    w[i] = 1e-5 * (u1 - 0.5);
+    p[i] = 1e-6;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_fill_markers(double *x, double *v, double *w, double *p, int64_t n, double lx, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill_markers, dim3(2048), dim3(256), 0, st, x, v, w, p, n, lx);
+  return hipGetLastError();
+}
+
 hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
                                unsigned long long *count, hipStream_t st) {
   int blocks = static_cast<int>((np + 255) / 256);

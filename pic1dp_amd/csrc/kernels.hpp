@@ -134,6 +134,8 @@ int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n);
 // generated dividends, on the device and with the host's fma
 hipError_t launch_divc_check(double c, uint64_t seed, int64_t n, unsigned long long *bad, hipStream_t st);
 int64_t host_divc_check(double c, uint64_t seed, int64_t n);
+// synthetic markers (timing runs on arrays that hold nothing yet)
+hipError_t launch_fill_markers(double *x, double *v, double *w, double *p, int64_t n, double lx, hipStream_t st);
 // cell index per marker and per-cell counts from (wrapped) x
 hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
                                unsigned long long *count, hipStream_t st);
