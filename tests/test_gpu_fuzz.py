@@ -80,3 +80,78 @@ def test_random_configuration(oracle_mod, amd, seed):
         npv = eng.local_sizes(isp)[1]
         assert np.max(np.abs(got["x"][:npv] - sim.gather("x", isp))) < 1e-8
         assert np.max(np.abs(got["v"][:npv] - sim.gather("v", isp))) < 1e-8
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_call_sequences_lazy_equals_eager(amd, monkeypatch, seed):
+    """differential test of the lazy call sites: random sequences of the hot-path
+    calls, field changes and inspections, applied to an engine with lazy call sites
+    and to one launching a kernel per call; every inspection and the final state
+    must agree bit for bit (fields are copied over after every solve so that both
+    push with the same bits)"""
+    rng = np.random.default_rng(1000 + seed)
+    kw = dict(nparticle_max=20001, nx=int(rng.choice([32, 48, 96])), linear=int(rng.integers(0, 2)),
+              iptcldist=int(rng.choice([0, 1, 2, 3])))
+    if kw["iptcldist"] == 2:
+        kw.update(species_density=[1.0], species_v0=[3.0])
+    engines = []
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("PIC1DP_LAZY_CALLS", lazy)
+        e = amd.Pic1dp(amd.make_input(**kw))
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+        engines.append(e)
+    a, b = engines
+    b.set_electric(a.get_field()["electric"])
+    nx = kw["nx"]
+
+    def same(tag):
+        ga, gb = a.particles_download(), b.particles_download()
+        for k in "xvw":
+            assert np.array_equal(ga[k], gb[k], equal_nan=True), (tag, k)
+
+    ops = ["push1", "collect", "solve", "push2", "collect", "solve"]      # the reference's order, mostly
+    log = []
+    for i in range(48):
+        r = rng.random()
+        if r < 0.70:
+            op = ops[i % 6]
+        else:
+            op = str(rng.choice(["push1", "push2", "collect", "solve", "setE", "look", "bak", "sums", "dist", "optimize"]))
+        pushes = [o for o in log if o in ("push1", "push2")]
+        if op == "push2" and not (pushes and pushes[-1] == "push1"):
+            op = "push1"       # push(2) without a push(1) before it reads an undefined RK backup
+        log.append(op)
+        if op in ("push1", "push2"):
+            for e in (a, b):
+                e.interaction_push_particle(int(op[-1]))
+        elif op == "collect":
+            for e in (a, b):
+                e.interaction_collect_charge()
+        elif op == "solve":
+            for e in (a, b):
+                e.field_solve_electric()
+            b.set_electric(a.get_field()["electric"])
+        elif op == "setE":
+            E = 0.02 * np.sin(2 * np.pi * np.arange(nx) / nx + rng.random()) + 0.002 * rng.standard_normal(nx)
+            for e in (a, b):
+                e.set_electric(E)
+        elif op == "look":
+            same("look after " + " ".join(log[-6:]))
+        elif op == "bak":
+            # the RK backup is defined between push(1) and push(2) only
+            pushes = [o for o in log if o in ("push1", "push2")]
+            if pushes and pushes[-1] == "push1":
+                ba, bb = a.particles_download_bak(), b.particles_download_bak()
+                for k in ("xb", "vb", "wb"):
+                    assert np.array_equal(ba[k], bb[k], equal_nan=True), (k, log[-6:])
+        elif op == "sums":
+            assert np.allclose(a.energy_sums(), b.energy_sums(), rtol=1e-12, atol=0, equal_nan=True)
+        elif op == "dist":
+            da, db = a.ptcldist(0, finish=False), b.ptcldist(0, finish=False)
+            assert np.allclose(da["markr_xv"], db["markr_xv"], rtol=1e-11, atol=1e-9, equal_nan=True)
+        elif op == "optimize":
+            for e in (a, b):
+                e.particle_optimize(2)
+    same("end: " + " ".join(log[-8:]))
