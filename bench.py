@@ -149,7 +149,14 @@ def main():
 
     # every rank owns one reference block of the global array (PETSC_DECIDE split)
     inp = pic1dp_amd.make_input(nparticle_max=total, nx=cfg["nx"])
-    eng = pic1dp_amd.Pic1dp(inp, rank=rank, nranks=world, device=local_rank)
+    # one GPU per rank; more ranks than visible GPUs (a rehearsal of the multi-rank
+    # control flow on a one-GPU box, host-staged all-reduce only) share the devices
+    ndev = pic1dp_amd.device_count()
+    device = local_rank % max(ndev, 1)
+    if world > ndev and not a.force_host_allreduce:
+        sys.exit("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank; "
+                 "--force-host-allreduce rehearses the control flow on fewer)" % (world, ndev))
+    eng = pic1dp_amd.Pic1dp(inp, rank=rank, nranks=world, device=device)
     if a.threads or a.blocks_per_cu:
         eng.set_launch(a.threads, a.blocks_per_cu)
     eng.set_step_mode(a.step_mode)
@@ -194,7 +201,7 @@ def main():
         try:
             import torch
             if torch.cuda.is_available():
-                torch.cuda.synchronize(local_rank)
+                torch.cuda.synchronize(device)
                 return "torch.cuda.synchronize"
         except Exception:
             pass
