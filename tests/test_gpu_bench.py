@@ -54,5 +54,5 @@ def test_bench_two_ranks_share_the_gpu(amd):
     eng.particle_load()
     eng.interaction_collect_charge()
     eng.field_solve_electric()
-    eng.step(warm + steps)
+    eng.step(d["settle_steps_before_warmup"] + warm + steps)
     assert abs(d["field_energy_end"] / eng.field_energy() - 1.0) < 1e-10
