@@ -222,7 +222,7 @@ def main():
                 eng.field_solve_electric()
 
     # the first ~30 steps over freshly loaded markers run 3-13 % slower than the
-    # steady state (tools/ramp_test.py), whatever the caller's W: settle first,
+    # steady state (tools/ramp_probe.py), whatever the caller's W: settle first,
     # untimed and reported, then do the W warm-up steps of the contract
     settle = max(0, 30 - a.warmup)
     device_sync()      # the first call initialises torch's device context (seconds): not between warm-up and timing

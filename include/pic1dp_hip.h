@@ -38,6 +38,7 @@ extern "C" {
 #define PIC1DP_MAX_MODES 4096 /* up to the full spectrum nx/2 of the largest grid */
 #define PIC1DP_MAX_INIT_MODES 16
 #define PIC1DP_COMM_ID_BYTES 128
+#define PIC1DP_XCHG_HANDLE_BYTES 64
 #define PIC1DP_MAX_OPT 32
 
 /* error codes */
@@ -356,6 +357,14 @@ int pic1dp_hip_debug_divc_check(pic1dp_ctx *ctx, int32_t ispecies, int64_t n,
 int pic1dp_hip_stream_probe(pic1dp_ctx *ctx, int32_t nread, int32_t nwrite, int64_t n,
                             int32_t reps, double *gbytes_per_s);
 
+/* tuning only (tools/layout_probe.py): the traffic shape of the second sub-step's
+ * kernel (4 arrays of n doubles read, 3 written back in place) timed over a fresh
+ * slab with the arrays apart (ms[0]) and interleaved in tiles of 2^log2_tile markers
+ * (ms[1]); keep != 0 leaves the slab allocated until destroy */
+int pic1dp_hip_debug_layout_probe(pic1dp_ctx *ctx, int64_t n, int32_t log2_tile,
+                                  int64_t stagger_bytes, int32_t reps, int32_t keep,
+                                  double ms[2]);
+
 /* ---- split-phase deposit for a host that owns the reduction (MPI) ------
  * charge_local: everything of collect_charge up to the all-reduce
  *   (src/pic1dp_interaction.F90:81-128) -> this rank's charge2[nx] on the host
@@ -373,6 +382,33 @@ int pic1dp_hip_charge_reduced(pic1dp_ctx *ctx, const double *charge1);
 int pic1dp_hip_comm_unique_id(unsigned char id[PIC1DP_COMM_ID_BYTES]);
 int pic1dp_hip_comm_init(pic1dp_ctx *ctx,
                          const unsigned char id[PIC1DP_COMM_ID_BYTES]);
+
+/* 0 when librccl can be loaded in this process (no device touched): lets every
+ * rank of a job agree on RCCL before any of them enters ncclCommInitRank */
+int pic1dp_hip_comm_available(void);
+
+/* ---- multi-GPU alternative: one-hop charge exchange (also replaces MPI_Allreduce
+ * at src/pic1dp_interaction.F90:132) ------------------------------
+ * Every rank keeps one slot per source rank; after its deposit a rank stores its
+ * charge vector into its slot on every GPU of the node (peer-mapped memory, one
+ * xGMI hop), then every GPU adds the slots in rank order inside the field
+ * solve's launch: one launch per sub-step instead of three, and the summed charge
+ * -- hence E and the trajectories -- are bit-identical on all ranks and from run to
+ * run.  Set-up: every rank calls xchg_create and hands its 64-byte handle to all
+ * ranks (MPI_Allgather / torch.distributed.all_gather); every rank then calls
+ * xchg_connect with the nranks handles in rank order (handles[rank] is its own),
+ * and set_allreduce(2) on all ranks at the same point of the run.  A rank that
+ * waits longer than PIC1DP_XCHG_TIMEOUT_MS (default 20 000) for a peer gives up:
+ * the kernels always finish and the next synchronising call returns
+ * PIC1DP_ERR_COMM. */
+int pic1dp_hip_xchg_create(pic1dp_ctx *ctx, unsigned char handle[PIC1DP_XCHG_HANDLE_BYTES]);
+int pic1dp_hip_xchg_connect(pic1dp_ctx *ctx, const unsigned char *handles);
+/* which reduction collect_charge / substep / step use from now on:
+ * 0 auto (RCCL when a communicator exists), 1 RCCL, 2 the one-hop exchange */
+int pic1dp_hip_set_allreduce(pic1dp_ctx *ctx, int32_t kind);
+/* memory kind of the exchange area (1 fine-grained, 2 uncached, 3 plain device
+ * memory), exchanges performed so far; returns PIC1DP_ERR_COMM after a time-out */
+int pic1dp_hip_xchg_info(pic1dp_ctx *ctx, int32_t *memkind, int64_t *exchanges);
 
 /* ---- timers: accumulated milliseconds under the reference's timer ids
  * (src/pic1dp_global.F90:38-50), measured with HIP events on the stream ---- */

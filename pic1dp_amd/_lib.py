@@ -14,6 +14,7 @@ MAX_SPECIES = 8
 MAX_MODES = 4096
 MAX_INIT_MODES = 16
 COMM_ID_BYTES = 128
+XCHG_HANDLE_BYTES = 64
 ABI_VERSION = 3
 MAX_OPT = 32
 
@@ -86,6 +87,7 @@ SIGNATURES = {
     "pic1dp_hip_host_divc_check": [C.c_double, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
     "pic1dp_hip_debug_divc_check": [_P, C.c_int32, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
     "pic1dp_hip_stream_probe": [_P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _D],
+    "pic1dp_hip_debug_layout_probe": [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _D],
     "pic1dp_hip_create": [_INP, C.POINTER(Layout), C.POINTER(_P)],
     "pic1dp_hip_destroy": [_P],
     "pic1dp_hip_local_sizes": [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
@@ -121,6 +123,11 @@ SIGNATURES = {
     "pic1dp_hip_charge_reduced": [_P, _P],
     "pic1dp_hip_comm_unique_id": [_P],
     "pic1dp_hip_comm_init": [_P, _P],
+    "pic1dp_hip_comm_available": [],
+    "pic1dp_hip_xchg_create": [_P, _P],
+    "pic1dp_hip_xchg_connect": [_P, _P],
+    "pic1dp_hip_set_allreduce": [_P, C.c_int32],
+    "pic1dp_hip_xchg_info": [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64)],
     "pic1dp_hip_timers_enable": [_P, C.c_int32],
     "pic1dp_hip_timer_ms": [_P, C.c_int32, _D],
     "pic1dp_hip_timers_reset": [_P],

@@ -67,6 +67,7 @@ struct Species {
   int64_t nalloc = 0, np = 0;
   PSet set[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   double *p = nullptr;
+  double *slab = nullptr;  // one allocation holding x, v, w, p of set 0 (null: four allocations)
   double *rho = nullptr;  // slice of rho_sp
   SpeciesConst sc{};
 };
@@ -105,6 +106,7 @@ struct pic1dp_ctx {
   int lz = 0;                    // LZ_CLEAN / LZ_PUSH1 / LZ_HALF / LZ_PUSH2
   double *d_E0 = nullptr;        // field the noted push(1) saw
   double *d_rho_dummy = nullptr; // accumulator of a wrap-only deposit
+  std::vector<double *> probe_keep;  // slabs a layout probe was asked to leave allocated
   int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
   int field_solver = 0;    // 0 the reference's mode-filter DFT solve, 1 finite-difference tridiagonal (opt-in)
   // marker state (bytes) above which k_step_half / k_step_full stream non-temporally
@@ -133,6 +135,19 @@ struct pic1dp_ctx {
   FieldArgs fa{};
   // comm
   ncclComm_t comm = nullptr;
+  // one-hop charge exchange (kernels.hip exchange_charge): the own area, the peers'
+  // areas as mapped through hipIpc, and the running exchange number
+  struct Xchg {
+    void *local = nullptr;                       // flags + slots of this rank
+    void *peer[XCHG_MAX_RANKS] = {nullptr};      // every rank's area as mapped here (own: local)
+    bool opened[XCHG_MAX_RANKS] = {false};       // peer[q] came from hipIpcOpenMemHandle
+    unsigned long long *err = nullptr;           // pinned host word the kernel reports a time-out in
+    unsigned long long epoch = 0;
+    long long timeout_ticks = 0;
+    bool connected = false;
+    int memkind = 0;                             // 1 fine-grained, 2 uncached, 3 plain hipMalloc
+  } xc;
+  int allreduce_kind = 0;  // 0 auto (RCCL when a communicator exists), 1 RCCL, 2 one-hop exchange
   // launch
   int threads_req = 0, bpc_req = 0;
   // timing
@@ -302,12 +317,52 @@ int validate(const pic1dp_input &in, const pic1dp_layout &lay) {
 int allreduce_charge(pic1dp_ctx *c) {
   if (c->lay.nranks == 1 && !c->comm) return 0;
   if (!c->comm)
-    return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: call pic1dp_hip_comm_init (or use charge_local/charge_reduced)");
+    return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: call pic1dp_hip_comm_init, connect the one-hop exchange (xchg_create / xchg_connect / set_allreduce), or use charge_local/charge_reduced");
   Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
   ncclResult_t r = rccl().AllReduce(c->d_charge, c->d_charge, static_cast<size_t>(c->in.nx), ncclDouble,
                                     ncclSum, c->comm, c->st);
   if (r != ncclSuccess) return fail(PIC1DP_ERR_COMM, "ncclAllReduce: %s", rccl().GetErrorString(r));
   return sp.end();
+}
+
+constexpr size_t kXchgFlagBytes = 4096;  // flags[2][XCHG_MAX_RANKS] u64, padded
+
+bool xchg_active(const pic1dp_ctx *c) { return c->allreduce_kind == 2 && c->xc.connected; }
+
+XchgArgs next_xchg_args(pic1dp_ctx *c) {
+  XchgArgs x{};
+  for (int q = 0; q < c->lay.nranks; ++q) {
+    char *b = reinterpret_cast<char *>(c->xc.peer[q]);
+    x.flags[q] = reinterpret_cast<unsigned long long *>(b);
+    x.slots[q] = reinterpret_cast<double *>(b + kXchgFlagBytes);
+  }
+  x.err = c->xc.err;
+  x.epoch = ++c->xc.epoch;
+  x.timeout_ticks = c->xc.timeout_ticks;
+  x.rank = c->lay.rank;
+  x.nranks = c->lay.nranks;
+  return x;
+}
+
+// a time-out reported by an exchange kernel (checked wherever the host synchronises)
+int xchg_check(pic1dp_ctx *c) {
+  if (!c->xc.err) return 0;
+  const unsigned long long e = *reinterpret_cast<volatile unsigned long long *>(c->xc.err);
+  if (e == 0) return 0;
+  return fail(PIC1DP_ERR_COMM, "charge exchange %llu: rank %d waited in vain for the charge of rank %d (peer stopped or out of step)",
+              e >> 8, c->lay.rank, static_cast<int>(e & 0xff) - 1);
+}
+
+// charge2 -> charge1 over ranks, whichever way is configured: the exchange kernel, or
+// k_charge_local + RCCL all-reduce (src/pic1dp_interaction.F90:126-135)
+int reduce_charge(pic1dp_ctx *c) {
+  if (xchg_active(c)) {
+    Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
+    HIP_TRY(launch_charge_exchange(c->fa, next_xchg_args(c), c->st));
+    return sp.end();
+  }
+  HIP_TRY(launch_charge_local(c->fa, c->st));
+  return allreduce_charge(c);
 }
 
 PushArgs make_push_args(pic1dp_ctx *c, int isp, int irk, const double *E) {
@@ -530,6 +585,7 @@ int pic1dp_hip_host_div_check(double lx, int32_t nx, int64_t n, uint64_t seed, i
 
 static bool step_recompute_ok(const pic1dp_ctx *c);
 static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh);
+static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full);
 
 // Where hipMalloc happens to put the four marker arrays of a species relative to
 // one another moves the whole-step kernels by several percent (HBM channel / bank
@@ -549,7 +605,7 @@ static int place_markers(pic1dp_ctx *c) {
   c->stats_on = c->timers_on = false;
   int rc = 0;
   for (Species &S : c->sp) {
-    if (static_cast<double>(S.nalloc) * 32.0 < 1073741824.0) continue;
+    if (static_cast<double>(S.nalloc) * 32.0 < 1073741824.0 || S.slab) continue;
     const size_t bytes = sizeof(double) * static_cast<size_t>(S.nalloc + 2);
     struct Cand {
       double *a[4];  // x, v, w, p
@@ -716,10 +772,28 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     // four arrays per species up front (x, v, w, p: 32 B per marker, 9e9 markers
     // in 288 GB); the second set of the RK ping-pong is allocated on the first
     // sub-step call that needs it (ensure_second_set) -- pic1dp_hip_step never does
-    HIP_TRY_C(hipMalloc(&S.p, bytes));
-    HIP_TRY_C(hipMalloc(&S.set[0].x, bytes));
-    HIP_TRY_C(hipMalloc(&S.set[0].v, bytes));
-    HIP_TRY_C(hipMalloc(&S.set[0].w, bytes));
+    int layout = 0;  // 0: four allocations; 1: one slab, arrays PIC1DP_SLAB_STAGGER bytes out of step
+    if (const char *e = std::getenv("PIC1DP_MARKER_LAYOUT")) layout = std::atoi(e);
+    if (layout == 1) {
+      size_t stagger = 0;
+      if (const char *e = std::getenv("PIC1DP_SLAB_STAGGER")) stagger = static_cast<size_t>(std::atoll(e)) & ~static_cast<size_t>(255);
+      const size_t unit = static_cast<size_t>(2) << 20;
+      const size_t stride = (bytes + unit - 1) / unit * unit + stagger;
+      HIP_TRY_C(hipMalloc(&S.slab, 4 * stride));
+      char *b = reinterpret_cast<char *>(S.slab);
+      S.set[0].x = reinterpret_cast<double *>(b);
+      S.set[0].v = reinterpret_cast<double *>(b + stride);
+      S.set[0].w = reinterpret_cast<double *>(b + 2 * stride);
+      S.p = reinterpret_cast<double *>(b + 3 * stride);
+    } else {
+      HIP_TRY_C(hipMalloc(&S.p, bytes));
+      HIP_TRY_C(hipMalloc(&S.set[0].x, bytes));
+      HIP_TRY_C(hipMalloc(&S.set[0].v, bytes));
+      HIP_TRY_C(hipMalloc(&S.set[0].w, bytes));
+    }
+    if (std::getenv("PIC1DP_PLACEMENT_VERBOSE"))
+      std::fprintf(stderr, "pic1dp markers species %d: x %p v %p w %p p %p (%zu bytes each)\n", s,
+                   (void *)S.set[0].x, (void *)S.set[0].v, (void *)S.set[0].w, (void *)S.p, bytes);
   }
 
   // field storage and the operators of field_init (src/pic1dp_field.F90:158-210),
@@ -808,11 +882,19 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     rccl().CommDestroy(c->comm);
     c->comm = nullptr;
   }
+  for (int q = 0; q < XCHG_MAX_RANKS; ++q)
+    if (c->xc.opened[q]) (void)hipIpcCloseMemHandle(c->xc.peer[q]);
+  if (c->xc.local) (void)hipFree(c->xc.local);
+  if (c->xc.err) (void)hipHostFree(c->xc.err);
   for (auto &S : c->sp) {
-    (void)hipFree(S.p);
-    (void)hipFree(S.set[0].x);
-    (void)hipFree(S.set[0].v);
-    (void)hipFree(S.set[0].w);
+    if (S.slab) {
+      (void)hipFree(S.slab);
+    } else {
+      (void)hipFree(S.p);
+      (void)hipFree(S.set[0].x);
+      (void)hipFree(S.set[0].v);
+      (void)hipFree(S.set[0].w);
+    }
     (void)hipFree(S.set[1].x);
     if (S.set[1].v != S.set[0].v) (void)hipFree(S.set[1].v);
     if (S.set[1].w != S.set[0].w) (void)hipFree(S.set[1].w);
@@ -820,6 +902,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
                     c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy};
   for (double *b : bufs) (void)hipFree(b);
+  for (double *b : c->probe_keep) (void)hipFree(b);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -1084,10 +1167,8 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   if (!noted)
     if (int rc = deposit_or_step(c)) return rc;
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
-  if (multi) {
-    HIP_TRY(launch_charge_local(c->fa, c->st));
-    if (int rc = allreduce_charge(c)) return rc;
-  }
+  if (multi)
+    if (int rc = reduce_charge(c)) return rc;
   HIP_TRY(launch_chargeden(c->fa, !multi, c->st));
   return tm.end();
 }
@@ -1278,14 +1359,17 @@ static int substep_impl(pic1dp_ctx *c, int irk, bool record) {
     return rc;
   }
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
-  if (multi) {
-    HIP_TRY(launch_charge_local(c->fa, c->st));
-    if (int rc = allreduce_charge(c)) return rc;
-  }
+  const bool fused_xchg = xchg_active(c) && c->field_solver == 0;  // exchange inside the solve's launch
+  if (multi && !fused_xchg)
+    if (int rc = reduce_charge(c)) return rc;
   Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
   if (record && c->hist_count < kHistCap) f.history = c->d_hist + c->hist_count++;
-  if (int rc = enqueue_field_solve(c, f, !multi, false)) return rc;
+  if (fused_xchg) {
+    HIP_TRY(launch_field_solve_xchg(f, next_xchg_args(c), c->st));
+  } else if (int rc = enqueue_field_solve(c, f, !multi, false)) {
+    return rc;
+  }
   return tm.end();
 }
 
@@ -1379,15 +1463,18 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
   if (full) c->state_version++;
   if (int rc = step_particles(c, full, c->d_E, c->d_Eh)) return rc;
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
-  if (multi) {
-    HIP_TRY(launch_charge_local(c->fa, c->st));
-    if (int rc = allreduce_charge(c)) return rc;
-  }
+  const bool fused_xchg = xchg_active(c) && c->field_solver == 0;  // exchange inside the solve's launch
+  if (multi && !fused_xchg)
+    if (int rc = reduce_charge(c)) return rc;
   Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
   f.E = Eout;
   if (record && c->hist_count < kHistCap) f.history = c->d_hist + c->hist_count++;
-  if (int rc = enqueue_field_solve(c, f, !multi, false)) return rc;
+  if (fused_xchg) {
+    HIP_TRY(launch_field_solve_xchg(f, next_xchg_args(c), c->st));
+  } else if (int rc = enqueue_field_solve(c, f, !multi, false)) {
+    return rc;
+  }
   return tm.end();
 }
 
@@ -1433,7 +1520,7 @@ int pic1dp_hip_sync(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->st));
-  return 0;
+  return xchg_check(c);
 }
 
 int pic1dp_hip_get_time(pic1dp_ctx *c, int32_t *itime, double *time) {
@@ -1474,6 +1561,7 @@ int pic1dp_hip_get_field(pic1dp_ctx *c, double *E, double *cd, double *re, doubl
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->st));
   const size_t nx = c->in.nx, nm = c->in.nmode;
+  if (int rc = xchg_check(c)) return rc;
   if (E) HIP_TRY(hipMemcpy(E, c->d_E, sizeof(double) * nx, hipMemcpyDeviceToHost));
   if (cd) HIP_TRY(hipMemcpy(cd, c->d_chargeden, sizeof(double) * nx, hipMemcpyDeviceToHost));
   if (re) HIP_TRY(hipMemcpy(re, c->d_mode_re, sizeof(double) * nm, hipMemcpyDeviceToHost));
@@ -1508,6 +1596,7 @@ int pic1dp_hip_field_energy(pic1dp_ctx *c, double *energy) {
   double *slot = c->d_scratch + kEnergyBlocks * 3;
   HIP_TRY(launch_field_energy(c->d_E, c->in.nx, c->in.lx, static_cast<double>(c->in.nx), slot, c->st));
   HIP_TRY(hipStreamSynchronize(c->st));
+  if (int rc = xchg_check(c)) return rc;
   HIP_TRY(hipMemcpy(energy, slot, sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1516,6 +1605,7 @@ int pic1dp_hip_energy_history(pic1dp_ctx *c, double *energy, int64_t max, int64_
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->st));
+  if (int rc = xchg_check(c)) return rc;
   int64_t n = c->hist_count < max ? c->hist_count : max;
   if (n < 0) n = 0;
   if (energy && n > 0) HIP_TRY(hipMemcpy(energy, c->d_hist, sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -1784,6 +1874,48 @@ int pic1dp_hip_stream_probe(pic1dp_ctx *c, int32_t nread, int32_t nwrite, int64_
   return rc;
 }
 
+// tuning only (tools/layout_probe.py): time k_step_full's traffic shape (4 arrays read,
+// 3 written in place) over a fresh slab, SoA against tiled; keep != 0 leaves the slab
+// allocated until destroy so that the next call lands in other physical memory
+int pic1dp_hip_debug_layout_probe(pic1dp_ctx *c, int64_t n, int32_t log2_tile, int64_t stagger_bytes, int32_t reps,
+                                  int32_t keep, double ms[2]) {
+  CHECK_CTX(c);
+  if (!ms || n < 2 || reps < 1 || log2_tile < 2 || log2_tile > 24) return fail(PIC1DP_ERR_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  const int64_t tile = static_cast<int64_t>(1) << log2_tile;
+  n = n / tile * tile;
+  const size_t unit = static_cast<size_t>(2) << 20;
+  const size_t stride = (sizeof(double) * static_cast<size_t>(n) + unit - 1) / unit * unit + static_cast<size_t>(stagger_bytes);
+  double *base = nullptr;
+  HIP_TRY(hipMalloc(&base, 4 * stride));
+  int rc = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMemsetAsync(base, 0, 4 * stride, c->st);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  LaunchCfg lc = step_launch(c, n, true);
+  for (int tiled = 0; tiled < 2 && e == hipSuccess; ++tiled) {
+    for (int r = 0; r < 3 && e == hipSuccess; ++r)
+      e = launch_layout_probe(base, static_cast<int64_t>(stride / sizeof(double)), log2_tile, n, tiled != 0, lc.blocks, lc.threads, c->st);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->st);
+    for (int r = 0; r < reps && e == hipSuccess; ++r)
+      e = launch_layout_probe(base, static_cast<int64_t>(stride / sizeof(double)), log2_tile, n, tiled != 0, lc.blocks, lc.threads, c->st);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+    ms[tiled] = t / reps;
+  }
+  if (e != hipSuccess) rc = fail(PIC1DP_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (keep && rc == 0)
+    c->probe_keep.push_back(base);
+  else
+    (void)hipFree(base);
+  return rc;
+}
+
 int pic1dp_hip_debug_divc_check(pic1dp_ctx *c, int32_t isp, int64_t n, uint64_t seed, int64_t *mismatches) {
   CHECK_CTX(c);
   if (!mismatches || n < 0) return fail(PIC1DP_ERR_ARG, "bad argument");
@@ -1877,6 +2009,100 @@ int pic1dp_hip_comm_init(pic1dp_ctx *c, const unsigned char id[PIC1DP_COMM_ID_BY
     return fail(PIC1DP_ERR_COMM, "ncclCommInitRank: %s", rccl().GetErrorString(r));
   }
   return 0;
+}
+
+// ---------------------------------------------------------------------------
+// one-hop charge exchange over peer-mapped memory (alternative to the RCCL
+// all-reduce; kernels.hip exchange_charge)
+// ---------------------------------------------------------------------------
+int pic1dp_hip_comm_available(void) {
+  std::string err;
+  if (!rccl().load(err)) return fail(PIC1DP_ERR_COMM, "%s", err.c_str());
+  return 0;
+}
+
+int pic1dp_hip_xchg_create(pic1dp_ctx *c, unsigned char handle[PIC1DP_XCHG_HANDLE_BYTES]) {
+  static_assert(sizeof(hipIpcMemHandle_t) == PIC1DP_XCHG_HANDLE_BYTES, "ipc handle size");
+  CHECK_CTX(c);
+  if (!handle) return fail(PIC1DP_ERR_ARG, "null handle");
+  if (c->lay.nranks > XCHG_MAX_RANKS) return fail(PIC1DP_ERR_ARG, "the exchange serves at most %d ranks", XCHG_MAX_RANKS);
+  if (c->xc.local) return fail(PIC1DP_ERR_STATE, "exchange area already created");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t bytes = kXchgFlagBytes + sizeof(double) * 2 * static_cast<size_t>(c->lay.nranks) * c->in.nx;
+  // memory the peers' stores and this GPU's polls meet in: fine-grained (coherent
+  // across agents inside a kernel); PIC1DP_XCHG_MEM = 2 uncached, 3 plain hipMalloc
+  int want = 1;
+  if (const char *e = std::getenv("PIC1DP_XCHG_MEM")) want = std::atoi(e);
+  hipError_t e = hipErrorUnknown;
+  for (int kind = want; kind <= 3 && e != hipSuccess; ++kind) {
+    if (kind == 1) e = hipExtMallocWithFlags(&c->xc.local, bytes, hipDeviceMallocFinegrained);
+    if (kind == 2) e = hipExtMallocWithFlags(&c->xc.local, bytes, hipDeviceMallocUncached);
+    if (kind == 3) e = hipMalloc(&c->xc.local, bytes);
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) {
+      e = hipIpcGetMemHandle(&h, c->xc.local);
+      if (e == hipSuccess) {
+        std::memcpy(handle, &h, sizeof h);
+        c->xc.memkind = kind;
+      } else {
+        (void)hipFree(c->xc.local);
+        c->xc.local = nullptr;
+      }
+    }
+    if (e != hipSuccess) (void)hipGetLastError();
+  }
+  if (e != hipSuccess) return fail(PIC1DP_ERR_HIP, "exchange area: %s", hipGetErrorString(e));
+  HIP_TRY(hipMemset(c->xc.local, 0, bytes));
+  if (!c->xc.err) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->xc.err), 64, hipHostMallocDefault));
+    *c->xc.err = 0;
+  }
+  double tmo_ms = 20000.0;
+  if (const char *t = std::getenv("PIC1DP_XCHG_TIMEOUT_MS")) tmo_ms = std::atof(t);
+  c->xc.timeout_ticks = static_cast<long long>(tmo_ms * 1e5);  // wall_clock64 counts at 100 MHz
+  c->xc.epoch = 0;
+  HIP_TRY(hipDeviceSynchronize());
+  return 0;
+}
+
+int pic1dp_hip_xchg_connect(pic1dp_ctx *c, const unsigned char *handles) {
+  CHECK_CTX(c);
+  if (!handles) return fail(PIC1DP_ERR_ARG, "null handles");
+  if (!c->xc.local) return fail(PIC1DP_ERR_STATE, "xchg_connect before xchg_create");
+  if (c->xc.connected) return fail(PIC1DP_ERR_STATE, "exchange already connected");
+  HIP_TRY(hipSetDevice(c->device));
+  for (int q = 0; q < c->lay.nranks; ++q) {
+    if (q == c->lay.rank) {
+      c->xc.peer[q] = c->xc.local;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + static_cast<size_t>(q) * PIC1DP_XCHG_HANDLE_BYTES, sizeof h);
+    hipError_t e = hipIpcOpenMemHandle(&c->xc.peer[q], h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(PIC1DP_ERR_COMM, "hipIpcOpenMemHandle for the exchange area of rank %d: %s", q, hipGetErrorString(e));
+    }
+    c->xc.opened[q] = true;
+  }
+  c->xc.connected = true;
+  return 0;
+}
+
+int pic1dp_hip_set_allreduce(pic1dp_ctx *c, int32_t kind) {
+  CHECK_CTX(c);
+  if (kind < 0 || kind > 2) return fail(PIC1DP_ERR_ARG, "allreduce kind must be 0 (auto), 1 (RCCL) or 2 (one-hop exchange)");
+  if (kind == 2 && !c->xc.connected) return fail(PIC1DP_ERR_STATE, "the one-hop exchange is not connected");
+  if (kind == 1 && !c->comm) return fail(PIC1DP_ERR_STATE, "no RCCL communicator");
+  c->allreduce_kind = kind;
+  return 0;
+}
+
+int pic1dp_hip_xchg_info(pic1dp_ctx *c, int32_t *memkind, int64_t *exchanges) {
+  CHECK_CTX(c);
+  if (memkind) *memkind = c->xc.memkind;
+  if (exchanges) *exchanges = static_cast<int64_t>(c->xc.epoch);
+  return xchg_check(c);
 }
 
 // ---------------------------------------------------------------------------

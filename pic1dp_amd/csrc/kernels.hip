@@ -671,15 +671,11 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
 // field_solve_electric, src/pic1dp_field.F90:231-257, with the one-rank PETSc
 // summation order: forward sums run over ascending ix in ONE thread per
 // (mode, re/im) so the result is bit-identical to the sequential CPU loop.
+// chargeden into sCD (and memory) from: the all-reduced charge (neither flag), the
+// raw species deposits (WITH_LOCAL, one rank), or field_chargeden itself (FROM_CD)
 template <bool WITH_LOCAL, bool FROM_CD>
-__global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *sCD = reinterpret_cast<double *>(smem);       // [nx]
-  double *sMode = sCD + f.nx;                           // [2*nmode]: re then im
-  double *sScr = sMode + 2 * f.nmode;                   // [16]
-  double *sTab = sScr + 16;                             // [2][nmode][nx] when tab_lds
-  const int nx = f.nx, nm = f.nmode;
-
+__device__ __forceinline__ void solve_fill_chargeden(const FieldArgs &f, double *sCD) {
+  const int nx = f.nx;
   // four grid points per thread per trip, all loads issued before the first use
   // (one memory round trip instead of four for nx = 1024)
   constexpr int U = 4;
@@ -716,8 +712,13 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
       }
     }
   }
-  __syncthreads();
+}
 
+// the solve proper: chargeden in sCD -> mode_re/im, E (+ field energy)
+__device__ __forceinline__ void solve_body(const FieldArgs &f, double *sCD, double *sMode, double *sScr,
+                                           double *sTab) {
+  const int nx = f.nx, nm = f.nmode;
+  constexpr int U = 4;
   // forward partial DFT.  Every term table[ix]*chargeden[ix] is rounded on its
   // own in the reference too (no FMA), so the products are formed by all threads
   // at once (coalesced table reads) and only the additions run serially, in the
@@ -841,6 +842,107 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
       *f.history = nrm * nrm * f.lx / f.dnx;
     }
   }
+}
+
+template <bool WITH_LOCAL, bool FROM_CD>
+__global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sCD = reinterpret_cast<double *>(smem);       // [nx]
+  double *sMode = sCD + f.nx;                           // [2*nmode]: re then im
+  double *sScr = sMode + 2 * f.nmode;                   // [16]
+  double *sTab = sScr + 16;                             // [2][nmode][nx] when tab_lds
+  solve_fill_chargeden<WITH_LOCAL, FROM_CD>(f, sCD);
+  __syncthreads();
+  solve_body(f, sCD, sMode, sScr, sTab);
+}
+
+// ---------------------------------------------------------------------------
+// One-hop charge exchange (replaces MPI_Allreduce, src/pic1dp_interaction.F90:130-135,
+// for N processes = N GPUs of one node).  Every rank owns an exchange
+// area (fine-grained device memory, mapped into every peer through hipIpc handles):
+//     flags[2][XCHG_MAX_RANKS]   epoch of the last charge rank q delivered, per parity
+//     slots[2][nranks][nx]       the charge2 vectors, one slot per source rank
+// Exchange number e (1, 2, ...), parity e & 1:
+//   1. charge2 = sum_s rho_s * Z_s (accumulators re-zeroed), stored into slot [rank]
+//      of EVERY rank's area (system-scope stores: over xGMI for the peers),
+//   2. every storing wave drains its stores (system-scope release fence), the
+//      workgroup meets, then one lane per destination stores the flag e,
+//   3. lane q of the first wave polls flag q of the OWN area until it reads e
+//      (bounded by a wall-clock limit: on expiry the error word is set and the
+//      kernel goes on, so the grid always drains),
+//   4. charge1[ix] = slots[0][ix] + slots[1][ix] + ... in rank order: the same
+//      additions in the same order on every GPU, so charge1 -- and with it E and the
+//      marker trajectories -- are bit-identical on all ranks and from run to run,
+//      which RCCL's choice of algorithm does not promise.
+// Two parities suffice: a rank can start exchange e+2 (same parity as e) only after
+// every peer has flagged e+1, which a peer does after it has finished reading e.
+// ---------------------------------------------------------------------------
+#define PIC1DP_SYS __HIP_MEMORY_SCOPE_SYSTEM
+
+__device__ __forceinline__ void exchange_charge(const FieldArgs &f, const XchgArgs &x, double *sC) {
+  const int nx = f.nx, nr = x.nranks, par = static_cast<int>(x.epoch & 1);
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sC[ix] = charge_local_one(f, ix);
+  // own values only: no barrier needed before re-reading sC[ix] below
+  for (int k = 0; k < nr; ++k) {
+    int q = x.rank + k;  // start with the own area, then the peers in ring order
+    if (q >= nr) q -= nr;
+    double *dst = x.slots[q] + (static_cast<size_t>(par) * nr + x.rank) * nx;
+    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x)
+      __hip_atomic_store(dst + ix, sC[ix], __ATOMIC_RELAXED, PIC1DP_SYS);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this wave's stores have landed
+  __syncthreads();
+  if (threadIdx.x < nr) {
+    const int q = threadIdx.x;
+    __hip_atomic_store(x.flags[q] + par * XCHG_MAX_RANKS + x.rank, x.epoch, __ATOMIC_RELEASE, PIC1DP_SYS);
+    const unsigned long long *fl = x.flags[x.rank] + par * XCHG_MAX_RANKS + q;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, PIC1DP_SYS) < x.epoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > x.timeout_ticks) {  // give up: report, never hang
+        __hip_atomic_store(x.err, (x.epoch << 8) | static_cast<unsigned long long>(q + 1), __ATOMIC_RELAXED, PIC1DP_SYS);
+        break;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  __syncthreads();
+  const double *mine = x.slots[x.rank] + static_cast<size_t>(par) * nr * nx;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+    double t[XCHG_MAX_RANKS];
+#pragma unroll
+    for (int q = 0; q < XCHG_MAX_RANKS; ++q)
+      t[q] = q < nr ? __hip_atomic_load(mine + static_cast<size_t>(q) * nx + ix, __ATOMIC_RELAXED, PIC1DP_SYS) : 0.0;
+    double sum = t[0];
+#pragma unroll
+    for (int q = 1; q < XCHG_MAX_RANKS; ++q)
+      if (q < nr) sum = sum + t[q];
+    sC[ix] = sum;
+    f.charge[ix] = sum;
+  }
+}
+
+// exchange only: charge1 into field charge (collect_charge call site, many-mode solve)
+__global__ void __launch_bounds__(FIELD_THREADS) k_charge_exchange(const FieldArgs f, const XchgArgs x) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  exchange_charge(f, x, reinterpret_cast<double *>(smem));
+}
+
+// local charge -> exchange -> chargeden -> solve: one launch per sub-step
+__global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_xchg(const FieldArgs f, const XchgArgs x) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sCD = reinterpret_cast<double *>(smem);
+  double *sMode = sCD + f.nx;
+  double *sScr = sMode + 2 * f.nmode;
+  double *sTab = sScr + 16;
+  exchange_charge(f, x, sCD);
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) {  // own elements again
+    const double cd = chargeden_from(f, sCD[ix]);
+    f.chargeden[ix] = cd;
+    sCD[ix] = cd;
+  }
+  __syncthreads();
+  solve_body(f, sCD, sMode, sScr, sTab);
 }
 
 // Many kept modes (2*nmode > FIELD_THREADS, up to the full spectrum nmode = nx/2,
@@ -1050,6 +1152,23 @@ hipError_t launch_field_solve(const FieldArgs &f, bool with_local, bool from_cha
   } else {
     hipLaunchKernelGGL((k_field_solve<false, false>), dim3(1), dim3(FIELD_THREADS), lds, st, f);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_charge_exchange(const FieldArgs &f, const XchgArgs &x, hipStream_t st) {
+  hipLaunchKernelGGL(k_charge_exchange, dim3(1), dim3(FIELD_THREADS), sizeof(double) * f.nx, st, f, x);
+  return hipGetLastError();
+}
+
+hipError_t launch_field_solve_xchg(const FieldArgs &f, const XchgArgs &x, hipStream_t st) {
+  if (2 * f.nmode > FIELD_THREADS) {  // many modes: exchange, then the wide kernels from the summed charge
+    hipError_t e = launch_charge_exchange(f, x, st);
+    if (e != hipSuccess) return e;
+    return launch_field_solve(f, false, false, st);
+  }
+  const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
+                                       (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
+  hipLaunchKernelGGL(k_field_solve_xchg, dim3(1), dim3(FIELD_THREADS), lds, st, f, x);
   return hipGetLastError();
 }
 
@@ -1384,6 +1503,40 @@ hipError_t launch_probe_nr(const ProbeArgs &a, int nw, int variant, int blocks, 
 }
 
 }  // namespace
+
+namespace {
+
+// Layout probe (tuning only): the traffic of k_step_full -- four arrays read, three
+// of them written back in place, 16 B per lane, non-temporal -- over ONE slab, with
+// the four arrays either apart by `step` double2 (SoA, TILED = false) or interleaved
+// in tiles of 2^lt2 pairs: [x tile | v tile | w tile | p tile] (TILED = true).
+template <bool TILED>
+__global__ void __launch_bounds__(1024) k_layout_probe(double2 *base, int64_t step, int lt2, int64_t npair) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t mask = (static_cast<int64_t>(1) << lt2) - 1;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+    const int64_t o = TILED ? (((j >> lt2) << (lt2 + 2)) + (j & mask)) : j;
+    const int64_t d = TILED ? (static_cast<int64_t>(1) << lt2) : step;
+    const double2 a = ld2t<true>(base + o), b = ld2t<true>(base + o + d), c = ld2t<true>(base + o + 2 * d),
+                  e = ld2t<true>(base + o + 3 * d);
+    const double sx = a.x + b.x + c.x + e.x, sy = a.y + b.y + c.y + e.y;
+    st2t<true>(base + o, sx * 0.25, sy * 0.25);
+    st2t<true>(base + o + d, sx * 0.125, sy * 0.125);
+    st2t<true>(base + o + 2 * d, sx * 0.0625, sy * 0.0625);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_layout_probe(double *base, int64_t step_doubles, int log2_tile, int64_t n, bool tiled, int blocks,
+                               int threads, hipStream_t st) {
+  double2 *b2 = reinterpret_cast<double2 *>(base);
+  if (tiled)
+    hipLaunchKernelGGL(k_layout_probe<true>, dim3(blocks), dim3(threads), 0, st, b2, step_doubles >> 1, log2_tile - 1, n >> 1);
+  else
+    hipLaunchKernelGGL(k_layout_probe<false>, dim3(blocks), dim3(threads), 0, st, b2, step_doubles >> 1, log2_tile - 1, n >> 1);
+  return hipGetLastError();
+}
 
 hipError_t launch_stream_probe(double *const *in, int nr, double *const *out, int nw, int64_t n,
                                int blocks, int threads, int variant, hipStream_t st) {

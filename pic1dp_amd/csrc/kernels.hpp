@@ -94,6 +94,21 @@ struct FieldArgs {
   double Z[8], n0[8];
 };
 
+// one-hop charge exchange between the GPUs of a node (kernels.hip, exchange_charge)
+constexpr int XCHG_MAX_RANKS = 16;
+struct XchgArgs {
+  double *slots[XCHG_MAX_RANKS];               // every rank's slot area [2][nranks][nx] as mapped here
+  unsigned long long *flags[XCHG_MAX_RANKS];   // every rank's flag area [2][XCHG_MAX_RANKS]
+  unsigned long long *err;                     // host-visible error word (0 = fine)
+  unsigned long long epoch;                    // number of this exchange, from 1
+  long long timeout_ticks;                     // wall_clock64 ticks (100 MHz) a rank waits for its peers
+  int rank, nranks;
+};
+// local charge + exchange: the summed charge1 into f.charge
+hipError_t launch_charge_exchange(const FieldArgs &f, const XchgArgs &x, hipStream_t st);
+// local charge + exchange + chargeden + field solve in one launch
+hipError_t launch_field_solve_xchg(const FieldArgs &f, const XchgArgs &x, hipStream_t st);
+
 // charge2 = sum_s rho_sp[s]*Z_s ; rho_sp = 0      (src/pic1dp_interaction.F90:81-128)
 hipError_t launch_charge_local(const FieldArgs &f, hipStream_t st);
 // chargeden from charge (:138-148) only; with_local folds launch_charge_local in
@@ -125,6 +140,10 @@ int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu);
 // (nr, nw) in {1,4,7} x {0,1,3} arrays of n doubles read / written
 hipError_t launch_stream_probe(double *const *in, int nr, double *const *out, int nw, int64_t n,
                                int blocks, int threads, int variant, hipStream_t st);
+// tuning only: k_step_full's traffic shape over one slab, SoA (arrays step_doubles apart)
+// or tiled ([x|v|w|p] tiles of 2^log2_tile markers); n markers, n a multiple of the tile
+hipError_t launch_layout_probe(double *base, int64_t step_doubles, int log2_tile, int64_t n, bool tiled, int blocks,
+                               int threads, hipStream_t st);
 // div_lx (reciprocal + FMA corrections) against the hardware division on n test
 // positions; *bad counts results that differ in any bit
 hipError_t launch_div_check(const GridConst &g, uint64_t seed, int64_t n, unsigned long long *bad,

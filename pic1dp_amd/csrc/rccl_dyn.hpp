@@ -42,6 +42,8 @@ struct RcclApi {
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
       err = "librccl lacks a required symbol";
+      handle = nullptr;  // not usable: the next load() reports the failure again instead of returning true
+      GetUniqueId = nullptr, CommInitRank = nullptr, CommDestroy = nullptr, AllReduce = nullptr, GetErrorString = nullptr;
       return false;
     }
     return true;

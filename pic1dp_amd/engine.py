@@ -281,6 +281,31 @@ class Pic1dp:
         buf = (C.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(uid)
         check(self.L.pic1dp_hip_comm_init(self._ctx, buf))
 
+    def comm_available(self):
+        """raises unless librccl can be loaded in this process"""
+        check(self.L.pic1dp_hip_comm_available())
+
+    # -- one-hop charge exchange (alternative to the RCCL all-reduce) ---------------
+    def xchg_create(self):
+        buf = (C.c_ubyte * _lib.XCHG_HANDLE_BYTES)()
+        check(self.L.pic1dp_hip_xchg_create(self._ctx, buf))
+        return bytes(buf)
+
+    def xchg_connect(self, handles):
+        if len(handles) != _lib.XCHG_HANDLE_BYTES * self.nranks:
+            raise ValueError("need %d handle bytes per rank" % _lib.XCHG_HANDLE_BYTES)
+        buf = (C.c_ubyte * len(handles)).from_buffer_copy(handles)
+        check(self.L.pic1dp_hip_xchg_connect(self._ctx, buf))
+
+    def set_allreduce(self, kind):
+        """0 auto (RCCL when a communicator exists), 1 RCCL, 2 one-hop exchange"""
+        check(self.L.pic1dp_hip_set_allreduce(self._ctx, kind))
+
+    def xchg_info(self):
+        kind, n = C.c_int32(), C.c_int64()
+        check(self.L.pic1dp_hip_xchg_info(self._ctx, C.byref(kind), C.byref(n)))
+        return kind.value, n.value
+
     # -- timers / knobs -----------------------------------------------------------------
     def timers_enable(self, on=True):
         check(self.L.pic1dp_hip_timers_enable(self._ctx, int(on)))

@@ -391,6 +391,47 @@ interface
     integer(c_signed_char), intent(in) :: id(*)
     integer(c_int) :: ierr
   end function pic1dp_hip_comm_init
+  function pic1dp_hip_comm_available() bind(C, name="pic1dp_hip_comm_available") result(ierr)
+    import
+    integer(c_int) :: ierr
+  end function pic1dp_hip_comm_available
+  function pic1dp_hip_xchg_create(ctx, handle) bind(C, name="pic1dp_hip_xchg_create") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_signed_char), intent(out) :: handle(*)
+    integer(c_int) :: ierr
+  end function pic1dp_hip_xchg_create
+  function pic1dp_hip_xchg_connect(ctx, handles) bind(C, name="pic1dp_hip_xchg_connect") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_signed_char), intent(in) :: handles(*)
+    integer(c_int) :: ierr
+  end function pic1dp_hip_xchg_connect
+  function pic1dp_hip_set_allreduce(ctx, kind) bind(C, name="pic1dp_hip_set_allreduce") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: kind
+    integer(c_int) :: ierr
+  end function pic1dp_hip_set_allreduce
+  function pic1dp_hip_xchg_info(ctx, memkind, exchanges) bind(C, name="pic1dp_hip_xchg_info") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), intent(out) :: memkind
+    integer(c_int64_t), intent(out) :: exchanges
+    integer(c_int) :: ierr
+  end function pic1dp_hip_xchg_info
+  function pic1dp_hip_debug_layout_probe(ctx, n, log2_tile, stagger_bytes, reps, keep, ms) &
+      bind(C, name="pic1dp_hip_debug_layout_probe") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int64_t), value :: n
+    integer(c_int32_t), value :: log2_tile
+    integer(c_int64_t), value :: stagger_bytes
+    integer(c_int32_t), value :: reps
+    integer(c_int32_t), value :: keep
+    real(c_double), intent(out) :: ms(2)
+    integer(c_int) :: ierr
+  end function pic1dp_hip_debug_layout_probe
   function pic1dp_hip_timers_enable(ctx, on) bind(C, name="pic1dp_hip_timers_enable") result(ierr)
     import
     type(c_ptr), value :: ctx

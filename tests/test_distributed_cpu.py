@@ -70,11 +70,44 @@ def _worker(rank, world, port, q):
             def comm_unique_id(self):
                 return bytes((i * 7 + 3) % 256 for i in range(128))
 
+            def comm_available(self):
+                pass
+
             def comm_init(self, uid):
                 self.got = uid
 
+            # one-hop exchange: every rank's handle reaches every rank, in rank order
+            def xchg_create(self):
+                return bytes((rank * 64 + i) % 256 for i in range(64))
+
+            def xchg_connect(self, handles):
+                self.handles = handles
+
         fe = FakeEngine()
-        parallel.bootstrap_comm(fe, dist)
+        assert parallel.bootstrap_comm(fe, dist) is None
+        assert parallel.bootstrap_exchange(fe, dist) is None
+        assert fe.handles == b"".join(bytes((r * 64 + i) % 256 for i in range(64)) for r in range(world))
+
+        # failures are decided collectively: no rank enters comm_init / connect, none hangs
+        class NoId(FakeEngine):
+            def comm_unique_id(self):
+                raise RuntimeError("no librccl here")
+
+        class OneRankBlind(FakeEngine):
+            def comm_available(self):
+                if rank == 1:
+                    raise RuntimeError("cannot load")
+
+            def xchg_create(self):
+                if rank == 1:
+                    raise RuntimeError("no ipc")
+                return FakeEngine.xchg_create(self)
+
+        for cls in (NoId, OneRankBlind):
+            e = cls()
+            assert parallel.bootstrap_comm(e, dist) is not None and e.got is None
+        e = OneRankBlind()
+        assert parallel.bootstrap_exchange(e, dist) is not None and not hasattr(e, "handles")
         q.put((rank, chargeden, int(cnt.item()), fe.got))
     finally:
         dist.destroy_process_group()
