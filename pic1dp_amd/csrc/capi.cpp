@@ -67,7 +67,7 @@ struct Species {
   int64_t nalloc = 0, np = 0;
   PSet set[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   double *p = nullptr;
-  double *slab = nullptr;  // one allocation holding x, v, w, p of set 0 (null: four allocations)
+  double *slab[2] = {nullptr, nullptr};  // tiled storage of set 0 (+ p) and of the RK ping-pong set (kernels.hpp)
   double *rho = nullptr;  // slice of rho_sp
   SpeciesConst sc{};
 };
@@ -98,6 +98,7 @@ struct pic1dp_ctx {
   double *d_rho_sp = nullptr, *d_charge = nullptr, *d_chargeden = nullptr, *d_E = nullptr;
   double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
   double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
+  double *d_stage = nullptr;  // contiguous staging buffer between host arrays and the tiled marker arrays
   double *d_Eh = nullptr;  // field after the first sub-step of the last whole-step call
   // The reference's three call sites at whole-step cost (see "lazy call sites"
   // below): a push is only noted; the collect_charge that follows runs the
@@ -385,22 +386,16 @@ PushArgs make_push_args(pic1dp_ctx *c, int isp, int irk, const double *E) {
   return a;
 }
 
-// second particle set of the RK ping-pong (sub-step kernels only)
+// second particle set of the RK ping-pong (sub-step kernels only): a slab of the same
+// geometry as the first (its p tiles stay unused)
 int ensure_second_set(pic1dp_ctx *c) {
   for (Species &S : c->sp) {
-    if (S.set[1].x) continue;
-    const size_t bytes = sizeof(double) * static_cast<size_t>(S.nalloc + 2);
-    HIP_TRY(hipMalloc(&S.set[1].x, bytes));
-    if (c->in.linear == 1) {
-      S.set[1].v = S.set[0].v;  // v is never pushed in a linear run
-    } else {
-      HIP_TRY(hipMalloc(&S.set[1].v, bytes));
-    }
-    if (c->in.deltaf == 0) {
-      S.set[1].w = S.set[0].w;  // w is not evolved in a full-f run
-    } else {
-      HIP_TRY(hipMalloc(&S.set[1].w, bytes));
-    }
+    if (S.slab[1]) continue;
+    HIP_TRY(hipMalloc(&S.slab[1], sizeof(double) * static_cast<size_t>(slab_doubles(S.nalloc + 2))));
+    const int64_t as = slab_array_stride(S.nalloc + 2);
+    S.set[1].x = S.slab[1];
+    S.set[1].v = c->in.linear == 1 ? S.set[0].v : S.slab[1] + as;      // v is never pushed in a linear run
+    S.set[1].w = c->in.deltaf == 0 ? S.set[0].w : S.slab[1] + 2 * as;  // w is not evolved in a full-f run
   }
   return 0;
 }
@@ -587,109 +582,6 @@ static bool step_recompute_ok(const pic1dp_ctx *c);
 static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh);
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full);
 
-// Where hipMalloc happens to put the four marker arrays of a species relative to
-// one another moves the whole-step kernels by several percent (HBM channel / bank
-// phase: 1.04-1.16 ms for k_step_full at 1e8 markers between placements, stable
-// for the life of the allocation).  For marker sets beyond 1 GiB a few placements
-// are tried at create time -- synthetic markers, the two real kernels timed on
-// each -- and the fastest is kept.  PIC1DP_PLACEMENT_TRIES (default 4, 1 = off).
-static int place_markers(pic1dp_ctx *c) {
-  int tries = 4;
-  if (const char *e = std::getenv("PIC1DP_PLACEMENT_TRIES")) tries = std::atoi(e);
-  if (tries < 2 || !step_recompute_ok(c)) return 0;
-  const bool verbose = std::getenv("PIC1DP_PLACEMENT_VERBOSE") != nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  const bool stats = c->stats_on, timers = c->timers_on;
-  c->stats_on = c->timers_on = false;
-  int rc = 0;
-  for (Species &S : c->sp) {
-    if (static_cast<double>(S.nalloc) * 32.0 < 1073741824.0 || S.slab) continue;
-    const size_t bytes = sizeof(double) * static_cast<size_t>(S.nalloc + 2);
-    struct Cand {
-      double *a[4];  // x, v, w, p
-      float ms;
-    };
-    std::vector<Cand> cand;
-    const int64_t np_keep = S.np;
-    // all species but this one sit out the timing runs
-    std::vector<int64_t> others;
-    for (Species &T : c->sp) {
-      others.push_back(T.np);
-      if (&T != &S) T.np = 0;
-    }
-    // steps timed on candidate k (nsteps whole steps of the two real kernels)
-    auto run = [&](Cand &k, int nsteps, float *ms) -> int {
-      S.set[0].x = k.a[0], S.set[0].v = k.a[1], S.set[0].w = k.a[2], S.p = k.a[3];
-      S.np = S.nalloc;
-      HIP_TRY(hipEventRecord(e0, c->st));
-      for (int r = 0; r < nsteps; ++r) {
-        if (int q = step_particles(c, false, c->d_E, c->d_Eh)) return q;
-        if (int q = step_particles(c, true, c->d_E, c->d_Eh)) return q;
-      }
-      HIP_TRY(hipEventRecord(e1, c->st));
-      HIP_TRY(hipEventSynchronize(e1));
-      HIP_TRY(hipEventElapsedTime(ms, e0, e1));
-      return 0;
-    };
-    cand.push_back(Cand{{S.set[0].x, S.set[0].v, S.set[0].w, S.p}, 0.f});
-    for (int t = 1; t < tries; ++t) {
-      Cand k{{nullptr, nullptr, nullptr, nullptr}, 0.f};
-      size_t free_b = 0, total_b = 0;
-      bool ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 8 * bytes + (static_cast<size_t>(4) << 30);
-      for (int i = 0; i < 4 && ok; ++i) ok = hipMalloc(&k.a[i], bytes) == hipSuccess;
-      if (!ok) {  // (nearly) out of memory: stay with what there is
-        (void)hipGetLastError();
-        for (double *q : k.a) (void)hipFree(q);
-        break;
-      }
-      cand.push_back(k);
-    }
-    for (Cand &k : cand) {
-      hipError_t e = launch_fill_markers(k.a[0], k.a[1], k.a[2], k.a[3], S.nalloc, c->in.lx, c->st);
-      if (e != hipSuccess) rc = fail(PIC1DP_ERR_HIP, "placement: %s", hipGetErrorString(e));
-    }
-    // the first steps after an idle period run slower: warm up, then take the
-    // candidates in turn, twice, so that what drift is left hits all alike
-    float ms = 0.f;
-    if (rc == 0) rc = run(cand[0], 30, &ms);
-    for (int round = 0; round < 2 && rc == 0; ++round)
-      for (Cand &k : cand) {
-        if ((rc = run(k, 3, &ms)) != 0) break;
-        k.ms += ms;
-      }
-    size_t best = 0;
-    for (size_t i = 1; i < cand.size(); ++i)
-      if (rc == 0 && cand[i].ms < cand[best].ms) best = i;
-    if (verbose) {
-      std::fprintf(stderr, "pic1dp placement (ms per step):");
-      for (size_t i = 0; i < cand.size(); ++i) std::fprintf(stderr, " %.3f%s", cand[i].ms / 6, i == best ? "*" : "");
-      std::fprintf(stderr, "\n");
-    }
-    for (size_t i = 0; i < cand.size(); ++i)
-      if (i != best)
-        for (double *q : cand[i].a) (void)hipFree(q);
-    S.set[0].x = cand[best].a[0], S.set[0].v = cand[best].a[1], S.set[0].w = cand[best].a[2], S.p = cand[best].a[3];
-    S.np = np_keep;
-    for (size_t i = 0; i < c->sp.size(); ++i)
-      if (&c->sp[i] != &S) c->sp[i].np = others[i];
-    if (rc) break;
-  }
-  // the timing runs deposited synthetic charge
-  if (rc == 0) {
-    hipError_t e = hipMemsetAsync(c->d_rho_sp, 0, sizeof(double) * c->in.nspecies * c->in.nx, c->st);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->st);
-    if (e != hipSuccess) rc = fail(PIC1DP_ERR_HIP, "placement: %s", hipGetErrorString(e));
-  }
-  c->stats_on = stats;
-  c->timers_on = timers;
-  c->state_version++;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  return rc;
-}
-
 int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1dp_ctx **out) {
   if (!in || !layout || !out) return fail(PIC1DP_ERR_ARG, "null argument");
   *out = nullptr;
@@ -768,32 +660,16 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     for (int b = 0; b < c->nblk; ++b) S.np += block_np(*in, s, c->blk0 + b, npe);
     S.sc = make_species_const(*in, s);
     S.rho = c->d_rho_sp + static_cast<size_t>(s) * nx;
-    const size_t bytes = sizeof(double) * static_cast<size_t>(nalloc + 2);
-    // four arrays per species up front (x, v, w, p: 32 B per marker, 9e9 markers
-    // in 288 GB); the second set of the RK ping-pong is allocated on the first
-    // sub-step call that needs it (ensure_second_set) -- pic1dp_hip_step never does
-    int layout = 0;  // 0: four allocations; 1: one slab, arrays PIC1DP_SLAB_STAGGER bytes out of step
-    if (const char *e = std::getenv("PIC1DP_MARKER_LAYOUT")) layout = std::atoi(e);
-    if (layout == 1) {
-      size_t stagger = 0;
-      if (const char *e = std::getenv("PIC1DP_SLAB_STAGGER")) stagger = static_cast<size_t>(std::atoll(e)) & ~static_cast<size_t>(255);
-      const size_t unit = static_cast<size_t>(2) << 20;
-      const size_t stride = (bytes + unit - 1) / unit * unit + stagger;
-      HIP_TRY_C(hipMalloc(&S.slab, 4 * stride));
-      char *b = reinterpret_cast<char *>(S.slab);
-      S.set[0].x = reinterpret_cast<double *>(b);
-      S.set[0].v = reinterpret_cast<double *>(b + stride);
-      S.set[0].w = reinterpret_cast<double *>(b + 2 * stride);
-      S.p = reinterpret_cast<double *>(b + 3 * stride);
-    } else {
-      HIP_TRY_C(hipMalloc(&S.p, bytes));
-      HIP_TRY_C(hipMalloc(&S.set[0].x, bytes));
-      HIP_TRY_C(hipMalloc(&S.set[0].v, bytes));
-      HIP_TRY_C(hipMalloc(&S.set[0].w, bytes));
-    }
-    if (std::getenv("PIC1DP_PLACEMENT_VERBOSE"))
-      std::fprintf(stderr, "pic1dp markers species %d: x %p v %p w %p p %p (%zu bytes each)\n", s,
-                   (void *)S.set[0].x, (void *)S.set[0].v, (void *)S.set[0].w, (void *)S.p, bytes);
+    // x, v, w, p of a species interleaved in tiles in ONE slab (kernels.hpp: 32 B per
+    // marker, 9e9 markers in 288 GB); the slab of the RK ping-pong set is allocated on
+    // the first sub-step call that needs it (ensure_second_set) -- pic1dp_hip_step
+    // never does
+    HIP_TRY_C(hipMalloc(&S.slab[0], sizeof(double) * static_cast<size_t>(slab_doubles(nalloc + 2))));
+    const int64_t as = slab_array_stride(nalloc + 2);
+    S.set[0].x = S.slab[0];
+    S.set[0].v = S.slab[0] + as;
+    S.set[0].w = S.slab[0] + 2 * as;
+    S.p = S.slab[0] + 3 * as;
   }
 
   // field storage and the operators of field_init (src/pic1dp_field.F90:158-210),
@@ -866,10 +742,6 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   }
   HIP_TRY_C(hipStreamSynchronize(c->st));
 #undef HIP_TRY_C
-  if (place_markers(c) != 0) {
-    pic1dp_hip_destroy(c);
-    return PIC1DP_ERR_HIP;
-  }
   *out = c;
   return 0;
 }
@@ -887,20 +759,11 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
   if (c->xc.local) (void)hipFree(c->xc.local);
   if (c->xc.err) (void)hipHostFree(c->xc.err);
   for (auto &S : c->sp) {
-    if (S.slab) {
-      (void)hipFree(S.slab);
-    } else {
-      (void)hipFree(S.p);
-      (void)hipFree(S.set[0].x);
-      (void)hipFree(S.set[0].v);
-      (void)hipFree(S.set[0].w);
-    }
-    (void)hipFree(S.set[1].x);
-    if (S.set[1].v != S.set[0].v) (void)hipFree(S.set[1].v);
-    if (S.set[1].w != S.set[0].w) (void)hipFree(S.set[1].w);
+    (void)hipFree(S.slab[0]);
+    (void)hipFree(S.slab[1]);
   }
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
-                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy};
+                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage};
   for (double *b : bufs) (void)hipFree(b);
   for (double *b : c->probe_keep) (void)hipFree(b);
   for (auto &e : c->evpool) {
@@ -909,6 +772,42 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
   }
   if (c->st) (void)hipStreamDestroy(c->st);
   delete c;
+  return 0;
+}
+
+// Host arrays are contiguous, marker arrays tiled (kernels.hpp): every transfer goes
+// through a contiguous device staging buffer and a scatter / gather kernel, in chunks.
+constexpr int64_t kStageDoubles = static_cast<int64_t>(8) << 20;  // 64 MiB
+
+static int ensure_stage(pic1dp_ctx *c) {
+  if (!c->d_stage) HIP_TRY(hipMalloc(&c->d_stage, sizeof(double) * kStageDoubles));
+  return 0;
+}
+
+// host[0, cnt) -> markers [off, off + cnt) of the array starting at arr; returns
+// with the host buffer free for reuse
+static int put_range(pic1dp_ctx *c, double *arr, int64_t off, const double *host, int64_t cnt) {
+  if (cnt <= 0) return 0;
+  if (int rc = ensure_stage(c)) return rc;
+  for (int64_t done = 0; done < cnt; done += kStageDoubles) {
+    const int64_t n = std::min(kStageDoubles, cnt - done);
+    HIP_TRY(hipMemcpyAsync(c->d_stage, host + done, sizeof(double) * n, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(launch_tile_scatter(arr, off + done, c->d_stage, n, c->st));
+  }
+  HIP_TRY(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+// markers [off, off + cnt) of the array starting at arr -> host[0, cnt)
+static int get_range(pic1dp_ctx *c, const double *arr, int64_t off, double *host, int64_t cnt) {
+  if (cnt <= 0) return 0;
+  if (int rc = ensure_stage(c)) return rc;
+  for (int64_t done = 0; done < cnt; done += kStageDoubles) {
+    const int64_t n = std::min(kStageDoubles, cnt - done);
+    HIP_TRY(launch_tile_gather(arr, off + done, c->d_stage, n, c->st));
+    HIP_TRY(hipMemcpyAsync(host + done, c->d_stage, sizeof(double) * n, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+  }
   return 0;
 }
 
@@ -925,6 +824,7 @@ static int materialize(pic1dp_ctx *c);  // lazy call sites, see below
 int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));  // kernels of an earlier run may still be writing the arrays
   c->lz = LZ_CLEAN;  // a noted push of markers that are about to be replaced is void
   c->state_version++;
   const pic1dp_input &in = c->in;
@@ -965,13 +865,8 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
         const double *h;
       } arr[4] = {{S.set[0].x, hx}, {S.set[0].v, hv}, {S.p, hp}, {S.set[0].w, hw}};
       for (auto &a : arr) {
-        hipError_t e = hipMemcpy(a.d + voff[s], a.h, sizeof(double) * np, hipMemcpyHostToDevice);
-        if (e == hipSuccess && nt > 0)
-          e = hipMemcpy(a.d + toff[s], a.h + np, sizeof(double) * nt, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-          rc = fail(PIC1DP_ERR_HIP, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
-          break;
-        }
+        if ((rc = put_range(c, a.d, voff[s], a.h, np)) != 0) break;
+        if ((rc = put_range(c, a.d, toff[s], a.h + np, nt)) != 0) break;
       }
       voff[s] += np;
       toff[s] += nt;
@@ -1006,19 +901,18 @@ int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, con
   if (c->cur != 0) {
     for (Species &T : c->sp) {
       if (&T == &S) continue;
-      HIP_TRY(hipMemcpy(T.set[0].x, T.set[1].x, sizeof(double) * T.np, hipMemcpyDeviceToDevice));
-      if (T.set[1].v != T.set[0].v)
-        HIP_TRY(hipMemcpy(T.set[0].v, T.set[1].v, sizeof(double) * T.np, hipMemcpyDeviceToDevice));
-      if (T.set[1].w != T.set[0].w)
-        HIP_TRY(hipMemcpy(T.set[0].w, T.set[1].w, sizeof(double) * T.np, hipMemcpyDeviceToDevice));
+      HIP_TRY(launch_tile_copy(T.set[0].x, T.set[1].x, T.np, c->st));
+      if (T.set[1].v != T.set[0].v) HIP_TRY(launch_tile_copy(T.set[0].v, T.set[1].v, T.np, c->st));
+      if (T.set[1].w != T.set[0].w) HIP_TRY(launch_tile_copy(T.set[0].w, T.set[1].w, T.np, c->st));
     }
+    HIP_TRY(hipStreamSynchronize(c->st));
     c->cur = 0;
   }
   PSet &A = S.set[0];
-  HIP_TRY(hipMemcpy(A.x, x, sizeof(double) * n, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(A.v, v, sizeof(double) * n, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(A.w, w, sizeof(double) * n, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(S.p, p, sizeof(double) * n, hipMemcpyHostToDevice));
+  if (int rc = put_range(c, A.x, 0, x, n)) return rc;
+  if (int rc = put_range(c, A.v, 0, v, n)) return rc;
+  if (int rc = put_range(c, A.w, 0, w, n)) return rc;
+  if (int rc = put_range(c, S.p, 0, p, n)) return rc;
   S.np = np;
   if (c->nblk == 1) c->blk_np[isp][0] = np;
   c->rng_ready = false;  // the host's loader owns the random stream now
@@ -1038,17 +932,15 @@ int pic1dp_hip_particles_download(pic1dp_ctx *c, int32_t isp, double *x, double 
   const PSet &A = S.set[c->cur];
   const int64_t np = S.np;
   // slots beyond np are only defined in the set they were uploaded to (set 0)
-  auto pull = [&](double *h, const double *cur, const double *first) -> hipError_t {
-    if (!h) return hipSuccess;
-    hipError_t e = hipMemcpy(h, cur, sizeof(double) * np, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && n > np)
-      e = hipMemcpy(h + np, first + np, sizeof(double) * (n - np), hipMemcpyDeviceToHost);
-    return e;
+  auto pull = [&](double *h, const double *cur, const double *first) -> int {
+    if (!h) return 0;
+    if (int rc = get_range(c, cur, 0, h, np)) return rc;
+    return get_range(c, first, np, h + np, n - np);
   };
-  HIP_TRY(pull(x, A.x, S.set[0].x));
-  HIP_TRY(pull(v, A.v, S.set[0].v));
-  HIP_TRY(pull(w, A.w, S.set[0].w));
-  HIP_TRY(pull(p, S.p, S.p));
+  if (int rc = pull(x, A.x, S.set[0].x)) return rc;
+  if (int rc = pull(v, A.v, S.set[0].v)) return rc;
+  if (int rc = pull(w, A.w, S.set[0].w)) return rc;
+  if (int rc = pull(p, S.p, S.p)) return rc;
   return 0;
 }
 
@@ -1060,13 +952,16 @@ int pic1dp_hip_particles_download_bak(pic1dp_ctx *c, int32_t isp, double *xb, do
   if (n != S.nalloc) return fail(PIC1DP_ERR_ARG, "n does not match the owned slots");
   HIP_TRY(hipSetDevice(c->device));
   if (int rc = materialize(c)) return rc;
-  if (!S.set[1].x) return fail(PIC1DP_ERR_STATE, "no RK backup exists before the first push / substep call");
+  if (!S.slab[1]) return fail(PIC1DP_ERR_STATE, "no RK backup exists before the first push / substep call");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->st));
   const PSet &B = S.set[1 - c->cur];
-  if (xb) HIP_TRY(hipMemcpy(xb, B.x, sizeof(double) * S.np, hipMemcpyDeviceToHost));
-  if (vb) HIP_TRY(hipMemcpy(vb, B.v, sizeof(double) * S.np, hipMemcpyDeviceToHost));
-  if (wb) HIP_TRY(hipMemcpy(wb, B.w, sizeof(double) * S.np, hipMemcpyDeviceToHost));
+  if (xb)
+    if (int rc = get_range(c, B.x, 0, xb, S.np)) return rc;
+  if (vb)
+    if (int rc = get_range(c, B.v, 0, vb, S.np)) return rc;
+  if (wb)
+    if (int rc = get_range(c, B.w, 0, wb, S.np)) return rc;
   return 0;
 }
 
@@ -1276,9 +1171,8 @@ int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optim
       const int64_t na = c->blk_alloc[b], np = c->blk_np[s][b];
       for (int k = 0; k < 4; ++k) {
         host[s][b].a[k].resize(static_cast<size_t>(na));
-        HIP_TRY(hipMemcpy(host[s][b].a[k].data(), dev[k] + voff, sizeof(double) * np, hipMemcpyDeviceToHost));
-        if (na > np)
-          HIP_TRY(hipMemcpy(host[s][b].a[k].data() + np, dev[k] + toff, sizeof(double) * (na - np), hipMemcpyDeviceToHost));
+        if (int rc = get_range(c, dev[k], voff, host[s][b].a[k].data(), np)) return rc;
+        if (int rc = get_range(c, dev[k], toff, host[s][b].a[k].data() + np, na - np)) return rc;
       }
       voff += np;
       toff += na - np;
@@ -1336,9 +1230,8 @@ int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optim
     for (int b = 0; b < nb; ++b) {
       const int64_t na = c->blk_alloc[b], np = c->blk_np[s][b];
       for (int k = 0; k < 4; ++k) {
-        HIP_TRY(hipMemcpy(dev[k] + voff, host[s][b].a[k].data(), sizeof(double) * np, hipMemcpyHostToDevice));
-        if (na > np)
-          HIP_TRY(hipMemcpy(dev[k] + toff, host[s][b].a[k].data() + np, sizeof(double) * (na - np), hipMemcpyHostToDevice));
+        if (int rc = put_range(c, dev[k], voff, host[s][b].a[k].data(), np)) return rc;
+        if (int rc = put_range(c, dev[k], toff, host[s][b].a[k].data() + np, na - np)) return rc;
       }
       voff += np;
       toff += na - np;
@@ -1660,8 +1553,8 @@ static int ensure_diag(pic1dp_ctx *c, int isp) {
   const int64_t ntail = S.nalloc - S.np;
   if (ntail > 0) {
     const int blocks = static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256));
-    HIP_TRY(launch_energy_sums(S.set[0].v + S.np, S.p + S.np, in.deltaf ? S.set[0].w + S.np : nullptr, ntail,
-                               c->d_scratch, blocks, c->st));
+    HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, ntail, c->d_scratch, blocks,
+                               c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     HIP_TRY(hipMemcpy(part.data(), c->d_scratch, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
     for (int b = 0; b < blocks; ++b)

@@ -283,15 +283,16 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
 
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair;
        j += stride) {
-    const double2 X = ld2(sx2 + j), V = ld2(sv2 + j);
+    const int64_t o = tidx2(j);
+    const double2 X = ld2(sx2 + o), V = ld2(sv2 + o);
     double2 W = make_double2(0.0, 0.0), P = make_double2(0.0, 0.0);
-    if constexpr (HAS_W) W = ld2(sw2 + j);
-    if constexpr (MODE != MODE_FULLF || FUSED) P = ld2(p2 + j);
+    if constexpr (HAS_W) W = ld2(sw2 + o);
+    if constexpr (MODE != MODE_FULLF || FUSED) P = ld2(p2 + o);
     double2 XB = X, VB = V, WB = W;
     if constexpr (IRK2) {
-      XB = ld2(bx2 + j);
-      if constexpr (PUSH_V) VB = ld2(bv2 + j);
-      if constexpr (HAS_W) WB = ld2(bw2 + j);
+      XB = ld2(bx2 + o);
+      if constexpr (PUSH_V) VB = ld2(bv2 + o);
+      if constexpr (HAS_W) WB = ld2(bw2 + o);
     }
     One o0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, XB.x, VB.x, WB.x, sE, a.dt, a.g, a.s);
     One o1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, XB.y, VB.y, WB.y, sE, a.dt, a.g, a.s);
@@ -299,13 +300,13 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
       o0.x = deposit_one(o0.x, HAS_W ? o0.w : P.x, sR, a.g);
       o1.x = deposit_one(o1.x, HAS_W ? o1.w : P.y, sR, a.g);
     }
-    st2(dx2 + j, o0.x, o1.x);
-    if constexpr (PUSH_V) st2(dv2 + j, o0.v, o1.v);
-    if constexpr (HAS_W) st2(dw2 + j, o0.w, o1.w);
+    st2(dx2 + o, o0.x, o1.x);
+    if constexpr (PUSH_V) st2(dv2 + o, o0.v, o1.v);
+    if constexpr (HAS_W) st2(dw2 + o, o0.w, o1.w);
   }
   // odd tail marker
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = a.np - 1;
+    const int64_t i = tidx(a.np - 1);
     const double x = a.src.x[i], v = a.src.v[i];
     const double w = HAS_W ? a.src.w[i] : 0.0;
     const double p = a.p[i];
@@ -377,16 +378,17 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   const double2 *w2 = reinterpret_cast<const double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
-    const double2 X = ld2t<NT>(x2 + j), V = ld2t<NT>(v2 + j), P = ld2t<NT>(p2 + j);
+    const int64_t o = tidx2(j);
+    const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0);
-    if constexpr (HAS_W) W = ld2t<NT>(w2 + j);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
     const One h0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, X.x, V.x, W.x, sE, a.dt_half, a.g, a.s);
     const One h1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, X.y, V.y, W.y, sE, a.dt_half, a.g, a.s);
     deposit_one(h0.x, HAS_W ? h0.w : P.x, sR, a.g);
     deposit_one(h1.x, HAS_W ? h1.w : P.y, sR, a.g);
   }
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = a.np - 1;
+    const int64_t i = tidx(a.np - 1);
     const double x = a.x[i], v = a.v[i], p = a.p[i];
     const double w = HAS_W ? a.w[i] : 0.0;
     const One h = push_one<DIST, MODE, POW2>(x, v, w, p, x, v, w, sE, a.dt_half, a.g, a.s);
@@ -437,17 +439,18 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
-    const double2 X = ld2t<NT>(x2 + j), V = ld2t<NT>(v2 + j), P = ld2t<NT>(p2 + j);
+    const int64_t o = tidx2(j);
+    const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0);
-    if constexpr (HAS_W) W = ld2t<NT>(w2 + j);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
     const One n0 = step_full_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a);
     const One n1 = step_full_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a);
-    st2t<NT>(x2 + j, n0.x, n1.x);
-    if constexpr (PUSH_V) st2t<NT>(v2 + j, n0.v, n1.v);
-    if constexpr (HAS_W) st2t<NT>(w2 + j, n0.w, n1.w);
+    st2t<NT>(x2 + o, n0.x, n1.x);
+    if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
+    if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
   }
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = a.np - 1;
+    const int64_t i = tidx(a.np - 1);
     const double w = HAS_W ? a.w[i] : 0.0;
     const One n = step_full_one<DIST, MODE, POW2>(a.x[i], a.v[i], w, a.p[i], sE0, sEh, sR, a);
     a.x[i] = n.x;
@@ -508,14 +511,17 @@ k_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst g
   const double2 *q2 = reinterpret_cast<const double2 *>(q);
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair;
        j += stride) {
-    double2 X = ld2(x2 + j);
-    const double2 Q = ld2(q2 + j);
+    const int64_t o = tidx2(j);
+    double2 X = ld2(x2 + o);
+    const double2 Q = ld2(q2 + o);
     X.x = deposit_one(X.x, Q.x, sR, g);
     X.y = deposit_one(X.y, Q.y, sR, g);
-    st2(x2 + j, X.x, X.y);
+    st2(x2 + o, X.x, X.y);
   }
-  if ((np & 1) && blockIdx.x == 0 && threadIdx.x == 0)
-    x[np - 1] = deposit_one(x[np - 1], q[np - 1], sR, g);
+  if ((np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = tidx(np - 1);
+    x[i] = deposit_one(x[i], q[i], sR, g);
+  }
   __syncthreads();
   flush_rho(sR, rho, g.nx);
 }
@@ -897,9 +903,11 @@ __device__ __forceinline__ void exchange_charge(const FieldArgs &f, const XchgAr
     __hip_atomic_store(x.flags[q] + par * XCHG_MAX_RANKS + x.rank, x.epoch, __ATOMIC_RELEASE, PIC1DP_SYS);
     const unsigned long long *fl = x.flags[x.rank] + par * XCHG_MAX_RANKS + q;
     const long long t0 = wall_clock64();
+    // a run that already timed out once does not wait again: its remaining launches drain at once
+    const long long limit = __hip_atomic_load(x.err, __ATOMIC_RELAXED, PIC1DP_SYS) ? 0 : x.timeout_ticks;
     while (__hip_atomic_load(fl, __ATOMIC_RELAXED, PIC1DP_SYS) < x.epoch) {
       __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > x.timeout_ticks) {  // give up: report, never hang
+      if (wall_clock64() - t0 > limit) {  // give up: report, never hang
         __hip_atomic_store(x.err, (x.epoch << 8) | static_cast<unsigned long long>(q + 1), __ATOMIC_RELAXED, PIC1DP_SYS);
         break;
       }
@@ -1186,11 +1194,12 @@ namespace {
 // sum v^2, v^2 p, v^2 w (src/pic1dp_output.F90:126-151): per-workgroup partials,
 // the host adds them in workgroup order
 __global__ void __launch_bounds__(256)
-k_energy_sums(const double *v, const double *p, const double *w, int64_t n, double *partial) {
+k_energy_sums(const double *v, const double *p, const double *w, int64_t i0, int64_t n, double *partial) {
   __shared__ double scr[16];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const int64_t i = tidx(i0 + k);
     const double v2 = v[i] * v[i];
     s0 += v2;
     s1 += v2 * p[i];
@@ -1213,7 +1222,7 @@ k_cell_indices(const double *x, int64_t np, const GridConst g, int32_t *ixo,
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < np; i += stride) {
     int ix;
     double wl;
-    locate(x[i], g, ix, wl);
+    locate(x[tidx(i)], g, ix, wl);
     if (ixo) ixo[i] = ix;
     if (count) atomicAdd(&count[ix], 1ULL);
   }
@@ -1268,7 +1277,8 @@ k_ptcldist(const double *x, const double *v, const double *p, const double *w, i
   const double dnxo = static_cast<double>(nxo), dnv1 = static_cast<double>(nvo - 1);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < np; i += stride) {
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < np; k += stride) {
+    const int64_t i = tidx(k);
     const double pv = v[i];
     const double pp = p[i];
     const double pw = DELTAF ? w[i] : 0.0;
@@ -1633,35 +1643,51 @@ int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n) {
   return bad;
 }
 
-hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t n,
+hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t i0, int64_t n,
                               double *partial, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL(k_energy_sums, dim3(blocks), dim3(256), 0, st, v, p, w, n, partial);
+  hipLaunchKernelGGL(k_energy_sums, dim3(blocks), dim3(256), 0, st, v, p, w, i0, n, partial);
   return hipGetLastError();
 }
 
 namespace {
 
-// harmless synthetic markers for timing runs on not yet loaded arrays: x spread
-// over [0, lx), |v| < 4, tiny weights
-__global__ void __launch_bounds__(256)
-k_fill_markers(double *x, double *v, double *w, double *p, int64_t n, double lx) {
+// host arrays are contiguous, marker arrays tiled: the two meet in these kernels
+__global__ void __launch_bounds__(256) k_tile_scatter(double *arr, int64_t i0, const double *src, int64_t n) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-    uint64_t z = 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(i + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27;
-    const double u1 = static_cast<double>(z >> 11) * 0x1p-53, u2 = static_cast<double>((z * 0x94D049BB133111EBull) >> 11) * 0x1p-53;
-    x[i] = lx * u1;
-    v[i] = 8.0 * u2 - 4.0;
-    w[i] = 1e-5 * (u1 - 0.5);
-    p[i] = 1e-6;
-  }
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride)
+    arr[tidx(i0 + k)] = src[k];
+}
+__global__ void __launch_bounds__(256) k_tile_gather(const double *arr, int64_t i0, double *dst, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride)
+    dst[k] = arr[tidx(i0 + k)];
+}
+__global__ void __launch_bounds__(256) k_tile_copy(double *dst, const double *src, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride)
+    dst[tidx(k)] = src[tidx(k)];
+}
+
+int copy_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return static_cast<int>(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
 }  // namespace
 
-hipError_t launch_fill_markers(double *x, double *v, double *w, double *p, int64_t n, double lx, hipStream_t st) {
-  hipLaunchKernelGGL(k_fill_markers, dim3(2048), dim3(256), 0, st, x, v, w, p, n, lx);
+hipError_t launch_tile_scatter(double *arr, int64_t i0, const double *src, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tile_scatter, dim3(copy_blocks(n)), dim3(256), 0, st, arr, i0, src, n);
+  return hipGetLastError();
+}
+hipError_t launch_tile_gather(const double *arr, int64_t i0, double *dst, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tile_gather, dim3(copy_blocks(n)), dim3(256), 0, st, arr, i0, dst, n);
+  return hipGetLastError();
+}
+hipError_t launch_tile_copy(double *dst, const double *src, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tile_copy, dim3(copy_blocks(n)), dim3(256), 0, st, dst, src, n);
   return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace pic1dp {
 
@@ -30,7 +31,47 @@ struct GridConst {
   int fast_div;  // 1: x/lx by reciprocal + two FMA corrections (bit-identical), 0: hardware division
 };
 
-// One particle set = the three pushed arrays of a species.
+// Marker storage.  The four arrays of a species (x, v, w, p) are NOT four separate
+// allocations: they are interleaved in tiles of TILE markers,
+//     [ x tile | v tile | w tile | p tile ] [ x tile | v tile | ... ] ...
+// so that marker i of array k lives at slab[(i / TILE) * 4 * TILE + k * TILE + i % TILE].
+// Why: the second sub-step's kernel runs seven streams at once (x, v, w, p read; x, v,
+// w written back).  As four independent arrays their relative position in physical
+// memory -- which the allocator, not the program, decides -- moved that kernel between
+// 1.00 and 1.16 ms at 1e8 markers (DRAM bank/channel interference: tools/placement_probe.py
+// maps kernel time against the array-to-array distance), and a pure 4-read / 3-write
+// stream reached 5.0 TB/s.  Interleaved at 32 KiB the distances are fixed by the layout:
+// the same stream runs at 6.3 TB/s wherever the slab lands (tools/layout_probe.py;
+// 8 KiB: 5.3, 128 KiB: 5.3).  PIC1DP_TILE_LOG2=0 builds the untiled variant (arrays a
+// 2 MiB multiple apart in one slab) for A/B measurements.
+#ifndef PIC1DP_TILE_LOG2
+#define PIC1DP_TILE_LOG2 12
+#endif
+constexpr int TILE_LOG2 = PIC1DP_TILE_LOG2;
+constexpr int64_t TILE = static_cast<int64_t>(1) << TILE_LOG2;
+static_assert(TILE_LOG2 == 0 || TILE_LOG2 >= 7, "a wave's 64 pairs must not straddle a tile");
+// offset of marker i inside an array of a slab (arrays start k * TILE apart)
+__host__ __device__ constexpr int64_t tidx(int64_t i) {
+  return TILE_LOG2 ? (((i >> TILE_LOG2) << (TILE_LOG2 + 2)) + (i & (TILE - 1))) : i;
+}
+// the same for marker PAIRS, in double2 units
+__host__ __device__ constexpr int64_t tidx2(int64_t j) {
+  return TILE_LOG2 ? (((j >> (TILE_LOG2 - 1)) << (TILE_LOG2 + 1)) + (j & (TILE / 2 - 1))) : j;
+}
+// doubles of a slab holding n markers, and where array k (0 x, 1 v, 2 w, 3 p) starts
+inline int64_t slab_array_stride(int64_t n) {
+  if (TILE_LOG2) return TILE;
+  // untiled A/B build only: arrays a 2 MiB multiple (+ PIC1DP_SLAB_STAGGER bytes) apart
+  const int64_t unit = (2 << 20) / 8;
+  int64_t stagger = 0;
+  if (const char *e = std::getenv("PIC1DP_SLAB_STAGGER")) stagger = (std::atoll(e) & ~static_cast<long long>(255)) / 8;
+  return (n + unit - 1) / unit * unit + stagger;
+}
+inline int64_t slab_doubles(int64_t n) {
+  return TILE_LOG2 ? (n + TILE - 1) / TILE * 4 * TILE : 4 * slab_array_stride(n);
+}
+
+// One particle set = the three pushed arrays of a species (array bases inside a slab).
 struct PSet {
   double *x, *v, *w;
 };
@@ -125,9 +166,14 @@ hipError_t launch_field_fd(const double *chargeden, double *E, double *history, 
 hipError_t launch_field_energy(const double *E, int nx, double lx, double dnx, double *out,
                                hipStream_t st);
 
-// per-block partial sums of v^2, v^2 p, v^2 w -> partial[blocks][3]
-hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t n,
+// per-block partial sums of v^2, v^2 p, v^2 w over markers [i0, i0 + n) -> partial[blocks][3]
+hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t i0, int64_t n,
                               double *partial, int blocks, hipStream_t st);
+// contiguous buffer <-> markers [i0, i0 + n) of one array of a slab
+hipError_t launch_tile_scatter(double *arr, int64_t i0, const double *src, int64_t n, hipStream_t st);
+hipError_t launch_tile_gather(const double *arr, int64_t i0, double *dst, int64_t n, hipStream_t st);
+// markers [0, n) of one array copied between two slabs of the same geometry
+hipError_t launch_tile_copy(double *dst, const double *src, int64_t n, hipStream_t st);
 // raw (x,v) and v histograms of output_ptcldist into out =
 // [markr_xv | total_xv | pertb_xv | markr_v | total_v | pertb_v] (accumulated)
 // In the same pass: partial[blocks][3] = per-workgroup sums of v^2, v^2 p, v^2 w
@@ -153,8 +199,6 @@ int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n);
 // generated dividends, on the device and with the host's fma
 hipError_t launch_divc_check(double c, uint64_t seed, int64_t n, unsigned long long *bad, hipStream_t st);
 int64_t host_divc_check(double c, uint64_t seed, int64_t n);
-// synthetic markers (timing runs on arrays that hold nothing yet)
-hipError_t launch_fill_markers(double *x, double *v, double *w, double *p, int64_t n, double lx, hipStream_t st);
 // cell index per marker and per-cell counts from (wrapped) x
 hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
                                unsigned long long *count, hipStream_t st);

@@ -1,14 +1,15 @@
-"""bench.py end to end on the GPU box: the default contract line on one rank and a
-rehearsal of the multi-rank control flow -- two ranks launched by
-torch.distributed.run sharing the one GPU, charge summed through the host-staged
-path (RCCL needs one GPU per rank) -- whose physics must equal a one-process
-run holding the same two reference rank blocks as virtual ranks."""
+"""bench.py end to end on the GPU box: the default contract line on one rank, and
+rehearsals of the multi-rank control flow -- two ranks launched by
+torch.distributed.run sharing the one GPU (RCCL needs one GPU per rank, so the charge
+is summed by the library's one-hop exchange through IPC-mapped memory, or host-staged
+through gloo) -- for the configurations c3, c4 and c5 of BASELINE.json, whose physics
+must equal a one-process run holding the same reference rank blocks as virtual ranks."""
+import importlib.util
 import json
 import os
 import subprocess
 import sys
 
-import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -16,13 +17,20 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def run_bench(args, nproc=1, timeout=600):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def bench_module():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def run_bench(args, nproc=1, timeout=900, port=29533):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PIC1DP_XCHG_TIMEOUT_MS="60000")
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-               "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py")] + args
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -31,28 +39,64 @@ def run_bench(args, nproc=1, timeout=600):
 
 
 def test_bench_contract_line_small():
-    d = run_bench(["--particles", "2000000", "--nx", "256", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    n = 2_000_000
+    d = run_bench(["--particles", str(n), "--strong-total", str(n), "--nx", "256", "--steps", "5", "--warmup", "2",
+                   "--no-cpu-baseline"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "attribution", "strong_1e8_total"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["dtype"] == "f64"
+    assert d["warmup_effective"] == d["warmup"] + d["settle_steps_before_warmup"]
     assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert abs(d["value"] - 2_000_000 * 2 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - n * 2 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the fraction is priced at the bytes the kernel moves (56 B per marker), not at the 80-B reference price
+    assert r["bytes_per_marker"] == 56.0
+    assert abs(r["achieved"] - 56.0 * n / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert abs(r["reference_priced_GBs"] / r["achieved"] - 80.0 / 56.0) < 1e-9
+    assert r["whole_step_bytes"] == 88.0 * n
+    assert d["strong_1e8_total"]["same_run_as_headline"] is True
     assert d["drop_in_call_sites"]["value"] > 0
+    assert d["attribution"]["particle_kernels_ms_per_step"] > 0 and d["attribution"]["field_solve_ms_per_step"] > 0
 
 
-def test_bench_two_ranks_share_the_gpu(amd):
-    n_per, nx, steps, warm = 1_500_000, 128, 6, 2
-    d = run_bench(["--gpus", "2", "--particles", str(n_per), "--nx", str(nx), "--steps", str(steps),
-                   "--warmup", str(warm), "--force-host-allreduce", "--no-cpu-baseline"], nproc=2)
-    assert d["n_gpus"] == 2 and d["config"]["particles_total"] == 2 * n_per
-    assert d["config"]["allreduce"].startswith("host-staged")
-    # the same global problem in one process: two reference rank blocks as virtual ranks
-    eng = amd.Pic1dp(amd.make_input(nparticle_max=2 * n_per, nx=nx), npe=2)
+def virtual_rank_energy(amd, kw, npe, nsteps):
+    eng = amd.Pic1dp(amd.make_input(**kw), npe=npe)
     eng.particle_load()
     eng.interaction_collect_charge()
     eng.field_solve_electric()
-    eng.step(d["settle_steps_before_warmup"] + warm + steps)
-    assert abs(d["field_energy_end"] / eng.field_energy() - 1.0) < 1e-10
+    eng.step(nsteps)
+    return eng.field_energy()
+
+
+@pytest.mark.parametrize("config,particles,allreduce", [
+    ("c3", 1_500_000, "p2p"), ("c4", 3_000_000, "p2p"), ("c5", 1_500_000, "p2p"), ("c3", 1_000_000, "host")])
+def test_bench_two_ranks_share_the_gpu(amd, config, particles, allreduce):
+    """the weak headline and the strong object, both present, both with the physics of the
+    virtual-rank run (src/pic1dp_interaction.F90:126-150; `make run` uses 4 ranks, Makefile:39)"""
+    b = bench_module()
+    cfg = b.CONFIGS[config]
+    phys = dict(cfg["inp"])
+    nx_small = {"c3": 128, "c4": 128, "c5": 256}[config]
+    phys["nx"] = nx_small
+    steps, warm, strong_total = 6, 2, 2_000_000
+    d = run_bench(["--gpus", "2", "--config", config, "--particles", str(particles), "--nx", str(nx_small),
+                   "--steps", str(steps), "--warmup", str(warm), "--strong-total", str(strong_total),
+                   "--allreduce", allreduce, "--no-cpu-baseline"], nproc=2)
+    strong_cfg = "total" in cfg
+    total = particles if strong_cfg else 2 * particles
+    assert d["n_gpus"] == 2 and d["config"]["particles_total"] == total
+    assert d["scaling"] == ("strong" if strong_cfg else "weak")
+    assert d["config"]["allreduce"].startswith("one-hop" if allreduce == "p2p" else "host-staged")
+    assert "allreduce_ms_per_step" in d["attribution"] and "field_solve_ms_per_step" in d["attribution"]
+    nsteps = d["warmup_effective"] + steps
+    e = virtual_rank_energy(amd, dict(nparticle_max=total, **phys), 2, nsteps)
+    assert abs(d["field_energy_end"] / e - 1.0) < 1e-10
+    if strong_cfg:
+        assert "strong_1e8_total" not in d           # the headline is the strong run itself
+    else:
+        s = d["strong_1e8_total"]
+        assert s["particles_total"] == strong_total and s["same_run_as_headline"] is False and s["value"] > 0
+        e = virtual_rank_energy(amd, dict(nparticle_max=strong_total, **phys), 2, nsteps)
+        assert abs(s["field_energy_end"] / e - 1.0) < 1e-10

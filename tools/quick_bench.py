@@ -25,7 +25,7 @@ eng.interaction_collect_charge()
 eng.field_solve_electric()
 for mode in (0, 1):
     eng.set_step_mode(mode)
-    eng.step(3)
+    eng.step(int(os.environ.get("PIC1DP_QB_WARMUP", "3")))
     eng.sync()
     eng.kernel_stats_enable(True)
     eng.timers_reset()
