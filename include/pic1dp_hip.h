@@ -357,13 +357,19 @@ int pic1dp_hip_debug_divc_check(pic1dp_ctx *ctx, int32_t ispecies, int64_t n,
 int pic1dp_hip_stream_probe(pic1dp_ctx *ctx, int32_t nread, int32_t nwrite, int64_t n,
                             int32_t reps, double *gbytes_per_s);
 
-/* tuning only (tools/layout_probe.py): the traffic shape of the second sub-step's
- * kernel (4 arrays of n doubles read, 3 written back in place) timed over a fresh
- * slab with the arrays apart (ms[0]) and interleaved in tiles of 2^log2_tile markers
- * (ms[1]); keep != 0 leaves the slab allocated until destroy */
+/* y[i] = exp(x[i]), i < n, evaluated on the device by the function the push
+ * kernels call for the weight equation (src/pic1dp_interaction.F90:278-321): lets a
+ * test bound it against the host's libm (host arrays in and out) */
+int pic1dp_hip_debug_exp(pic1dp_ctx *ctx, const double *x, double *y, int64_t n);
+/* tuning only (tools/layout_probe.py): the traffic shapes of the two whole-step kernels
+ * (4 arrays of n doubles read; 3 of them written back in place, or nothing written) timed
+ * over a fresh slab: ms[0] arrays apart, read+write; ms[1] interleaved in tiles of
+ * 2^log2_tile markers, read+write; ms[2], ms[3] the same two read-only; ms[4], ms[5] tiled
+ * with one workgroup walking whole tiles, read+write and read-only.  keep != 0 leaves the
+ * slab allocated until destroy (the next call then lands in other physical memory) */
 int pic1dp_hip_debug_layout_probe(pic1dp_ctx *ctx, int64_t n, int32_t log2_tile,
                                   int64_t stagger_bytes, int32_t reps, int32_t keep,
-                                  double ms[2]);
+                                  double ms[6]);
 
 /* ---- split-phase deposit for a host that owns the reduction (MPI) ------
  * charge_local: everything of collect_charge up to the all-reduce

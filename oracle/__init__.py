@@ -152,6 +152,7 @@ def lib():
         "orc_deposit_species": (None, [IN, C.c_int64, _dp, _dp, _dp]),
         "orc_deposit_species_idx": (None, [IN, C.c_int64, _dp, _dp, _dp, _ip32, _ip64]),
         "orc_chargeden_from_charge": (None, [IN, _dp, _dp]),
+        "orc_exp_array": (None, [_dp, _dp, C.c_int64]),
         "orc_push_backup": (None, [C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int]),
         "orc_push_species": (None, [IN, C.c_int, C.c_int, _dp, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
         "orc_field_new": (P, [IN]),

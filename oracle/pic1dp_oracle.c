@@ -490,6 +490,13 @@ void orc_deposit_species(const orc_input *in, int64_t np, double *x,
   orc_deposit_species_idx(in, np, x, q, charge1, NULL, NULL);
 }
 
+/* libm exp() element by element: the transcendental of the weight equation
+ * (src/pic1dp_interaction.F90:278-321) as the reference's compiler links it; lets a
+ * test bound the device's exp against it */
+void orc_exp_array(const double *x, double *y, int64_t n) {
+  for (int64_t i = 0; i < n; i++) y[i] = exp(x[i]);
+}
+
 /* src/pic1dp_interaction.F90:138-148 */
 void orc_chargeden_from_charge(const orc_input *in, const double *charge1,
                                double *chargeden) {

@@ -125,6 +125,8 @@ void orc_deposit_species(const orc_input *in, int64_t np, double *x,
 void orc_deposit_species_idx(const orc_input *in, int64_t np, double *x,
                              const double *q, double *charge1, int32_t *ix_out,
                              int64_t *count);
+/* y[i] = exp(x[i]) with libm (the weight equation's transcendental) */
+void orc_exp_array(const double *x, double *y, int64_t n);
 /* :138-148: chargeden = charge1*nx/lx (- Z n0 for full-f) */
 void orc_chargeden_from_charge(const orc_input *in, const double *charge1,
                                double *chargeden);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "pic1dp_hip_host_divc_check": [C.c_double, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
     "pic1dp_hip_debug_divc_check": [_P, C.c_int32, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
     "pic1dp_hip_stream_probe": [_P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _D],
+    "pic1dp_hip_debug_exp": [_P, _P, _P, C.c_int64],
     "pic1dp_hip_debug_layout_probe": [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _D],
     "pic1dp_hip_create": [_INP, C.POINTER(Layout), C.POINTER(_P)],
     "pic1dp_hip_destroy": [_P],

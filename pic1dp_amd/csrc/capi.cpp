@@ -208,7 +208,8 @@ struct Span {
 LaunchCfg particle_launch(const pic1dp_ctx *c, int64_t np, bool with_E, bool with_rho) {
   const int nx = c->in.nx;
   LaunchCfg lc{};
-  lc.lds = sizeof(double) * ((with_E ? static_cast<size_t>((nx + 2) & ~1) : 0) + (with_rho ? nx : 0));
+  lc.lds = sizeof(double) * ((with_E ? static_cast<size_t>((nx + 2) & ~1) : 0) +
+                             (with_rho ? static_cast<size_t>(nx) * c->grid.rcopies : 0));
   const size_t lds_cap = 160 * 1024;
   int by_lds = lc.lds ? static_cast<int>(lds_cap / lc.lds) : 8;
   if (by_lds < 1) by_lds = 1;
@@ -581,6 +582,7 @@ int pic1dp_hip_host_div_check(double lx, int32_t nx, int64_t n, uint64_t seed, i
 static bool step_recompute_ok(const pic1dp_ctx *c);
 static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh);
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full);
+static size_t step_lds_bytes(int nx, bool full, int rcopies);
 
 int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1dp_ctx **out) {
   if (!in || !layout || !out) return fail(PIC1DP_ERR_ARG, "null argument");
@@ -642,6 +644,14 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   c->grid.rlx = 1.0 / in->lx;
   c->grid.fast_div = 1;
   if (const char *e = std::getenv("PIC1DP_FAST_DIV")) c->grid.fast_div = std::atoi(e) != 0;
+  // copies of the per-workgroup rho tile: as many (up to 8) as leave two workgroups per CU
+  // their LDS (E0, Eh and the copies within 80 KiB); PIC1DP_RHO_COPIES overrides
+  c->grid.rcopies = 1;
+  if (const char *e = std::getenv("PIC1DP_RHO_COPIES")) {
+    const int k = std::atoi(e);
+    if (k == 1 || k == 2 || k == 4 || k == 8) c->grid.rcopies = k;
+  }
+  while (c->grid.rcopies > 1 && step_lds_bytes(nx, true, c->grid.rcopies) > 80 * 1024) c->grid.rcopies >>= 1;
   if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_MB"))
     c->nt_threshold_half = c->nt_threshold_full = std::atof(e) * 1048576.0;
   if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_FULL_MB")) c->nt_threshold_full = std::atof(e) * 1048576.0;
@@ -1274,9 +1284,9 @@ int pic1dp_hip_substep(pic1dp_ctx *c, int32_t irk) {
 }
 
 // LDS bytes of the whole-step kernels: E0 tile, Eh tile (full only), rho tile
-static size_t step_lds_bytes(int nx, bool full) {
+static size_t step_lds_bytes(int nx, bool full, int rcopies = 1) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
-  return sizeof(double) * ((full ? 2 : 1) * ne + nx);
+  return sizeof(double) * ((full ? 2 : 1) * ne + static_cast<size_t>(nx) * rcopies);
 }
 
 static bool step_recompute_ok(const pic1dp_ctx *c) {
@@ -1285,7 +1295,7 @@ static bool step_recompute_ok(const pic1dp_ctx *c) {
 
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
   LaunchCfg lc{};
-  lc.lds = step_lds_bytes(c->in.nx, full);
+  lc.lds = step_lds_bytes(c->in.nx, full, c->grid.rcopies);
   int by_lds = static_cast<int>((160 * 1024) / lc.lds);
   if (by_lds < 1) by_lds = 1;
   // two workgroups of 768 threads per CU (24 waves): measured inside one process
@@ -1771,7 +1781,7 @@ int pic1dp_hip_stream_probe(pic1dp_ctx *c, int32_t nread, int32_t nwrite, int64_
 // 3 written in place) over a fresh slab, SoA against tiled; keep != 0 leaves the slab
 // allocated until destroy so that the next call lands in other physical memory
 int pic1dp_hip_debug_layout_probe(pic1dp_ctx *c, int64_t n, int32_t log2_tile, int64_t stagger_bytes, int32_t reps,
-                                  int32_t keep, double ms[2]) {
+                                  int32_t keep, double ms[6]) {
   CHECK_CTX(c);
   if (!ms || n < 2 || reps < 1 || log2_tile < 2 || log2_tile > 24) return fail(PIC1DP_ERR_ARG, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
@@ -1787,17 +1797,19 @@ int pic1dp_hip_debug_layout_probe(pic1dp_ctx *c, int64_t n, int32_t log2_tile, i
   if (e == hipSuccess) e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
   LaunchCfg lc = step_launch(c, n, true);
-  for (int tiled = 0; tiled < 2 && e == hipSuccess; ++tiled) {
+  // ms[]: SoA r/w, tiled r/w, SoA read-only, tiled read-only, tiled r/w one workgroup per tile, the same read-only
+  const int variants[6] = {0, 1, 2, 3, 5, 7};
+  for (int k = 0; k < 6 && e == hipSuccess; ++k) {
     for (int r = 0; r < 3 && e == hipSuccess; ++r)
-      e = launch_layout_probe(base, static_cast<int64_t>(stride / sizeof(double)), log2_tile, n, tiled != 0, lc.blocks, lc.threads, c->st);
+      e = launch_layout_probe(base, static_cast<int64_t>(stride / sizeof(double)), log2_tile, n, variants[k], lc.blocks, lc.threads, c->st);
     if (e == hipSuccess) e = hipEventRecord(e0, c->st);
     for (int r = 0; r < reps && e == hipSuccess; ++r)
-      e = launch_layout_probe(base, static_cast<int64_t>(stride / sizeof(double)), log2_tile, n, tiled != 0, lc.blocks, lc.threads, c->st);
+      e = launch_layout_probe(base, static_cast<int64_t>(stride / sizeof(double)), log2_tile, n, variants[k], lc.blocks, lc.threads, c->st);
     if (e == hipSuccess) e = hipEventRecord(e1, c->st);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float t = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
-    ms[tiled] = t / reps;
+    ms[k] = t / reps;
   }
   if (e != hipSuccess) rc = fail(PIC1DP_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
   if (e0) (void)hipEventDestroy(e0);
@@ -1823,6 +1835,22 @@ int pic1dp_hip_debug_divc_check(pic1dp_ctx *c, int32_t isp, int64_t n, uint64_t 
   unsigned long long h = 0;
   HIP_TRY(hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost));
   *mismatches = static_cast<int64_t>(h);
+  return 0;
+}
+
+int pic1dp_hip_debug_exp(pic1dp_ctx *c, const double *x, double *y, int64_t n) {
+  CHECK_CTX(c);
+  if (!x || !y || n < 0) return fail(PIC1DP_ERR_ARG, "bad argument");
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  double *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(double) * 2 * static_cast<size_t>(n)));
+  hipError_t e = hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_exp_array(d, d + n, n, c->st);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+  if (e == hipSuccess) e = hipMemcpy(y, d + n, sizeof(double) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(e);
   return 0;
 }
 

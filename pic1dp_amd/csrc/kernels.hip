@@ -98,29 +98,56 @@ __device__ __forceinline__ double div_const(double a, double c, double rc, int f
 }
 
 // Division by a species constant c, bit-identical to a / c in all three forms:
-//   POW2 = 0  div_const         (general)
-//   POW2 = 1  a * (1/c)         (every divisor constant is a power of two)
 //   POW2 = 2  a                 (unit species: m = T = T2 = 1, so T/m = sqrt(T/m) = 1
 //                                and 2T/m = 2 -- the reference's default input)
-template <int POW2>
-__device__ __forceinline__ double divc(double a, double c, double rc, int fast) {
+//   POW2 = 1  a * (1/c)         (every divisor constant is a power of two)
+//   POW2 = 0  general constants: through a divider object D, either
+//       DivTrue   the hardware's IEEE division, or
+//       DivFast   div_const's five operations WITHOUT its per-division range test: the
+//                 divider only tracks the smallest and largest |dividend| it was given, and
+//                 the caller checks ok() ONCE after the whole -f0'/f0 + push evaluation (ten
+//                 divisions for bump-on-tail); a marker that fails (a zero, tiny or huge
+//                 dividend: measure zero) is evaluated again with DivTrue.  One test per
+//                 marker instead of ten, and ten independent FMA chains with no branches
+//                 between them.
+struct DivTrue {
+  __device__ __forceinline__ double operator()(double a, double c, double) const { return a / c; }
+};
+struct DivFast {
+  double lo = 1.0, hi = 1.0;
+  __device__ __forceinline__ double operator()(double a, double c, double rc) {
+    const double aa = fabs(a);
+    lo = fmin(lo, aa);
+    hi = fmax(hi, aa);
+    const double q0 = a * rc;
+    const double r0 = fma(-c, q0, a);
+    const double q1 = fma(r0, rc, q0);
+    const double r1 = fma(-c, q1, a);
+    return fma(r1, rc, q1);
+  }
+  // Markstein's premises (no underflow in the residuals) hold for every dividend seen
+  __device__ __forceinline__ bool ok() const { return lo > 0x1p-500 && hi < 0x1p+500; }
+};
+
+template <int POW2, class D>
+__device__ __forceinline__ double divc(double a, double c, double rc, D &d) {
   if constexpr (POW2 == 2) {
     return a;
   } else if constexpr (POW2 == 1) {
     return a * rc;
   } else {
-    return div_const(a, c, rc, fast);
+    return d(a, c, rc);
   }
 }
 // the same for the constants 2T/m, 2T2/m (= 2 for a unit species)
-template <int POW2>
-__device__ __forceinline__ double divh(double a, double c, double rc, int fast) {
+template <int POW2, class D>
+__device__ __forceinline__ double divh(double a, double c, double rc, D &d) {
   if constexpr (POW2 == 2) {
     return a * 0.5;
   } else if constexpr (POW2 == 1) {
     return a * rc;
   } else {
-    return div_const(a, c, rc, fast);
+    return d(a, c, rc);
   }
 }
 
@@ -173,33 +200,54 @@ __device__ __forceinline__ double wrap(double x, double lx) {
 }
 
 // -(d f0/dv)/f0 at v, src/pic1dp_interaction.F90:274-326
-template <int DIST, int POW2>
-__device__ __forceinline__ double dlnf0(double v, const SpeciesConst &c) {
+template <int DIST, int POW2, class D>
+__device__ __forceinline__ double dlnf0(double v, const SpeciesConst &c, D &dv) {
   if constexpr (DIST == 1) {  // two-stream1 :276
     return v - 2.0 / v;
   } else if constexpr (DIST == 2) {  // two-stream2 :278-292
     const double vp = v + c.v0, vm = v - c.v0;
-    const double ep = exp(-divh<POW2>(vp * vp, c.two_tm, c.r_two_tm, c.fastc));
-    const double em = exp(-divh<POW2>(vm * vm, c.two_tm, c.r_two_tm, c.fastc));
+    const double ep = exp(-divh<POW2>(vp * vp, c.two_tm, c.r_two_tm, dv));
+    const double em = exp(-divh<POW2>(vm * vm, c.two_tm, c.r_two_tm, dv));
     const double q = (vp * ep + vm * em) / (ep + em);
-    return divc<POW2>(q * c.m, c.T, c.r_T, c.fastc);
+    return divc<POW2>(q * c.m, c.T, c.r_T, dv);
   } else if constexpr (DIST == 3) {  // bump-on-tail :294-321
     const double vm = v - c.v0;
-    const double e1 = exp(-divh<POW2>(v * v, c.two_tm, c.r_two_tm, c.fastc));
-    const double e2 = exp(-divh<POW2>(vm * vm, c.two_tm2, c.r_two_tm2, c.fastc));
-    const double a = divc<POW2>(divc<POW2>(c.den * v, c.tm, c.r_tm, c.fastc) * e1, c.stm, c.r_stm, c.fastc);
-    const double b = divc<POW2>(divc<POW2>(c.beam * vm, c.tm2, c.r_tm2, c.fastc) * e2, c.stm2, c.r_stm2, c.fastc);
-    const double cc = divc<POW2>(c.den * e1, c.stm, c.r_stm, c.fastc);
-    const double d = divc<POW2>(c.beam * e2, c.stm2, c.r_stm2, c.fastc);
+    const double e1 = exp(-divh<POW2>(v * v, c.two_tm, c.r_two_tm, dv));
+    const double e2 = exp(-divh<POW2>(vm * vm, c.two_tm2, c.r_two_tm2, dv));
+    const double a = divc<POW2>(divc<POW2>(c.den * v, c.tm, c.r_tm, dv) * e1, c.stm, c.r_stm, dv);
+    const double b = divc<POW2>(divc<POW2>(c.beam * vm, c.tm2, c.r_tm2, dv) * e2, c.stm2, c.r_stm2, dv);
+    const double cc = divc<POW2>(c.den * e1, c.stm, c.r_stm, dv);
+    const double d = divc<POW2>(c.beam * e2, c.stm2, c.r_stm2, dv);
     return (a + b) / (cc + d);
   } else {  // (shifted) Maxwellian :323-325
-    return divc<POW2>(v - c.v0, c.tm, c.r_tm, c.fastc);
+    return divc<POW2>(v - c.v0, c.tm, c.r_tm, dv);
   }
 }
 
 struct One {
   double x, v, w;
 };
+
+// the weight and velocity updates of one marker given its field e,
+// src/pic1dp_interaction.F90:261-338
+template <int DIST, int MODE, int POW2, class D>
+__device__ __forceinline__ One push_core(double v, double w, double p, double xb, double vb, double wb, double e,
+                                         double dt, const SpeciesConst &s, D &dv) {
+  One o;
+  o.x = xb + dt * v;                     // :261
+  o.w = w;
+  if constexpr (MODE != MODE_FULLF) {
+    const double tmp1 = (MODE == MODE_DF_LIN) ? p * e : (p - w) * e;   // :268-272
+    const double tmp2 = dlnf0<DIST, POW2>(v, s, dv);
+    o.w = wb + divc<POW2>(dt * tmp1 * tmp2 * s.Z, s.m, s.r_m, dv);  // :329
+  }
+  if constexpr (MODE == MODE_DF_LIN) {
+    o.v = v;
+  } else {
+    o.v = vb + divc<POW2>(dt * e * s.Z, s.m, s.r_m, dv);  // :336
+  }
+  return o;
+}
 
 // gather + push of one marker, src/pic1dp_interaction.F90:246-338:
 // derivatives at (x, v, w), base (xb, vb, wb), field tile sE, step dt
@@ -212,20 +260,15 @@ __device__ __forceinline__ One push_one(double x, double v, double w, double p, 
   locate(x, g, ix, wl);
   double e = sE[ix] * wl;                // :254
   e = e + sE[ix + 1] * (1.0 - wl);       // :257 (sE[nx] holds E[0])
-  One o;
-  o.x = xb + dt * v;                     // :261
-  o.w = w;
-  if constexpr (MODE != MODE_FULLF) {
-    const double tmp1 = (MODE == MODE_DF_LIN) ? p * e : (p - w) * e;   // :268-272
-    const double tmp2 = dlnf0<DIST, POW2>(v, s);
-    o.w = wb + divc<POW2>(dt * tmp1 * tmp2 * s.Z, s.m, s.r_m, s.fastc);  // :329
+  if constexpr (POW2 == 0) {
+    if (s.fastc) {
+      DivFast dv;
+      const One o = push_core<DIST, MODE, POW2>(v, w, p, xb, vb, wb, e, dt, s, dv);
+      if (dv.ok()) return o;
+    }
   }
-  if constexpr (MODE == MODE_DF_LIN) {
-    o.v = v;
-  } else {
-    o.v = vb + divc<POW2>(dt * e * s.Z, s.m, s.r_m, s.fastc);  // :336
-  }
-  return o;
+  DivTrue dv;
+  return push_core<DIST, MODE, POW2>(v, w, p, xb, vb, wb, e, dt, s, dv);
 }
 
 // wrap + linear deposit of one marker into the LDS copy of rho,
@@ -242,13 +285,25 @@ __device__ __forceinline__ double deposit_one(double x, double q, double *sR, co
   return px;
 }
 
-__device__ __forceinline__ void flush_rho(const double *sR, double *rho, int nx) {
+// The workgroup's LDS copy of rho may be replicated (g.rcopies = 1, 2, 4 or 8 copies,
+// lane l deposits into copy l % rcopies): neighbouring lanes of a wave that hit the same
+// cell then hit different addresses, which matters for small grids (at nx = 192 a wave's
+// 64 lanes share 192 cells).  The copies are added up in the flush.
+__device__ __forceinline__ double *my_rho_copy(double *sR, const GridConst &g) {
+  return sR + (threadIdx.x & (g.rcopies - 1)) * g.nx;
+}
+__device__ __forceinline__ void zero_rho(double *sR, const GridConst &g) {
+  for (int i = threadIdx.x; i < g.nx * g.rcopies; i += blockDim.x) sR[i] = 0.0;
+}
+__device__ __forceinline__ void flush_rho(const double *sR, double *rho, const GridConst &g) {
   // one global atomic per cell per workgroup; start cell rotated by workgroup
+  const int nx = g.nx;
   const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);
   for (int i = threadIdx.x; i < nx; i += blockDim.x) {
     int j = i + rot;
     if (j >= nx) j -= nx;
-    const double val = sR[j];
+    double val = sR[j];
+    for (int c = 1; c < g.rcopies; ++c) val += sR[c * nx + j];
     if (val != 0.0) glb_add(&rho[j], val);
   }
 }
@@ -258,13 +313,12 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *sE = reinterpret_cast<double *>(smem);
   const int nx = a.g.nx;
-  double *sR = sE + ((nx + 2) & ~1);
-  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-    sE[i] = a.E[i];
-    if constexpr (FUSED) sR[i] = 0.0;
-  }
+  double *sR0 = sE + ((nx + 2) & ~1);
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) sE[i] = a.E[i];
+  if constexpr (FUSED) zero_rho(sR0, a.g);
   if (threadIdx.x == 0) sE[nx] = a.E[0];
   __syncthreads();
+  double *sR = my_rho_copy(sR0, a.g);
 
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
@@ -324,7 +378,7 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
   }
   if constexpr (FUSED) {
     __syncthreads();
-    flush_rho(sR, a.rho, nx);
+    flush_rho(sR0, a.rho, a.g);
   }
 }
 
@@ -363,13 +417,12 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *sE = reinterpret_cast<double *>(smem);
   const int nx = a.g.nx;
-  double *sR = sE + ((nx + 2) & ~1);
-  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-    sE[i] = a.E0[i];
-    sR[i] = 0.0;
-  }
+  double *sR0 = sE + ((nx + 2) & ~1);
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) sE[i] = a.E0[i];
+  zero_rho(sR0, a.g);
   if (threadIdx.x == 0) sE[nx] = a.E0[0];
   __syncthreads();
+  double *sR = my_rho_copy(sR0, a.g);
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   const int64_t npair = a.np >> 1;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -395,7 +448,7 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
     deposit_one(h.x, HAS_W ? h.w : p, sR, a.g);
   }
   __syncthreads();
-  flush_rho(sR, a.rho, nx);
+  flush_rho(sR0, a.rho, a.g);
 }
 
 // one marker through the second half of the time step
@@ -419,17 +472,18 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   const int ne = (nx + 2) & ~1;
   double *sE0 = reinterpret_cast<double *>(smem);
   double *sEh = sE0 + ne;
-  double *sR = sEh + ne;
+  double *sR0 = sEh + ne;
   for (int i = threadIdx.x; i < nx; i += blockDim.x) {
     sE0[i] = a.E0[i];
     sEh[i] = a.Eh[i];
-    sR[i] = 0.0;
   }
+  zero_rho(sR0, a.g);
   if (threadIdx.x == 0) {
     sE0[nx] = a.E0[0];
     sEh[nx] = a.Eh[0];
   }
   __syncthreads();
+  double *sR = my_rho_copy(sR0, a.g);
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
   const int64_t npair = a.np >> 1;
@@ -458,7 +512,7 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
     if constexpr (HAS_W) a.w[i] = n.w;
   }
   __syncthreads();
-  flush_rho(sR, a.rho, nx);
+  flush_rho(sR0, a.rho, a.g);
 }
 
 template <typename K>
@@ -502,9 +556,10 @@ hipError_t launch_step_d(const StepArgsDev &d, int deltaf, int linear, bool full
 __global__ void __launch_bounds__(1024)
 k_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *sR = reinterpret_cast<double *>(smem);
-  for (int i = threadIdx.x; i < g.nx; i += blockDim.x) sR[i] = 0.0;
+  double *sR0 = reinterpret_cast<double *>(smem);
+  zero_rho(sR0, g);
   __syncthreads();
+  double *sR = my_rho_copy(sR0, g);
   const int64_t npair = np >> 1;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   double2 *x2 = reinterpret_cast<double2 *>(x);
@@ -523,7 +578,7 @@ k_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst g
     x[i] = deposit_one(x[i], q[i], sR, g);
   }
   __syncthreads();
-  flush_rho(sR, rho, g.nx);
+  flush_rho(sR0, rho, g);
 }
 
 template <int DIST, int MODE, int POW2, bool IRK2, bool FUSED>
@@ -1520,31 +1575,58 @@ namespace {
 // of them written back in place, 16 B per lane, non-temporal -- over ONE slab, with
 // the four arrays either apart by `step` double2 (SoA, TILED = false) or interleaved
 // in tiles of 2^lt2 pairs: [x tile | v tile | w tile | p tile] (TILED = true).
-template <bool TILED>
+template <bool TILED, bool WRITE, bool WG_PER_TILE>
 __global__ void __launch_bounds__(1024) k_layout_probe(double2 *base, int64_t step, int lt2, int64_t npair) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   const int64_t mask = (static_cast<int64_t>(1) << lt2) - 1;
-  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+  double2 acc = make_double2(0.0, 0.0);
+  auto body = [&](int64_t j) {
     const int64_t o = TILED ? (((j >> lt2) << (lt2 + 2)) + (j & mask)) : j;
     const int64_t d = TILED ? (static_cast<int64_t>(1) << lt2) : step;
     const double2 a = ld2t<true>(base + o), b = ld2t<true>(base + o + d), c = ld2t<true>(base + o + 2 * d),
                   e = ld2t<true>(base + o + 3 * d);
     const double sx = a.x + b.x + c.x + e.x, sy = a.y + b.y + c.y + e.y;
-    st2t<true>(base + o, sx * 0.25, sy * 0.25);
-    st2t<true>(base + o + d, sx * 0.125, sy * 0.125);
-    st2t<true>(base + o + 2 * d, sx * 0.0625, sy * 0.0625);
+    if constexpr (WRITE) {
+      st2t<true>(base + o, sx * 0.25, sy * 0.25);
+      st2t<true>(base + o + d, sx * 0.125, sy * 0.125);
+      st2t<true>(base + o + 2 * d, sx * 0.0625, sy * 0.0625);
+    } else {
+      acc.x += sx;
+      acc.y += sy;
+    }
+  };
+  if constexpr (WG_PER_TILE) {  // a workgroup walks whole tiles: [x|v|w|p] of one tile, then its next tile
+    const int64_t tp = static_cast<int64_t>(1) << lt2, ntile = (npair + tp - 1) >> lt2;
+    for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x)
+      for (int64_t l = threadIdx.x; l < tp; l += blockDim.x)
+        if ((t << lt2) + l < npair) body((t << lt2) + l);
+  } else {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) body(j);
+  }
+  if constexpr (!WRITE) {
+    if (acc.x == 1.2345e300 && acc.y == -1.2345e300) base[0] = acc;  // keeps the loads alive
   }
 }
 
 }  // namespace
 
-hipError_t launch_layout_probe(double *base, int64_t step_doubles, int log2_tile, int64_t n, bool tiled, int blocks,
+// variant: bit 0 tiled, bit 1 read-only (k_step_half's shape), bit 2 one workgroup per tile
+hipError_t launch_layout_probe(double *base, int64_t step_doubles, int log2_tile, int64_t n, int variant, int blocks,
                                int threads, hipStream_t st) {
   double2 *b2 = reinterpret_cast<double2 *>(base);
-  if (tiled)
-    hipLaunchKernelGGL(k_layout_probe<true>, dim3(blocks), dim3(threads), 0, st, b2, step_doubles >> 1, log2_tile - 1, n >> 1);
-  else
-    hipLaunchKernelGGL(k_layout_probe<false>, dim3(blocks), dim3(threads), 0, st, b2, step_doubles >> 1, log2_tile - 1, n >> 1);
+  const int64_t s2 = step_doubles >> 1, np = n >> 1;
+  const int lt2 = log2_tile - 1;
+#define PIC1DP_LP(T, W, G) hipLaunchKernelGGL((k_layout_probe<T, W, G>), dim3(blocks), dim3(threads), 0, st, b2, s2, lt2, np)
+  switch (variant & 7) {
+    case 0: PIC1DP_LP(false, true, false); break;
+    case 1: PIC1DP_LP(true, true, false); break;
+    case 2: PIC1DP_LP(false, false, false); break;
+    case 3: PIC1DP_LP(true, false, false); break;
+    case 5: PIC1DP_LP(true, true, true); break;
+    case 7: PIC1DP_LP(true, false, true); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef PIC1DP_LP
   return hipGetLastError();
 }
 
@@ -1595,6 +1677,19 @@ __global__ void k_divc_check(double c, double rc, uint64_t seed, int64_t n, unsi
 }
 
 }  // namespace
+
+namespace {
+// the push's transcendental on its own (tests bound it against libm)
+__global__ void __launch_bounds__(256) k_exp_array(const double *x, double *y, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = exp(x[i]);
+}
+}  // namespace
+
+hipError_t launch_exp_array(const double *x, double *y, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_exp_array, dim3(1024), dim3(256), 0, st, x, y, n);
+  return hipGetLastError();
+}
 
 hipError_t launch_divc_check(double c, uint64_t seed, int64_t n, unsigned long long *bad, hipStream_t st) {
   hipLaunchKernelGGL(k_divc_check, dim3(2048), dim3(256), 0, st, c, 1.0 / c, seed, n, bad);

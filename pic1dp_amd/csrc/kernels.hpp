@@ -29,6 +29,7 @@ struct GridConst {
   double rlx;    // RN(1/lx), for the exact division by the constant lx
   int nx;
   int fast_div;  // 1: x/lx by reciprocal + two FMA corrections (bit-identical), 0: hardware division
+  int rcopies;   // copies of the workgroup's LDS rho tile (1, 2, 4, 8; lane l deposits into copy l % rcopies)
 };
 
 // Marker storage.  The four arrays of a species (x, v, w, p) are NOT four separate
@@ -188,7 +189,8 @@ hipError_t launch_stream_probe(double *const *in, int nr, double *const *out, in
                                int blocks, int threads, int variant, hipStream_t st);
 // tuning only: k_step_full's traffic shape over one slab, SoA (arrays step_doubles apart)
 // or tiled ([x|v|w|p] tiles of 2^log2_tile markers); n markers, n a multiple of the tile
-hipError_t launch_layout_probe(double *base, int64_t step_doubles, int log2_tile, int64_t n, bool tiled, int blocks,
+// variant: bit 0 tiled, bit 1 read-only (the first sub-step's shape), bit 2 one workgroup per tile
+hipError_t launch_layout_probe(double *base, int64_t step_doubles, int log2_tile, int64_t n, int variant, int blocks,
                                int threads, hipStream_t st);
 // div_lx (reciprocal + FMA corrections) against the hardware division on n test
 // positions; *bad counts results that differ in any bit
@@ -199,6 +201,8 @@ int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n);
 // generated dividends, on the device and with the host's fma
 hipError_t launch_divc_check(double c, uint64_t seed, int64_t n, unsigned long long *bad, hipStream_t st);
 int64_t host_divc_check(double c, uint64_t seed, int64_t n);
+// y[i] = exp(x[i]) as the push kernels evaluate it (device arrays)
+hipError_t launch_exp_array(const double *x, double *y, int64_t n, hipStream_t st);
 // cell index per marker and per-cell counts from (wrapped) x
 hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
                                unsigned long long *count, hipStream_t st);

@@ -420,6 +420,14 @@ interface
     integer(c_int64_t), intent(out) :: exchanges
     integer(c_int) :: ierr
   end function pic1dp_hip_xchg_info
+  function pic1dp_hip_debug_exp(ctx, x, y, n) bind(C, name="pic1dp_hip_debug_exp") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    real(c_double), intent(in) :: x(*)
+    real(c_double), intent(out) :: y(*)
+    integer(c_int64_t), value :: n
+    integer(c_int) :: ierr
+  end function pic1dp_hip_debug_exp
   function pic1dp_hip_debug_layout_probe(ctx, n, log2_tile, stagger_bytes, reps, keep, ms) &
       bind(C, name="pic1dp_hip_debug_layout_probe") result(ierr)
     import
@@ -429,7 +437,7 @@ interface
     integer(c_int64_t), value :: stagger_bytes
     integer(c_int32_t), value :: reps
     integer(c_int32_t), value :: keep
-    real(c_double), intent(out) :: ms(2)
+    real(c_double), intent(out) :: ms(6)
     integer(c_int) :: ierr
   end function pic1dp_hip_debug_layout_probe
   function pic1dp_hip_timers_enable(ctx, on) bind(C, name="pic1dp_hip_timers_enable") result(ierr)

@@ -38,17 +38,71 @@ def smooth_field(nx, seed=0, amp=0.05):
     return amp * np.sin(2 * np.pi * ix / nx + 0.3) + 0.2 * amp * rng.standard_normal(nx)
 
 
-def assert_w_close(w_gpu, w_orc, wb_orc, exact):
+# largest distance (ulp) between the device's exp and libm's on the weight equation's
+# argument range that the w tolerance below is derived from; test_device_exp_against_libm
+# measures it and fails if it is exceeded
+EXP_ULP_MAX = 2
+
+
+def w_cancellation(inp, v):
+    """kappa = (|a| + |b|) / |a + b| of the numerator of -f0'/f0 at v
+    (src/pic1dp_interaction.F90:278-321): a rounding difference of the two exp() enters
+    tmp2 -- and the weight update -- amplified by it.  1 where no exp is involved."""
+    T, T2, m = inp.species_temperature[0], inp.species_temperature2[0], inp.species_mass[0]
+    den, v0 = inp.species_density[0], inp.species_v0[0]
+    if inp.iptcldist == 2:
+        a = (v + v0) * np.exp(-(v + v0) ** 2 / (2.0 * T / m))
+        b = (v - v0) * np.exp(-(v - v0) ** 2 / (2.0 * T / m))
+    elif inp.iptcldist == 3:
+        a = den * v / (T / m) * np.exp(-v ** 2 / (2.0 * T / m)) / np.sqrt(T / m)
+        b = (1.0 - den) * (v - v0) / (T2 / m) * np.exp(-(v - v0) ** 2 / (2.0 * T2 / m)) / np.sqrt(T2 / m)
+    else:
+        return np.ones_like(v)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        k = (np.abs(a) + np.abs(b)) / np.abs(a + b)
+    return np.where(np.isfinite(k), k, 1e300)
+
+
+def assert_w_close(w_gpu, w_orc, wb_orc, exact, kappa=None):
+    """w = wb + dt*tmp1*tmp2*Z/m (:329).  Everything but exp() is the same IEEE
+    operation on both sides; with exp within EXP_ULP_MAX ulp of libm each of the four
+    exp-bearing terms of tmp2 is within EXP_ULP_MAX + 1 ulp, the quotient within
+    (EXP_ULP_MAX + 1) * (kappa + 1) + 1, the update after its three products and one
+    division by m within that + 2, and the final sum adds half an ulp of w: allow twice that."""
     if exact:
         assert np.array_equal(w_gpu, w_orc)
         return
-    scale = np.abs(w_orc) + np.abs(wb_orc)
+    upd = np.abs(w_orc - wb_orc)
+    kap = np.ones_like(upd) if kappa is None else kappa
     err = np.abs(w_gpu - w_orc)
-    # exp() differs by <= 1 ulp (OCML vs libm) and the bump-on-tail / two-stream
-    # numerators cancel partially, so allow a few hundred ulp of the update scale
-    bad = err > 512 * EPS * scale + 1e-300
-    assert not bad.any(), "w off by %g (scale %g) at %d" % (
-        err[bad].max(), scale[bad][np.argmax(err[bad])], np.flatnonzero(bad)[0])
+    tol = 2.0 * (((EXP_ULP_MAX + 1) * (kap + 1.0) + 3.0) * EPS * upd + 0.5 * EPS * np.abs(w_orc)) + 1e-300
+    # kappa -> infinity means a + b -> 0 and an update near zero: bound by the update scale itself there
+    tol = np.where(kap >= 1e299, 64 * EPS * (np.abs(w_orc) + np.abs(wb_orc)), tol)
+    bad = err > tol
+    assert not bad.any(), "w off by %g (tolerance %g, update %g, kappa %g) at %d" % (
+        err[bad].max(), tol[bad][np.argmax(err[bad])], upd[bad][np.argmax(err[bad])], kap[bad][np.argmax(err[bad])],
+        np.flatnonzero(bad)[0])
+
+
+def test_device_exp_against_libm(oracle_mod, amd):
+    """the one operation of the push that is not bit-identical by construction: the
+    device's exp (OCML) against libm's on the arguments the weight equation forms,
+    -(v -+ v0)^2 / (2T/m) with |v| <= v_max + drift: [-260, 0], dense near 0, plus the
+    rest of the double range that does not overflow"""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    x = np.concatenate([-260.0 * rng.random(3_000_000), -rng.random(1_000_000) ** 4, -745.0 * rng.random(500_000),
+                        700.0 * rng.random(500_000), -np.logspace(-300, 2, 20001), [0.0, -0.0]])
+    eng = amd.Pic1dp(amd.make_input(nparticle_max=1000, nx=16))
+    y = np.empty_like(x)
+    amd._lib.check(eng.L.pic1dp_hip_debug_exp(eng._ctx, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size))
+    ref = np.empty_like(x)
+    oracle_mod.lib().orc_exp_array(x, ref, x.size)
+    d = ulp_diff(y, ref)
+    assert d.max() <= EXP_ULP_MAX, "device exp differs from libm by %d ulp at x = %r" % (d.max(), x[np.argmax(d)])
+    # and it is not the same function: a silent switch to a bit-identical exp would make the
+    # exp-bearing w comparisons exact -- worth knowing, not an error
+    print("device exp vs libm: max %d ulp, %.3f %% of arguments differ" % (d.max(), 100.0 * np.mean(d > 0)))
 
 
 # --------------------------------------------------------------------------
@@ -238,12 +292,13 @@ def test_push_particle(oracle_mod, amd, name, kw, linear):
         sim.set_field(E)
         eng.set_electric(E)
         wb = sim.gather("w") if irk == 1 else sim.gather("wb")
+        kappa = w_cancellation(sim.inp, sim.gather("v"))      # v the derivatives are evaluated at
         sim.push(irk)
         eng.interaction_push_particle(irk)
         g = eng.particles_download()
         assert np.array_equal(g["x"], sim.gather("x")), "x irk=%d" % irk
         assert np.array_equal(g["v"], sim.gather("v")), "v irk=%d" % irk
-        assert_w_close(g["w"], sim.gather("w"), wb, exact_w)
+        assert_w_close(g["w"], sim.gather("w"), wb, exact_w, kappa)
         if irk == 1:
             b = eng.particles_download_bak()
             assert np.array_equal(b["xb"], sim.gather("xb"))
@@ -641,6 +696,7 @@ def test_non_unit_species_fast_and_hardware_division_agree(oracle_mod, amd, monk
         E = smooth_field(nx, seed)
         sim.set_field(E)
         wb = sim.gather("w") if irk == 1 else sim.gather("wb")
+        kappa = w_cancellation(sim.inp, sim.gather("v"))
         sim.push(irk)
         out = []
         for e in (eng, ref):
@@ -649,7 +705,7 @@ def test_non_unit_species_fast_and_hardware_division_agree(oracle_mod, amd, monk
             g = e.particles_download()
             assert np.array_equal(g["x"], sim.gather("x")), irk
             assert np.array_equal(g["v"], sim.gather("v")), irk
-            assert_w_close(g["w"], sim.gather("w"), wb, False)
+            assert_w_close(g["w"], sim.gather("w"), wb, False, kappa)
             out.append(g["w"])
             e.interaction_collect_charge()
         assert np.array_equal(out[0], out[1]), irk

@@ -102,6 +102,9 @@ def test_long_run_through_saturation(oracle_mod, amd):
 
 BASELINE_CASES = [
     # id, input, reference ranks (virtual ranks on the one GPU), steps, per-marker checks
+    # configs[0]: the reference's own default input at its own size, 1 MPI rank
+    # (src/pic1dp_input.F90:113,128); the oracle runs it on one thread (~30 s)
+    ("C1_default_1rank", dict(nparticle_max=6_400_000, nx=192), 1, 100, True),
     ("C2_bump_1e7", dict(nparticle_max=10**7, nx=256), 16, 200, True),
     ("C3_bump_1e8", dict(nparticle_max=10**8, nx=1024), 16, 24, True),
     ("C4_two_stream_1e8_4ranks", dict(nparticle_max=10**8, nx=512, iptcldist=2, species_density=[1.0],
@@ -113,7 +116,7 @@ BASELINE_CASES = [
 
 @pytest.mark.parametrize("name,kw,npe,nsteps,per_marker", BASELINE_CASES, ids=[c[0] for c in BASELINE_CASES])
 def test_baseline_sizes_against_oracle(oracle_mod, amd, name, kw, npe, nsteps, per_marker):
-    """BASELINE configs[1..4] at their real sizes on the GPU and in the oracle: the
+    """BASELINE configs[0..4] at their real sizes on the GPU and in the oracle: the
     GPU holds the reference's rank blocks as virtual ranks (16 for the one-GPU
     configs, 4 and 8 for the 4- and 8-GPU ones), the oracle runs one reference rank
     per host thread.  int E^2 dx within 1e-10 at every step, the fitted rate within

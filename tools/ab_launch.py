@@ -13,8 +13,8 @@ eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=n, nx=nx))
 eng.particle_load()
 eng.interaction_collect_charge()
 eng.field_solve_electric()
-eng.step(3)
-shapes = [(0, 0), (256, 8), (256, 4), (512, 4), (512, 2), (512, 3), (1024, 2), (1024, 1), (768, 2), (0, 0)]
+eng.step(40)
+shapes = [(0, 0), (256, 8), (512, 4), (512, 3), (640, 3), (768, 2), (896, 2), (1024, 2), (1024, 1), (0, 0)]
 for rnd in range(2):
     for th, bpc in shapes:
         eng.set_launch(th, bpc)

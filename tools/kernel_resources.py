@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""kernel_resources.py -- VGPRs / scratch / occupancy of every kernel of kernels.hip as hipcc
+reports them (-Rpass-analysis=kernel-resource-usage); runs on the CPU (cross-compile).
+    python tools/kernel_resources.py [filter]"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "pic1dp_amd", "csrc", "kernels.hip")
+r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                    "-munsafe-fp-atomics", "-c", "-x", "hip", src, "-o", "/tmp/kernel_resources.o",
+                    "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("PIC1DP_EXTRA_FLAGS", "").split(),
+                   capture_output=True, text=True)
+blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+names = [b.split()[0] for b in blocks]
+dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
+flt = sys.argv[1] if len(sys.argv) > 1 else ""
+for b, d in zip(blocks, dem):
+    def g(k):
+        m = re.search(re.escape(k) + r": (\d+)", b)
+        return int(m.group(1)) if m else -1
+    d = d.replace("pic1dp::(anonymous namespace)::", "").replace("void ", "")
+    d = re.sub(r"\(.*", "", d)
+    if flt in d:
+        print("%-60s VGPR %3d  SGPR %3d  scratch %4d  waves/SIMD %d  spill %d" % (
+            d[:60], g("VGPRs"), g("TotalSGPRs"), g("ScratchSize [bytes/lane]"), g("Occupancy [waves/SIMD]"), g("VGPRs Spill")))

@@ -13,20 +13,22 @@ from pic1dp_amd._lib import check  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**8
 eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=1000, nx=1024))
-ms = (C.c_double * 2)()
+ms = (C.c_double * 6)()
 
 
 def probe(lt, stagger, keep):
     check(eng.L.pic1dp_hip_debug_layout_probe(eng._ctx, n, lt, stagger, 20, keep, ms))
-    return ms[0], ms[1]
+    return list(ms)
 
 
 probe(10, 0, 0)
+rw, ro = 56.0 * n / 1e6, 32.0 * n / 1e6
 for keep in (0, 1):
-    for rnd in range(8 if keep else 3):
-        for lt in (8, 10, 12, 14):
-            a, b = probe(lt, 0, keep if lt == 14 else 0)
-            gb = 56.0 * n / 1e6
-            print("LAYOUT keep %d round %d tile 2^%-2d : SoA %.4f ms (%.0f GB/s)  tiled %.4f ms (%.0f GB/s)"
-                  % (keep, rnd, lt, a, gb / a, b, gb / b), flush=True)
+    for rnd in range(4 if keep else 2):
+        for lt in (10, 11, 12, 13, 14):
+            m = probe(lt, 0, keep if lt == 14 else 0)
+            print("LAYOUT keep %d round %d tile 2^%-2d : r/w  SoA %.4f ms (%4.0f GB/s) tiled %.4f (%4.0f) tiled-wg %.4f (%4.0f)"
+                  " | read-only  SoA %.4f (%4.0f) tiled %.4f (%4.0f) tiled-wg %.4f (%4.0f)"
+                  % (keep, rnd, lt, m[0], rw / m[0], m[1], rw / m[1], m[4], rw / m[4], m[2], ro / m[2], m[3], ro / m[3],
+                     m[5], ro / m[5]), flush=True)
 eng.close()
