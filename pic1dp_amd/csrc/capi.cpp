@@ -67,6 +67,7 @@ struct Species {
   int64_t nalloc = 0, np = 0;
   PSet set[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   double *p = nullptr;
+  double *t2 = nullptr;   // carry of -f0'/f0 between the whole-step kernels (general species constants only)
   double *slab[2] = {nullptr, nullptr};  // tiled storage of set 0 (+ p) and of the RK ping-pong set (kernels.hpp)
   double *rho = nullptr;  // slice of rho_sp
   SpeciesConst sc{};
@@ -108,6 +109,7 @@ struct pic1dp_ctx {
   double *d_E0 = nullptr;        // field the noted push(1) saw
   double *d_rho_dummy = nullptr; // accumulator of a wrap-only deposit
   std::vector<double *> probe_keep;  // slabs a layout probe was asked to leave allocated
+  int carry = 1;           // whole-step kernels may carry -f0'/f0 between them (PIC1DP_CARRY=0: never)
   int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
   int field_solver = 0;    // 0 the reference's mode-filter DFT solve, 1 finite-difference tridiagonal (opt-in)
   // marker state (bytes) above which k_step_half / k_step_full stream non-temporally
@@ -182,11 +184,12 @@ struct Span {
   int rc = 0;
   Span(pic1dp_ctx *c_, int tag, bool on) : c(c_) {
     if (!on) return;
+    if (c->ev_used == c->evpool.size() && c->evpool.size() >= (1u << 16)) {
+      // a long run that reads its timers only at the end: fold what has been recorded into
+      // the accumulators (one stream synchronisation per 65 536 spans) and reuse the pool
+      if ((rc = ev_resolve(c)) != 0) return;
+    }
     if (c->ev_used == c->evpool.size()) {
-      if (c->evpool.size() >= (1u << 20)) {
-        rc = fail(PIC1DP_ERR_STATE, "event pool exhausted: read the timers / kernel stats more often");
-        return;
-      }
       EvPair p{};
       if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
         rc = fail(PIC1DP_ERR_HIP, "hipEventCreate failed");
@@ -692,6 +695,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMalloc(&c->d_E0, sizeof(double) * nx));
   HIP_TRY_C(hipMalloc(&c->d_rho_dummy, sizeof(double) * nx));
   if (const char *e = std::getenv("PIC1DP_LAZY_CALLS")) c->lazy_calls = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PIC1DP_CARRY")) c->carry = std::atoi(e);
   HIP_TRY_C(hipMalloc(&c->d_mode_re, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_mode_im, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_fre, sizeof(double) * nm * nx));
@@ -771,6 +775,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
   for (auto &S : c->sp) {
     (void)hipFree(S.slab[0]);
     (void)hipFree(S.slab[1]);
+    (void)hipFree(S.t2);
   }
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
                     c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage};
@@ -1351,6 +1356,16 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     a.deltaf = c->in.deltaf;
     a.linear = c->in.linear;
     a.stream_nt = stream_nt;
+    // a species with general divisor constants and an exp-bearing f0 is FP64-issue-bound: its
+    // -f0'/f0 at the step-start velocity goes from the first kernel to the second through
+    // memory (8 B per marker) instead of being evaluated twice.  Measured at 1e8 markers
+    // (tools/ab_pipe_carry.sh): bump-on-tail with T = 1.3, T2 = 0.7, m = 1.1 8.9e10 -> 9.85e10
+    // updates/s; two-stream2 (one division fewer per exp pair) 1.05e11 either way, so only
+    // bump-on-tail carries.  PIC1DP_CARRY=0 switches it off, 2 also carries for two-stream2.
+    if (c->carry && c->in.deltaf && !S.sc.pow2 && (c->in.iptcldist == 3 || (c->carry == 2 && c->in.iptcldist == 2))) {
+      if (!S.t2) HIP_TRY(hipMalloc(&S.t2, sizeof(double) * static_cast<size_t>(S.nalloc + 2)));
+      a.t2 = S.t2;
+    }
     LaunchCfg lc = step_launch(c, S.np, full);
     Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
     Span ks(c, full ? kTagStepFull : kTagStepHalf, c->stats_on);

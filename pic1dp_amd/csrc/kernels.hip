@@ -52,6 +52,11 @@ __device__ __forceinline__ void glb_add(double *p, double v) {
 #ifndef PIC1DP_NT
 #define PIC1DP_NT 1
 #endif
+// tuning builds of the whole-step kernels' marker loop: 0 one pair per lane per trip (default),
+// 1 next trip's loads before this trip's arithmetic (k_step_full), 2 two pairs per trip
+#ifndef PIC1DP_STEP_PIPE
+#define PIC1DP_STEP_PIPE 0
+#endif
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 template <bool NT>
@@ -229,16 +234,24 @@ struct One {
 };
 
 // the weight and velocity updates of one marker given its field e,
-// src/pic1dp_interaction.F90:261-338
-template <int DIST, int MODE, int POW2, class D>
+// src/pic1dp_interaction.F90:261-338.  T2MODE: 0 evaluate tmp2 = -f0'/f0(v); 1 evaluate it and
+// hand it out through t2io; 2 take it from t2io (the whole-step kernels can carry it from the
+// first sub-step's kernel to the second's instead of evaluating it twice, see k_step_half)
+template <int DIST, int MODE, int POW2, int T2MODE, class D>
 __device__ __forceinline__ One push_core(double v, double w, double p, double xb, double vb, double wb, double e,
-                                         double dt, const SpeciesConst &s, D &dv) {
+                                         double dt, const SpeciesConst &s, D &dv, double *t2io) {
   One o;
   o.x = xb + dt * v;                     // :261
   o.w = w;
   if constexpr (MODE != MODE_FULLF) {
     const double tmp1 = (MODE == MODE_DF_LIN) ? p * e : (p - w) * e;   // :268-272
-    const double tmp2 = dlnf0<DIST, POW2>(v, s, dv);
+    double tmp2;
+    if constexpr (T2MODE == 2) {
+      tmp2 = *t2io;
+    } else {
+      tmp2 = dlnf0<DIST, POW2>(v, s, dv);
+      if constexpr (T2MODE == 1) *t2io = tmp2;
+    }
     o.w = wb + divc<POW2>(dt * tmp1 * tmp2 * s.Z, s.m, s.r_m, dv);  // :329
   }
   if constexpr (MODE == MODE_DF_LIN) {
@@ -251,10 +264,10 @@ __device__ __forceinline__ One push_core(double v, double w, double p, double xb
 
 // gather + push of one marker, src/pic1dp_interaction.F90:246-338:
 // derivatives at (x, v, w), base (xb, vb, wb), field tile sE, step dt
-template <int DIST, int MODE, int POW2>
+template <int DIST, int MODE, int POW2, int T2MODE = 0>
 __device__ __forceinline__ One push_one(double x, double v, double w, double p, double xb,
                                         double vb, double wb, const double *sE, double dt,
-                                        const GridConst &g, const SpeciesConst &s) {
+                                        const GridConst &g, const SpeciesConst &s, double *t2io = nullptr) {
   int ix;
   double wl;
   locate(x, g, ix, wl);
@@ -263,12 +276,12 @@ __device__ __forceinline__ One push_one(double x, double v, double w, double p, 
   if constexpr (POW2 == 0) {
     if (s.fastc) {
       DivFast dv;
-      const One o = push_core<DIST, MODE, POW2>(v, w, p, xb, vb, wb, e, dt, s, dv);
+      const One o = push_core<DIST, MODE, POW2, T2MODE>(v, w, p, xb, vb, wb, e, dt, s, dv, t2io);
       if (dv.ok()) return o;
     }
   }
   DivTrue dv;
-  return push_core<DIST, MODE, POW2>(v, w, p, xb, vb, wb, e, dt, s, dv);
+  return push_core<DIST, MODE, POW2, T2MODE>(v, w, p, xb, vb, wb, e, dt, s, dv, t2io);
 }
 
 // wrap + linear deposit of one marker into the LDS copy of rho,
@@ -406,13 +419,20 @@ struct StepArgsDev {
   GridConst g;
   SpeciesConst s;
   int nt;
+  double *t2;  // [np + 2] -f0'/f0 at the step-start velocity, carried from k_step_half to k_step_full (or null)
 };
 
+// CARRY: a species whose divisor constants are general numbers spends most of either kernel
+// in -f0'/f0 (two exp, eight constant divisions, one true division: FP64-issue-bound).  The
+// second kernel evaluates it twice -- at the step-start velocity again, to recompute the
+// half-step state, and at the half-step velocity.  With CARRY the first kernel stores its
+// value (8 B per marker, contiguous array) and the second loads it: 16 B more traffic per
+// marker and step for a third less arithmetic.  Same value, same bits.
 // NT: non-temporal loads and stores.  They win once the marker state no longer
 // fits the 256 MiB Infinity Cache (+15 % at 2e7 markers); below that, plain
 // accesses keep the state cache-resident between the two kernels of a step
 // (+5 % at the reference's default 6.4e6 markers).  Chosen per launch.
-template <int DIST, int MODE, int POW2, bool NT>
+template <int DIST, int MODE, int POW2, bool NT, bool CARRY>
 __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *sE = reinterpret_cast<double *>(smem);
@@ -430,21 +450,52 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   const double2 *v2 = reinterpret_cast<const double2 *>(a.v);
   const double2 *w2 = reinterpret_cast<const double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+#if PIC1DP_STEP_PIPE == 2
+  // tuning variant: two pairs per lane per trip, all eight loads in flight before the arithmetic
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += 2 * stride) {
+    const bool hb = j + stride < npair;
+    const int64_t oa = tidx2(j), ob = tidx2(hb ? j + stride : j);
+    const double2 XA = ld2t<NT>(x2 + oa), VA = ld2t<NT>(v2 + oa), PA = ld2t<NT>(p2 + oa);
+    const double2 XB = ld2t<NT>(x2 + ob), VB = ld2t<NT>(v2 + ob), PB = ld2t<NT>(p2 + ob);
+    double2 WA = make_double2(0.0, 0.0), WB = WA;
+    if constexpr (HAS_W) {
+      WA = ld2t<NT>(w2 + oa);
+      WB = ld2t<NT>(w2 + ob);
+    }
+    {
+      const One h0 = push_one<DIST, MODE, POW2>(XA.x, VA.x, WA.x, PA.x, XA.x, VA.x, WA.x, sE, a.dt_half, a.g, a.s);
+      const One h1 = push_one<DIST, MODE, POW2>(XA.y, VA.y, WA.y, PA.y, XA.y, VA.y, WA.y, sE, a.dt_half, a.g, a.s);
+      deposit_one(h0.x, HAS_W ? h0.w : PA.x, sR, a.g);
+      deposit_one(h1.x, HAS_W ? h1.w : PA.y, sR, a.g);
+    }
+    if (hb) {
+      const One h0 = push_one<DIST, MODE, POW2>(XB.x, VB.x, WB.x, PB.x, XB.x, VB.x, WB.x, sE, a.dt_half, a.g, a.s);
+      const One h1 = push_one<DIST, MODE, POW2>(XB.y, VB.y, WB.y, PB.y, XB.y, VB.y, WB.y, sE, a.dt_half, a.g, a.s);
+      deposit_one(h0.x, HAS_W ? h0.w : PB.x, sR, a.g);
+      deposit_one(h1.x, HAS_W ? h1.w : PB.y, sR, a.g);
+    }
+  }
+#else
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
     const int64_t o = tidx2(j);
     const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0);
     if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
-    const One h0 = push_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, X.x, V.x, W.x, sE, a.dt_half, a.g, a.s);
-    const One h1 = push_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, X.y, V.y, W.y, sE, a.dt_half, a.g, a.s);
+    double t0 = 0.0, t1 = 0.0;
+    const One h0 = push_one<DIST, MODE, POW2, CARRY ? 1 : 0>(X.x, V.x, W.x, P.x, X.x, V.x, W.x, sE, a.dt_half, a.g, a.s, &t0);
+    const One h1 = push_one<DIST, MODE, POW2, CARRY ? 1 : 0>(X.y, V.y, W.y, P.y, X.y, V.y, W.y, sE, a.dt_half, a.g, a.s, &t1);
+    if constexpr (CARRY) st2t<NT>(reinterpret_cast<double2 *>(a.t2) + j, t0, t1);
     deposit_one(h0.x, HAS_W ? h0.w : P.x, sR, a.g);
     deposit_one(h1.x, HAS_W ? h1.w : P.y, sR, a.g);
   }
+#endif
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = tidx(a.np - 1);
     const double x = a.x[i], v = a.v[i], p = a.p[i];
     const double w = HAS_W ? a.w[i] : 0.0;
-    const One h = push_one<DIST, MODE, POW2>(x, v, w, p, x, v, w, sE, a.dt_half, a.g, a.s);
+    double t0 = 0.0;
+    const One h = push_one<DIST, MODE, POW2, CARRY ? 1 : 0>(x, v, w, p, x, v, w, sE, a.dt_half, a.g, a.s, &t0);
+    if constexpr (CARRY) a.t2[a.np - 1] = t0;
     deposit_one(h.x, HAS_W ? h.w : p, sR, a.g);
   }
   __syncthreads();
@@ -452,12 +503,12 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
 }
 
 // one marker through the second half of the time step
-template <int DIST, int MODE, int POW2>
+template <int DIST, int MODE, int POW2, bool CARRY = false>
 __device__ __forceinline__ One step_full_one(double x, double v, double w, double p, const double *sE0,
-                                             const double *sEh, double *sR, const StepArgsDev &a) {
+                                             const double *sEh, double *sR, const StepArgsDev &a, double t2 = 0.0) {
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   // sub-step 1 again (identical arithmetic), with the wrap the deposit applied
-  One h = push_one<DIST, MODE, POW2>(x, v, w, p, x, v, w, sE0, a.dt_half, a.g, a.s);
+  One h = push_one<DIST, MODE, POW2, CARRY ? 2 : 0>(x, v, w, p, x, v, w, sE0, a.dt_half, a.g, a.s, &t2);
   h.x = wrap(h.x, a.g.lx);
   // sub-step 2: derivatives at the half-step state, base = step-start state
   One n = push_one<DIST, MODE, POW2>(h.x, h.v, h.w, p, x, v, w, sEh, a.dt_full, a.g, a.s);
@@ -465,7 +516,7 @@ __device__ __forceinline__ One step_full_one(double x, double v, double w, doubl
   return n;
 }
 
-template <int DIST, int MODE, int POW2, bool NT>
+template <int DIST, int MODE, int POW2, bool NT, bool CARRY>
 __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nx = a.g.nx;
@@ -492,21 +543,75 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   double2 *v2 = reinterpret_cast<double2 *>(a.v);
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+#if PIC1DP_STEP_PIPE == 2
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += 2 * stride) {
+    const bool hb = j + stride < npair;
+    const int64_t oa = tidx2(j), ob = tidx2(hb ? j + stride : j);
+    const double2 XA = ld2t<NT>(x2 + oa), VA = ld2t<NT>(v2 + oa), PA = ld2t<NT>(p2 + oa);
+    const double2 XB = ld2t<NT>(x2 + ob), VB = ld2t<NT>(v2 + ob), PB = ld2t<NT>(p2 + ob);
+    double2 WA = make_double2(0.0, 0.0), WB = WA;
+    if constexpr (HAS_W) {
+      WA = ld2t<NT>(w2 + oa);
+      WB = ld2t<NT>(w2 + ob);
+    }
+    {
+      const One n0 = step_full_one<DIST, MODE, POW2>(XA.x, VA.x, WA.x, PA.x, sE0, sEh, sR, a);
+      const One n1 = step_full_one<DIST, MODE, POW2>(XA.y, VA.y, WA.y, PA.y, sE0, sEh, sR, a);
+      st2t<NT>(x2 + oa, n0.x, n1.x);
+      if constexpr (PUSH_V) st2t<NT>(v2 + oa, n0.v, n1.v);
+      if constexpr (HAS_W) st2t<NT>(w2 + oa, n0.w, n1.w);
+    }
+    if (hb) {
+      const One n0 = step_full_one<DIST, MODE, POW2>(XB.x, VB.x, WB.x, PB.x, sE0, sEh, sR, a);
+      const One n1 = step_full_one<DIST, MODE, POW2>(XB.y, VB.y, WB.y, PB.y, sE0, sEh, sR, a);
+      st2t<NT>(x2 + ob, n0.x, n1.x);
+      if constexpr (PUSH_V) st2t<NT>(v2 + ob, n0.v, n1.v);
+      if constexpr (HAS_W) st2t<NT>(w2 + ob, n0.w, n1.w);
+    }
+  }
+#elif PIC1DP_STEP_PIPE == 1
+  // tuning variant: the next trip's loads are issued before this trip's arithmetic
+  {
+    int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    double2 X = make_double2(0.0, 0.0), V = X, P = X, W = X;
+    if (j < npair) {
+      const int64_t o = tidx2(j);
+      X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
+      if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
+    }
+    for (; j < npair; j += stride) {
+      const int64_t o = tidx2(j), jn = j + stride, on = tidx2(jn < npair ? jn : j);
+      const double2 Xn = ld2t<NT>(x2 + on), Vn = ld2t<NT>(v2 + on), Pn = ld2t<NT>(p2 + on);
+      double2 Wn = make_double2(0.0, 0.0);
+      if constexpr (HAS_W) Wn = ld2t<NT>(w2 + on);
+      const One n0 = step_full_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a);
+      const One n1 = step_full_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a);
+      st2t<NT>(x2 + o, n0.x, n1.x);
+      if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
+      if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
+      X = Xn, V = Vn, P = Pn, W = Wn;
+    }
+  }
+#else
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
     const int64_t o = tidx2(j);
     const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0);
     if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
-    const One n0 = step_full_one<DIST, MODE, POW2>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a);
-    const One n1 = step_full_one<DIST, MODE, POW2>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a);
+    double2 T = make_double2(0.0, 0.0);
+    if constexpr (CARRY) T = ld2t<NT>(reinterpret_cast<const double2 *>(a.t2) + j);
+    const One n0 = step_full_one<DIST, MODE, POW2, CARRY>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x);
+    const One n1 = step_full_one<DIST, MODE, POW2, CARRY>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y);
     st2t<NT>(x2 + o, n0.x, n1.x);
     if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
     if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
   }
+#endif
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = tidx(a.np - 1);
     const double w = HAS_W ? a.w[i] : 0.0;
-    const One n = step_full_one<DIST, MODE, POW2>(a.x[i], a.v[i], w, a.p[i], sE0, sEh, sR, a);
+    const One n = step_full_one<DIST, MODE, POW2, CARRY>(a.x[i], a.v[i], w, a.p[i], sE0, sEh, sR, a,
+                                                         CARRY ? a.t2[a.np - 1] : 0.0);
     a.x[i] = n.x;
     if constexpr (PUSH_V) a.v[i] = n.v;
     if constexpr (HAS_W) a.w[i] = n.w;
@@ -526,13 +631,13 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc,
   return hipGetLastError();
 }
 
-template <int DIST, int MODE, int POW2>
+template <int DIST, int MODE, int POW2, bool CARRY = false>
 hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
   if (d.nt)
-    return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true>, d, lc, st)
-                : launch_step_kernel(k_step_half<DIST, MODE, POW2, true>, d, lc, st);
-  return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, false>, d, lc, st)
-              : launch_step_kernel(k_step_half<DIST, MODE, POW2, false>, d, lc, st);
+    return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY>, d, lc, st)
+                : launch_step_kernel(k_step_half<DIST, MODE, POW2, true, CARRY>, d, lc, st);
+  return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, false, CARRY>, d, lc, st)
+              : launch_step_kernel(k_step_half<DIST, MODE, POW2, false, CARRY>, d, lc, st);
 }
 
 template <int DIST>
@@ -544,10 +649,17 @@ hipError_t launch_step_d(const StepArgsDev &d, int deltaf, int linear, bool full
   if (!deltaf)
     return pow2 ? launch_step_dmp<0, MODE_FULLF, 1>(d, full, lc, st)
                 : launch_step_dmp<0, MODE_FULLF, 0>(d, full, lc, st);
-  if (linear)
+  // general divisor constants and an exp-bearing distribution: -f0'/f0 carried between the kernels
+  const bool carry = !pow2 && d.t2 != nullptr && (DIST == 2 || DIST == 3) && PIC1DP_STEP_PIPE == 0;
+  if (linear) {
+    if constexpr (DIST == 2 || DIST == 3)
+      if (carry) return launch_step_dmp<DIST, MODE_DF_LIN, 0, true>(d, full, lc, st);
     return pow2 ? launch_step_dmp<DIST, MODE_DF_LIN, 1>(d, full, lc, st)
                 : launch_step_dmp<DIST, MODE_DF_LIN, 0>(d, full, lc, st);
+  }
   if (d.s.unit) return launch_step_dmp<DIST, MODE_DF_NL, 2>(d, full, lc, st);
+  if constexpr (DIST == 2 || DIST == 3)
+    if (carry) return launch_step_dmp<DIST, MODE_DF_NL, 0, true>(d, full, lc, st);
   return pow2 ? launch_step_dmp<DIST, MODE_DF_NL, 1>(d, full, lc, st)
               : launch_step_dmp<DIST, MODE_DF_NL, 0>(d, full, lc, st);
 }
@@ -652,6 +764,7 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.g = a.g;
   d.s = a.s;
   d.nt = a.stream_nt;
+  d.t2 = a.t2;
   switch (a.iptcldist) {
     case 1: return launch_step_d<1>(d, a.deltaf, a.linear, full, lc, st);
     case 2: return launch_step_d<2>(d, a.deltaf, a.linear, full, lc, st);

@@ -110,6 +110,7 @@ struct StepArgs {
   SpeciesConst s;
   int iptcldist, deltaf, linear;
   int stream_nt;       // 1: non-temporal loads/stores (state larger than the Infinity Cache)
+  double *t2;          // [np + 2] carry of -f0'/f0 from the first kernel to the second, or null (kernels.hip CARRY)
 };
 // full = false: first sub-step (deposit of the half-step state, nothing stored)
 // full = true : second sub-step (recompute half-step state, push, deposit, store)
