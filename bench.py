@@ -190,14 +190,9 @@ class Job:
                 if shared_gpus:
                     self.rccl_why = "ranks share GPUs (RCCL needs one GPU per rank)"
                 else:
-                    try:
-                        self.rccl_why = parallel.bootstrap_comm(self.eng, dist)
-                    except Exception as e:      # noqa: BLE001
-                        # inside ncclCommInitRank the ranks cannot agree any more: the job is
-                        # restarted by the launcher, not limped on
-                        sys.stderr.write("bench.py rank %d: RCCL communicator: %s\n" % (rank, e))
-                        sys.stderr.flush()
-                        os._exit(3)
+                    # every rank gets the same answer (pic1dp_amd/parallel.py); a communicator that
+                    # comes up on some ranks only ends the job at the process group's timeout
+                    self.rccl_why = parallel.bootstrap_comm(self.eng, dist)
                 self.have_rccl = self.rccl_why is None
             if a.allreduce in ("auto", "p2p"):
                 self.p2p_why = parallel.bootstrap_exchange(self.eng, dist)
@@ -306,8 +301,8 @@ def main():
     ndev = pic1dp_amd.device_count()
     device = local_rank % max(ndev, 1)
     shared = world > ndev
-    if shared and a.allreduce in ("auto", "rccl") and not os.environ.get("PIC1DP_BENCH_ALLOW_SHARED_GPU"):
-        sys.exit("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank; --allreduce p2p or "
+    if shared and a.allreduce == "rccl":
+        sys.exit("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank; --allreduce auto, p2p or "
                  "host rehearses the control flow on fewer)" % (world, ndev))
 
     # every rank owns one reference block of the global array (PETSC_DECIDE split)

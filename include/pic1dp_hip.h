@@ -273,6 +273,15 @@ int pic1dp_hip_step(pic1dp_ctx *ctx, int32_t nsteps);
  *     for three grid tiles in LDS
  *   1 two fused sub-steps through the RK ping-pong sets (136 B per marker) */
 int pic1dp_hip_set_step_mode(pic1dp_ctx *ctx, int32_t mode);
+/* on != 0: a time step after which the driver will call output_all (the cadence test of
+ * src/pic1dp.F90:98-107 evaluated one step ahead from the library's time, see set_time; the
+ * last step of a pic1dp_hip_step call, or the collect_charge that follows push(2)) takes the
+ * histograms of output_ptcldist and the kinetic sums of output_field inside its second
+ * kernel, on the state it has just computed: pic1dp_hip_output_scalars / pic1dp_hip_ptcldist
+ * then cost no pass over the markers.  Results equal the separate pass up to the summation
+ * order of the atomics.  Off by default (a host that never asks for output would pay ~30 % on
+ * that one kernel launch for nothing). */
+int pic1dp_hip_set_output_fusion(pic1dp_ctx *ctx, int32_t on);
 /* which field solve pic1dp_hip_solve_field / substep / step perform:
  *   0 (default) the reference's field_solve_electric: mode-filtered partial DFT
  *     (src/pic1dp_field.F90:218-270) -- the only solver with reference parity
@@ -433,7 +442,8 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
  * accumulated device milliseconds (HIP events on the context's stream) and
  * launch count of the fused push+deposit kernel (which=0), the separate push
  * kernel (1), the separate deposit kernel (2), and the whole-step kernels:
- * first sub-step k_step_half (3), second sub-step k_step_full (4) */
+ * first sub-step k_step_half (3), second sub-step k_step_full (4); which = 5: number
+ * of separate diagnostics passes (k_ptcldist) launched so far, *ms = 0 */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

@@ -131,7 +131,11 @@ struct pic1dp_ctx {
   uint64_t state_version = 1;              // bumped by everything that writes marker arrays
   std::vector<uint64_t> diag_version;      // [nspecies] version the cached results belong to
   std::vector<double> diag_sums;           // [nspecies][3]
-  double *d_diag_part = nullptr;           // per-workgroup partial sums of the fused pass
+  double *d_diag_part = nullptr;           // [nspecies][3 * diag_max_blocks] per-workgroup partial sums of the pass
+  std::vector<char> diag_pending;          // [nspecies] a pass ran, its partial sums are still on the device
+  std::vector<int> diag_blocks;            // [nspecies] workgroups of that pass
+  int fuse_output = 0;                     // take the diagnostics inside k_step_full on steps output_all follows
+  int64_t diag_passes = 0;                 // separate k_ptcldist passes launched so far
   int32_t itime = 0;
   double time = 0.0;
   GridConst grid{};
@@ -583,9 +587,13 @@ int pic1dp_hip_host_div_check(double lx, int32_t nx, int64_t n, uint64_t seed, i
 }
 
 static bool step_recompute_ok(const pic1dp_ctx *c);
-static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh);
+static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag = false);
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full);
 static size_t step_lds_bytes(int nx, bool full, int rcopies);
+static bool output_follows(const pic1dp_ctx *c);
+static int diag_buffers(pic1dp_ctx *c);
+static int diag_max_blocks(const pic1dp_ctx *c);
+static size_t dist_len(const pic1dp_input &in);
 
 int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1dp_ctx **out) {
   if (!in || !layout || !out) return fail(PIC1DP_ERR_ARG, "null argument");
@@ -654,6 +662,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     const int k = std::atoi(e);
     if (k == 1 || k == 2 || k == 4 || k == 8) c->grid.rcopies = k;
   }
+  c->grid.debug_noflush = std::getenv("PIC1DP_DEBUG_NOFLUSH") != nullptr;
   while (c->grid.rcopies > 1 && step_lds_bytes(nx, true, c->grid.rcopies) > 80 * 1024) c->grid.rcopies >>= 1;
   if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_MB"))
     c->nt_threshold_half = c->nt_threshold_full = std::atof(e) * 1048576.0;
@@ -664,8 +673,22 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   c->sp.resize(ns);
   int64_t nalloc = 0;
   for (int b = 0; b < c->nblk; ++b) nalloc += block_alloc(in->nparticle_max, c->blk0 + b, npe);
-  HIP_TRY_C(hipMalloc(&c->d_rho_sp, sizeof(double) * ns * nx));
-  HIP_TRY_C(hipMemsetAsync(c->d_rho_sp, 0, sizeof(double) * ns * nx, c->st));
+  // species charge accumulators in gcopies copies: workgroup b adds its LDS tile into copy b % gcopies,
+  // so an address receives 1/gcopies of the flush atomics; the field kernels add the copies up.
+  // Measured (tools/fresh_and_flush.sh): the flush into ONE copy costs 4.8 % of a step at 6.4e6
+  // markers / nx 192, 1.5 % at 1e7 / 256, 0.9 % at 1e8 / 1024.  Eight copies (tools/ab_global_copies.sh)
+  // win back 2 % of the step at nx 192, nothing at nx 256, and LOSE 4 % at 1.25e7 markers / nx 1024: the
+  // one-workgroup field kernel then reads and re-zeroes 8 x nx words on the critical path.  So: eight
+  // copies for small grids only.  PIC1DP_RHO_GLOBAL_COPIES overrides.
+  c->grid.gcopies = nx <= 256 ? 8 : 1;
+  if (const char *e = std::getenv("PIC1DP_RHO_GLOBAL_COPIES")) {
+    const int k = std::atoi(e);
+    if (k >= 1 && k <= 64 && (k & (k - 1)) == 0) c->grid.gcopies = k;
+  }
+  c->grid.gstride = ns * nx;
+  const size_t rho_doubles = static_cast<size_t>(c->grid.gcopies) * ns * nx;
+  HIP_TRY_C(hipMalloc(&c->d_rho_sp, sizeof(double) * rho_doubles));
+  HIP_TRY_C(hipMemsetAsync(c->d_rho_sp, 0, sizeof(double) * rho_doubles, c->st));
   for (int s = 0; s < ns; ++s) {
     Species &S = c->sp[s];
     S.nalloc = nalloc;
@@ -693,7 +716,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMalloc(&c->d_Eh, sizeof(double) * nx));
   HIP_TRY_C(hipMemsetAsync(c->d_Eh, 0, sizeof(double) * nx, c->st));
   HIP_TRY_C(hipMalloc(&c->d_E0, sizeof(double) * nx));
-  HIP_TRY_C(hipMalloc(&c->d_rho_dummy, sizeof(double) * nx));
+  HIP_TRY_C(hipMalloc(&c->d_rho_dummy, sizeof(double) * rho_doubles));
   if (const char *e = std::getenv("PIC1DP_LAZY_CALLS")) c->lazy_calls = std::atoi(e) != 0;
   if (const char *e = std::getenv("PIC1DP_CARRY")) c->carry = std::atoi(e);
   HIP_TRY_C(hipMalloc(&c->d_mode_re, sizeof(double) * nm));
@@ -732,6 +755,8 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   }
   FieldArgs &f = c->fa;
   f.rho_sp = c->d_rho_sp;
+  f.rho_copies = c->grid.gcopies;
+  f.rho_stride = c->grid.gstride;
   f.charge = c->d_charge;
   f.chargeden = c->d_chargeden;
   f.E = c->d_E;
@@ -1016,7 +1041,6 @@ static int require_loaded(pic1dp_ctx *c) {
 // ---------------------------------------------------------------------------
 static bool step_recompute_ok(const pic1dp_ctx *c);
 static bool optimize_due_any(const pic1dp_ctx *c);
-static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh);
 
 static bool lazy_ok(const pic1dp_ctx *c) {
   return c->lazy_calls && step_recompute_ok(c) && !optimize_due_any(c);
@@ -1056,8 +1080,8 @@ static int deposit_or_step(pic1dp_ctx *c) {
     return 0;
   }
   if (c->lz == LZ_PUSH2) {
-    if (int rc = step_particles(c, true, c->d_E0, c->d_E)) return rc;
     c->state_version++;
+    if (int rc = step_particles(c, true, c->d_E0, c->d_E, c->fuse_output && output_follows(c))) return rc;
     c->lz = LZ_CLEAN;
     return 0;
   }
@@ -1324,7 +1348,25 @@ static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
 
 // the particle kernel(s) of one sub-step of the whole-step path: E0 = field at
 // the start of the step, Eh = field after the first sub-step (full only)
-static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh) {
+// does output_all follow the step that is being taken?  (src/pic1dp.F90:98-107 evaluated one step ahead)
+static bool output_follows(const pic1dp_ctx *c) {
+  const pic1dp_input &in = c->in;
+  if (!(in.output_interval > 0.0)) return false;
+  const double t = c->time + in.dt;
+  if (c->itime + 1 >= in.ntime_max || t + kSqrtEps >= in.time_max) return true;
+  return std::fmod(t + kSqrtEps, in.output_interval) < std::fmod(t + kSqrtEps - in.dt, in.output_interval);
+}
+
+static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag) {
+  // the diagnostics of output_all inside k_step_full: when asked for, the LDS holds them, and the
+  // tuning build of the marker loop is the default one
+  if (diag) {
+    const size_t need = step_lds_bytes(c->in.nx, true, c->grid.rcopies) +
+                        step_diag_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nx_opd, c->in.nv_opd);
+    if (!full || c->in.nx_opd < 1 || c->in.nv_opd < 2 || need > 160 * 1024) diag = false;
+  }
+  if (diag)
+    if (int rc = diag_buffers(c)) return rc;
   // x, v, w, p of all species against the 256 MiB Infinity Cache
   double state_bytes = 0.0;
   for (int s = 0; s < c->in.nspecies; ++s) state_bytes += 32.0 * static_cast<double>(c->sp[s].np);
@@ -1367,6 +1409,21 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       a.t2 = S.t2;
     }
     LaunchCfg lc = step_launch(c, S.np, full);
+    if (diag) {  // one workgroup of 1024 threads per CU: grid tiles + histograms in its LDS
+      const size_t ntot = dist_len(c->in);
+      a.dg = DistGeom{c->in.lx, c->in.v_max, c->in.nx_opd, c->in.nv_opd};
+      a.dist_out = c->d_dist + ntot * s;
+      a.dist_partial = c->d_diag_part + static_cast<size_t>(3) * diag_max_blocks(c) * s;
+      HIP_TRY(hipMemsetAsync(a.dist_out, 0, sizeof(double) * ntot, c->st));
+      lc.lds += step_diag_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nx_opd, c->in.nv_opd);
+      lc.threads = 1024;
+      int64_t blocks = c->num_cu;
+      const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
+      lc.blocks = static_cast<int>(std::max<int64_t>(1, std::min(blocks, need)));
+      c->diag_blocks[s] = lc.blocks;
+      c->diag_pending[s] = 1;
+      c->diag_version[s] = c->state_version;  // the caller has bumped it for this step already
+    }
     Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
     Span ks(c, full ? kTagStepFull : kTagStepHalf, c->stats_on);
     HIP_TRY(launch_step(a, full, lc, c->st));
@@ -1377,9 +1434,9 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
 }
 
 // sub-step of the whole-step path: particle kernel(s), charge, field into Eout
-static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record) {
+static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool diag = false) {
   if (full) c->state_version++;
-  if (int rc = step_particles(c, full, c->d_E, c->d_Eh)) return rc;
+  if (int rc = step_particles(c, full, c->d_E, c->d_Eh, diag)) return rc;
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   const bool fused_xchg = xchg_active(c) && c->field_solver == 0;  // exchange inside the solve's launch
   if (multi && !fused_xchg)
@@ -1406,7 +1463,9 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
     if (recompute && !optimize_due_any(c)) {
       // E0 = d_E stays untouched until the second solve overwrites it
       if (int rc = step_phase(c, false, c->d_Eh, false)) return rc;
-      if (int rc = step_phase(c, true, c->d_E, true)) return rc;
+      // the host can only call output_all after the last step of this call
+      const bool diag = c->fuse_output && it == nsteps - 1 && output_follows(c);
+      if (int rc = step_phase(c, true, c->d_E, true, diag)) return rc;
     } else {
       if (int rc = substep_impl(c, 1, false)) return rc;
       HIP_TRY(hipMemcpyAsync(c->d_Eh, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
@@ -1422,6 +1481,12 @@ int pic1dp_hip_set_step_mode(pic1dp_ctx *c, int32_t mode) {
   CHECK_CTX(c);
   if (mode != 0 && mode != 1) return fail(PIC1DP_ERR_ARG, "step mode must be 0 or 1");
   c->step_mode = mode;
+  return 0;
+}
+
+int pic1dp_hip_set_output_fusion(pic1dp_ctx *c, int32_t on) {
+  CHECK_CTX(c);
+  c->fuse_output = on != 0;
   return 0;
 }
 
@@ -1544,48 +1609,69 @@ static size_t dist_len(const pic1dp_input &in) {
   return 3 * static_cast<size_t>(in.nx_opd) * in.nv_opd + 3 * static_cast<size_t>(in.nv_opd);
 }
 
-static int ensure_diag(pic1dp_ctx *c, int isp) {
+static int diag_max_blocks(const pic1dp_ctx *c) { return 2 * c->num_cu; }
+
+// buffers of the marker diagnostics: [nspecies] cached histograms + one for the all-reduced
+// copy handed out, per-workgroup partial sums per species
+static int diag_buffers(pic1dp_ctx *c) {
   const pic1dp_input &in = c->in;
   const int ns = in.nspecies;
   if (in.nx_opd < 1 || in.nv_opd < 2) return fail(PIC1DP_ERR_ARG, "nx_opd >= 1 and nv_opd >= 2 required");
   if (c->diag_version.empty()) {
     c->diag_version.assign(ns, 0);
     c->diag_sums.assign(3 * static_cast<size_t>(ns), 0.0);
+    c->diag_pending.assign(ns, 0);
+    c->diag_blocks.assign(ns, 0);
   }
-  if (c->diag_version[isp] == c->state_version) return 0;
+  if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * dist_len(in) * (ns + 1)));
+  if (!c->d_diag_part) HIP_TRY(hipMalloc(&c->d_diag_part, sizeof(double) * 3 * diag_max_blocks(c) * ns));
+  return 0;
+}
+
+static int ensure_diag(pic1dp_ctx *c, int isp) {
+  const pic1dp_input &in = c->in;
+  if (int rc = diag_buffers(c)) return rc;
   const size_t ntot = dist_len(in);
-  // [nspecies] cached histograms + one buffer for the all-reduced copy handed out
-  if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * ntot * (ns + 1)));
-  const int max_blocks = 2 * c->num_cu;
-  if (!c->d_diag_part) HIP_TRY(hipMalloc(&c->d_diag_part, sizeof(double) * 3 * max_blocks));
   Species &S = c->sp[isp];
-  const PSet &A = S.set[c->cur];
-  double *hist = c->d_dist + ntot * isp;
-  HIP_TRY(hipMemsetAsync(hist, 0, sizeof(double) * ntot, c->st));
+  double *part_dev = c->d_diag_part + static_cast<size_t>(3) * diag_max_blocks(c) * isp;
+  if (c->diag_version[isp] != c->state_version) {  // no pass has seen these markers yet: run one
+    const PSet &A = S.set[c->cur];
+    double *hist = c->d_dist + ntot * isp;
+    HIP_TRY(hipMemsetAsync(hist, 0, sizeof(double) * ntot, c->st));
+    c->diag_blocks[isp] = 0;
+    if (S.np > 0) {
+      c->diag_blocks[isp] = ptcldist_blocks(S.np, in.nx_opd, in.nv_opd, c->num_cu);
+      HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, in.lx, in.v_max, in.nx_opd, in.nv_opd, in.deltaf == 1, hist,
+                              part_dev, c->num_cu, c->st));
+      c->diag_passes++;
+    }
+    c->diag_pending[isp] = 1;
+    c->diag_version[isp] = c->state_version;
+  }
+  if (!c->diag_pending[isp]) return 0;
+  // collect: partial kinetic sums of the pass (k_ptcldist, or k_step_full's DIAG variant), workgroup order
   double *sums = &c->diag_sums[3 * static_cast<size_t>(isp)];
   sums[0] = sums[1] = sums[2] = 0.0;
-  std::vector<double> part(3 * static_cast<size_t>(std::max(max_blocks, kEnergyBlocks)));
-  if (S.np > 0) {
-    const int blocks = ptcldist_blocks(S.np, in.nx_opd, in.nv_opd, c->num_cu);
-    HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, in.lx, in.v_max, in.nx_opd, in.nv_opd, in.deltaf == 1, hist,
-                            c->d_diag_part, c->num_cu, c->st));
+  std::vector<double> part(3 * static_cast<size_t>(std::max(diag_max_blocks(c), kEnergyBlocks)));
+  const int blocks = c->diag_blocks[isp];
+  if (blocks > 0) {
     HIP_TRY(hipStreamSynchronize(c->st));
-    HIP_TRY(hipMemcpy(part.data(), c->d_diag_part, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(part.data(), part_dev, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
     for (int b = 0; b < blocks; ++b)
       for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
   }
   // the reference sums the whole local vector (VecSum); slots beyond np live in set 0
   const int64_t ntail = S.nalloc - S.np;
   if (ntail > 0) {
-    const int blocks = static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256));
-    HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, ntail, c->d_scratch, blocks,
+    const int tb = static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256));
+    HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, ntail, c->d_scratch, tb,
                                c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
-    HIP_TRY(hipMemcpy(part.data(), c->d_scratch, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
-    for (int b = 0; b < blocks; ++b)
+    HIP_TRY(hipMemcpy(part.data(), c->d_scratch, sizeof(double) * tb * 3, hipMemcpyDeviceToHost));
+    for (int b = 0; b < tb; ++b)
       for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
   }
-  c->diag_version[isp] = c->state_version;
+  c->diag_pending[isp] = 0;
   return 0;
 }
 
@@ -2092,7 +2178,12 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 4) return fail(PIC1DP_ERR_ARG, "which must be 0..4");
+  if (which < 0 || which > 5) return fail(PIC1DP_ERR_ARG, "which must be 0..5");
+  if (which == 5) {  // separate diagnostics passes (k_ptcldist): a count, no time
+    if (ms) *ms = 0.0;
+    if (launches) *launches = c->diag_passes;
+    return 0;
+  }
   if (int rc = ev_resolve(c)) return rc;
   if (ms) *ms = c->acc_ms[kTagFused + which];
   if (launches) *launches = c->acc_n[kTagFused + which];

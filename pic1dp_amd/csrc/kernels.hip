@@ -310,14 +310,16 @@ __device__ __forceinline__ void zero_rho(double *sR, const GridConst &g) {
 }
 __device__ __forceinline__ void flush_rho(const double *sR, double *rho, const GridConst &g) {
   // one global atomic per cell per workgroup; start cell rotated by workgroup
+  if (g.debug_noflush) return;
   const int nx = g.nx;
+  rho += static_cast<size_t>(blockIdx.x & (g.gcopies - 1)) * g.gstride;
   const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);
   for (int i = threadIdx.x; i < nx; i += blockDim.x) {
     int j = i + rot;
     if (j >= nx) j -= nx;
     double val = sR[j];
     for (int c = 1; c < g.rcopies; ++c) val += sR[c * nx + j];
-    if (val != 0.0) glb_add(&rho[j], val);
+    if (val != 0.0) glb_add(&rho[j], val);  // rho: this workgroup's copy of the accumulator
   }
 }
 
@@ -396,6 +398,120 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// diagnostics of output_all, per marker (used by k_ptcldist and by the DIAG variant of
+// k_step_full): src/pic1dp_output.F90:126-151 (kinetic sums) and :239-315 (histograms)
+// ---------------------------------------------------------------------------
+struct DistBins {
+  double *h;       // base of [markr_xv | total_xv | pertb_xv | markr_v | total_v | pertb_v]
+  int nxv, nv;     // nx_opd*nv_opd, nv_opd
+  __device__ __forceinline__ double *xv(int k) const { return h + static_cast<size_t>(k) * nxv; }
+  __device__ __forceinline__ double *vv(int k) const { return h + static_cast<size_t>(3) * nxv + k * nv; }
+};
+struct DistSums {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;  // sum v^2, v^2 p, v^2 w of this thread
+};
+
+template <bool LDS>
+__device__ __forceinline__ void bin_add(double *p, double v) {
+  if constexpr (LDS) {
+    lds_add(p, v);
+  } else {
+    glb_add(p, v);
+  }
+}
+
+template <bool LDS, bool DELTAF>
+__device__ __forceinline__ void ptcldist_one(double px, double pv, double pp, double pw, const DistGeom &dg,
+                                             const DistBins &b, DistSums &sm) {
+  const int nxo = dg.nxo, nvo = dg.nvo;
+  const double v2 = pv * pv;
+  sm.s0 += v2;
+  sm.s1 += v2 * pp;
+  if constexpr (DELTAF) sm.s2 += v2 * pw;
+  if (fabs(pv) >= dg.vmax) return;                      // :241
+  double sx = px / dg.lx * static_cast<double>(nxo);    // :243
+  const double fx = floor(sx);
+  int ix = static_cast<int>(fx);
+  sx = 1.0 - (sx - fx);
+  double sv = (pv + dg.vmax) / (dg.vmax * 2.0) * static_cast<double>(nvo - 1);  // :247
+  const double fv = floor(sv);
+  const int iv = static_cast<int>(fv);
+  sv = 1.0 - (sv - fv);
+  // memory safety only (the reference would write out of bounds)
+  if (static_cast<unsigned>(ix) >= static_cast<unsigned>(nxo) || iv < 0 || iv + 1 >= nvo) return;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int a = iv * nxo + ix, c = (iv + 1) * nxo + ix;
+    bin_add<LDS>(&b.xv(0)[a], sx * sv);
+    bin_add<LDS>(&b.xv(1)[a], sx * sv * pp);
+    if constexpr (DELTAF) bin_add<LDS>(&b.xv(2)[a], sx * sv * pw);
+    bin_add<LDS>(&b.xv(0)[c], sx * (1.0 - sv));
+    bin_add<LDS>(&b.xv(1)[c], sx * (1.0 - sv) * pp);
+    if constexpr (DELTAF) bin_add<LDS>(&b.xv(2)[c], sx * (1.0 - sv) * pw);
+    ix = ix + 1;                                        // :274-276
+    if (ix > nxo - 1) ix = 0;
+    sx = 1.0 - sx;
+  }
+  if constexpr (!LDS) {                                 // :300-314
+    bin_add<LDS>(&b.vv(0)[iv], sv);
+    bin_add<LDS>(&b.vv(1)[iv], sv * pp);
+    if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv], sv * pw);
+    bin_add<LDS>(&b.vv(0)[iv + 1], 1.0 - sv);
+    bin_add<LDS>(&b.vv(1)[iv + 1], (1.0 - sv) * pp);
+    if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv + 1], (1.0 - sv) * pw);
+  }
+}
+
+// sum reduced over the workgroup (tree order); valid on thread 0
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (blockDim.x >> 6); ++w) t += scratch[w];
+  return t;
+}
+
+// per-workgroup partial kinetic sums, v histograms as row sums, flush of the LDS copy
+template <bool LDS, bool DELTAF>
+__device__ __forceinline__ void ptcldist_finish(const DistGeom &dg, const DistBins &b, const DistSums &sm, double *scr,
+                                                double *out, double *partial) {
+  const int nxo = dg.nxo, nvo = dg.nvo, ntot = 3 * nxo * nvo + 3 * nvo;
+  if (partial) {
+    const double t0 = block_sum(sm.s0, scr);
+    const double t1 = block_sum(sm.s1, scr);
+    const double t2 = block_sum(sm.s2, scr);
+    if (threadIdx.x == 0) {
+      partial[blockIdx.x * 3 + 0] = t0;
+      partial[blockIdx.x * 3 + 1] = t1;
+      partial[blockIdx.x * 3 + 2] = t2;
+    }
+  }
+  if constexpr (LDS) {
+    __syncthreads();
+    // v histograms = row sums of the (x,v) histograms, one thread per (k, iv)
+    for (int t = threadIdx.x; t < (DELTAF ? 3 : 2) * nvo; t += blockDim.x) {
+      const int k = t / nvo, iv = t - k * nvo;
+      const double *row = b.xv(k) + static_cast<size_t>(iv) * nxo;
+      double acc = 0.0;
+      for (int ix = 0; ix < nxo; ++ix) acc += row[ix];
+      b.vv(k)[iv] = acc;
+    }
+    __syncthreads();
+    const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * ntot) / gridDim.x);
+    for (int i = threadIdx.x; i < ntot; i += blockDim.x) {
+      int j = i + rot;
+      if (j >= ntot) j -= ntot;
+      const double val = b.h[j];
+      if (val != 0.0) glb_add(&out[j], val);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Whole-time-step kernels (pic1dp_hip_step): the half-step state is never
 // written to memory.  RK2 (midpoint) needs, for the second sub-step, the state
 // after the first one; instead of storing it (24 B) and loading it back (24 B)
@@ -420,6 +536,10 @@ struct StepArgsDev {
   SpeciesConst s;
   int nt;
   double *t2;  // [np + 2] -f0'/f0 at the step-start velocity, carried from k_step_half to k_step_full (or null)
+  // DIAG variant of k_step_full: the diagnostics of output_all taken on the new state in the same pass
+  DistGeom dg;
+  double *dist_out;      // histograms [3*nxo*nvo + 3*nvo] of this species (accumulated with atomics), or null
+  double *dist_partial;  // [gridDim][3] kinetic sums per workgroup
 };
 
 // CARRY: a species whose divisor constants are general numbers spends most of either kernel
@@ -516,7 +636,11 @@ __device__ __forceinline__ One step_full_one(double x, double v, double w, doubl
   return n;
 }
 
-template <int DIST, int MODE, int POW2, bool NT, bool CARRY>
+// DIAG: on a step after which the host will call output_all, the histograms of output_ptcldist and
+// the kinetic sums of output_field (k_ptcldist's work: another 32 B per marker read) are taken here on
+// the state just computed, into an LDS copy of the histograms next to the grid tiles (one workgroup
+// of 1024 threads per CU then).
+template <int DIST, int MODE, int POW2, bool NT, bool CARRY, bool DIAG>
 __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nx = a.g.nx;
@@ -533,10 +657,17 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
     sE0[nx] = a.E0[0];
     sEh[nx] = a.Eh[0];
   }
-  __syncthreads();
-  double *sR = my_rho_copy(sR0, a.g);
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
+  // DIAG: histograms behind the rho copies (16-byte aligned), then the block_sum scratch
+  double *sH = sR0 + ((nx * a.g.rcopies + 1) & ~1);
+  const int ntot = DIAG ? 3 * a.dg.nxo * a.dg.nvo + 3 * a.dg.nvo : 0;
+  const DistBins bins{sH, a.dg.nxo * a.dg.nvo, a.dg.nvo};
+  DistSums sums;
+  if constexpr (DIAG)
+    for (int i = threadIdx.x; i < ntot; i += blockDim.x) sH[i] = 0.0;
+  __syncthreads();
+  double *sR = my_rho_copy(sR0, a.g);
   const int64_t npair = a.np >> 1;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   double2 *x2 = reinterpret_cast<double2 *>(a.x);
@@ -605,6 +736,10 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
     st2t<NT>(x2 + o, n0.x, n1.x);
     if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
     if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
+    if constexpr (DIAG) {
+      ptcldist_one<true, HAS_W>(n0.x, n0.v, P.x, n0.w, a.dg, bins, sums);
+      ptcldist_one<true, HAS_W>(n1.x, n1.v, P.y, n1.w, a.dg, bins, sums);
+    }
   }
 #endif
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -615,9 +750,11 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
     a.x[i] = n.x;
     if constexpr (PUSH_V) a.v[i] = n.v;
     if constexpr (HAS_W) a.w[i] = n.w;
+    if constexpr (DIAG) ptcldist_one<true, HAS_W>(n.x, n.v, a.p[i], n.w, a.dg, bins, sums);
   }
   __syncthreads();
   flush_rho(sR0, a.rho, a.g);
+  if constexpr (DIAG) ptcldist_finish<true, HAS_W>(a.dg, bins, sums, sH + ntot, a.dist_out, a.dist_partial);
 }
 
 template <typename K>
@@ -633,10 +770,15 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc,
 
 template <int DIST, int MODE, int POW2, bool CARRY = false>
 hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
+#if PIC1DP_STEP_PIPE == 0
+  if (full && d.dist_out)  // with the diagnostics of output_all
+    return d.nt ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY, true>, d, lc, st)
+                : launch_step_kernel(k_step_full<DIST, MODE, POW2, false, CARRY, true>, d, lc, st);
+#endif
   if (d.nt)
-    return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY>, d, lc, st)
+    return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY, false>, d, lc, st)
                 : launch_step_kernel(k_step_half<DIST, MODE, POW2, true, CARRY>, d, lc, st);
-  return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, false, CARRY>, d, lc, st)
+  return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, false, CARRY, false>, d, lc, st)
               : launch_step_kernel(k_step_half<DIST, MODE, POW2, false, CARRY>, d, lc, st);
 }
 
@@ -765,6 +907,9 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.s = a.s;
   d.nt = a.stream_nt;
   d.t2 = a.t2;
+  d.dg = a.dg;
+  d.dist_out = a.dist_out;
+  d.dist_partial = a.dist_partial;
   switch (a.iptcldist) {
     case 1: return launch_step_d<1>(d, a.deltaf, a.linear, full, lc, st);
     case 2: return launch_step_d<2>(d, a.deltaf, a.linear, full, lc, st);
@@ -803,8 +948,13 @@ __device__ __forceinline__ double charge_local_one(const FieldArgs &f, int ix) {
   double c2 = 0.0;
   for (int s = 0; s < f.nspecies; ++s) {
     double *r = f.rho_sp + static_cast<size_t>(s) * f.nx + ix;
-    c2 = c2 + *r * f.Z[s];
+    double c1 = *r;
     *r = 0.0;
+    for (int g = 1; g < f.rho_copies; ++g) {  // the copies the workgroups flushed into
+      c1 = c1 + r[static_cast<size_t>(g) * f.rho_stride];
+      r[static_cast<size_t>(g) * f.rho_stride] = 0.0;
+    }
+    c2 = c2 + c1 * f.Z[s];
   }
   f.charge[ix] = c2;
   return c2;
@@ -829,19 +979,6 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_chargeden(const FieldArgs f) 
     f.chargeden[ix] = chargeden_from(f, WITH_LOCAL ? charge_local_one(f, ix) : f.charge[ix]);
 }
 
-// sum of squares reduced over the workgroup (tree order)
-__device__ __forceinline__ double block_sum(double v, double *scratch) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) scratch[wave] = v;
-  __syncthreads();
-  double t = 0.0;
-  if (threadIdx.x == 0)
-    for (int w = 0; w < (blockDim.x >> 6); ++w) t += scratch[w];
-  return t;  // valid on thread 0
-}
-
 // field_solve_electric, src/pic1dp_field.F90:231-257, with the one-rank PETSc
 // summation order: forward sums run over ascending ix in ONE thread per
 // (mode, re/im) so the result is bit-identical to the sequential CPU loop.
@@ -863,7 +1000,12 @@ __device__ __forceinline__ void solve_fill_chargeden(const FieldArgs &f, double 
         if constexpr (FROM_CD) {
           c[u] = f.chargeden[ix];
         } else if constexpr (WITH_LOCAL) {  // src/pic1dp_interaction.F90:126-127
-          for (int sp = 0; sp < f.nspecies; ++sp) c[u] = c[u] + f.rho_sp[static_cast<size_t>(sp) * nx + ix] * f.Z[sp];
+          for (int sp = 0; sp < f.nspecies; ++sp) {
+            const double *r = f.rho_sp + static_cast<size_t>(sp) * nx + ix;
+            double c1 = *r;
+            for (int g = 1; g < f.rho_copies; ++g) c1 = c1 + r[static_cast<size_t>(g) * f.rho_stride];
+            c[u] = c[u] + c1 * f.Z[sp];
+          }
         } else {
           c[u] = f.charge[ix];
         }
@@ -876,7 +1018,9 @@ __device__ __forceinline__ void solve_fill_chargeden(const FieldArgs &f, double 
         double cd = c[u];
         if constexpr (!FROM_CD) {
           if constexpr (WITH_LOCAL) {
-            for (int sp = 0; sp < f.nspecies; ++sp) f.rho_sp[static_cast<size_t>(sp) * nx + ix] = 0.0;
+            for (int sp = 0; sp < f.nspecies; ++sp)
+              for (int g = 0; g < f.rho_copies; ++g)
+                f.rho_sp[static_cast<size_t>(g) * f.rho_stride + static_cast<size_t>(sp) * nx + ix] = 0.0;
             f.charge[ix] = c[u];
           }
           cd = chargeden_from(f, c[u]);
@@ -1400,22 +1544,6 @@ k_cell_indices(const double *x, int64_t np, const GridConst g, int32_t *ixo,
 
 namespace {
 
-struct DistBins {
-  double *h;       // base of [markr_xv | total_xv | pertb_xv | markr_v | total_v | pertb_v]
-  int nxv, nv;     // nx_opd*nv_opd, nv_opd
-  __device__ __forceinline__ double *xv(int k) const { return h + static_cast<size_t>(k) * nxv; }
-  __device__ __forceinline__ double *vv(int k) const { return h + static_cast<size_t>(3) * nxv + k * nv; }
-};
-
-template <bool LDS>
-__device__ __forceinline__ void bin_add(double *p, double v) {
-  if constexpr (LDS) {
-    lds_add(p, v);
-  } else {
-    glb_add(p, v);
-  }
-}
-
 // One pass over a species for everything output_all needs from the markers:
 // * the (x,v) and v histograms of output_ptcldist, src/pic1dp_output.F90:239-315:
 //   4-point bilinear weights on an nx_opd x nv_opd grid, markers with
@@ -1429,94 +1557,26 @@ __device__ __forceinline__ void bin_add(double *p, double v) {
 // histograms -- the same numbers in exact arithmetic, (sx + (1-sx))*sv = sv, and
 // within rounding (<= 1e-15 relative per term) of the separate accumulation.
 // LDS = false (grids too large for 160 KiB) adds everything straight to memory.
+// The per-marker part and the finish are shared with the DIAG variant of k_step_full.
 template <bool LDS, bool DELTAF>
 __global__ void __launch_bounds__(1024)
-k_ptcldist(const double *x, const double *v, const double *p, const double *w, int64_t np, double lx,
-           double vmax, int nxo, int nvo, double *out, double *partial) {
+k_ptcldist(const double *x, const double *v, const double *p, const double *w, int64_t np, const DistGeom dg,
+           double *out, double *partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nxv = nxo * nvo;
-  const int ntot = 3 * nxv + 3 * nvo;
-  DistBins b{LDS ? reinterpret_cast<double *>(smem) : out, nxv, nvo};
+  const int ntot = 3 * dg.nxo * dg.nvo + 3 * dg.nvo;
+  DistBins b{LDS ? reinterpret_cast<double *>(smem) : out, dg.nxo * dg.nvo, dg.nvo};
   double *scr = reinterpret_cast<double *>(smem) + (LDS ? ntot : 0);  // [16]
   if constexpr (LDS) {
     for (int i = threadIdx.x; i < ntot; i += blockDim.x) b.h[i] = 0.0;
     __syncthreads();
   }
-  const double dnxo = static_cast<double>(nxo), dnv1 = static_cast<double>(nvo - 1);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  DistSums sm;
   for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < np; k += stride) {
     const int64_t i = tidx(k);
-    const double pv = v[i];
-    const double pp = p[i];
-    const double pw = DELTAF ? w[i] : 0.0;
-    const double v2 = pv * pv;
-    s0 += v2;
-    s1 += v2 * pp;
-    if constexpr (DELTAF) s2 += v2 * pw;
-    if (fabs(pv) >= vmax) continue;                       // :241
-    const double px = x[i];
-    double sx = px / lx * dnxo;                           // :243
-    const double fx = floor(sx);
-    int ix = static_cast<int>(fx);
-    sx = 1.0 - (sx - fx);
-    double sv = (pv + vmax) / (vmax * 2.0) * dnv1;        // :247
-    const double fv = floor(sv);
-    const int iv = static_cast<int>(fv);
-    sv = 1.0 - (sv - fv);
-    // memory safety only (the reference would write out of bounds)
-    if (static_cast<unsigned>(ix) >= static_cast<unsigned>(nxo) || iv < 0 || iv + 1 >= nvo) continue;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int a = iv * nxo + ix, c = (iv + 1) * nxo + ix;
-      bin_add<LDS>(&b.xv(0)[a], sx * sv);
-      bin_add<LDS>(&b.xv(1)[a], sx * sv * pp);
-      if constexpr (DELTAF) bin_add<LDS>(&b.xv(2)[a], sx * sv * pw);
-      bin_add<LDS>(&b.xv(0)[c], sx * (1.0 - sv));
-      bin_add<LDS>(&b.xv(1)[c], sx * (1.0 - sv) * pp);
-      if constexpr (DELTAF) bin_add<LDS>(&b.xv(2)[c], sx * (1.0 - sv) * pw);
-      ix = ix + 1;                                        // :274-276
-      if (ix > nxo - 1) ix = 0;
-      sx = 1.0 - sx;
-    }
-    if constexpr (!LDS) {                                 // :300-314
-      bin_add<LDS>(&b.vv(0)[iv], sv);
-      bin_add<LDS>(&b.vv(1)[iv], sv * pp);
-      if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv], sv * pw);
-      bin_add<LDS>(&b.vv(0)[iv + 1], 1.0 - sv);
-      bin_add<LDS>(&b.vv(1)[iv + 1], (1.0 - sv) * pp);
-      if constexpr (DELTAF) bin_add<LDS>(&b.vv(2)[iv + 1], (1.0 - sv) * pw);
-    }
+    ptcldist_one<LDS, DELTAF>(x[i], v[i], p[i], DELTAF ? w[i] : 0.0, dg, b, sm);
   }
-  if (partial) {
-    const double t0 = block_sum(s0, scr);
-    const double t1 = block_sum(s1, scr);
-    const double t2 = block_sum(s2, scr);
-    if (threadIdx.x == 0) {
-      partial[blockIdx.x * 3 + 0] = t0;
-      partial[blockIdx.x * 3 + 1] = t1;
-      partial[blockIdx.x * 3 + 2] = t2;
-    }
-  }
-  if constexpr (LDS) {
-    __syncthreads();
-    // v histograms = row sums of the (x,v) histograms, one thread per (k, iv)
-    for (int t = threadIdx.x; t < (DELTAF ? 3 : 2) * nvo; t += blockDim.x) {
-      const int k = t / nvo, iv = t - k * nvo;
-      const double *row = b.xv(k) + static_cast<size_t>(iv) * nxo;
-      double acc = 0.0;
-      for (int ix = 0; ix < nxo; ++ix) acc += row[ix];
-      b.vv(k)[iv] = acc;
-    }
-    __syncthreads();
-    const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * ntot) / gridDim.x);
-    for (int i = threadIdx.x; i < ntot; i += blockDim.x) {
-      int j = i + rot;
-      if (j >= ntot) j -= ntot;
-      const double val = b.h[j];
-      if (val != 0.0) glb_add(&out[j], val);
-    }
-  }
+  ptcldist_finish<LDS, DELTAF>(dg, b, sm, scr, out, partial);
 }
 
 }  // namespace
@@ -1539,14 +1599,15 @@ hipError_t launch_ptcldist(const double *x, const double *v, const double *p, co
   const size_t bytes = (lds ? hist : 0) + 16 * sizeof(double);  // + block_sum scratch
   const int threads = 1024;
   const int blocks = ptcldist_blocks(np, nxo, nvo, num_cu);
+  const DistGeom dg{lx, vmax, nxo, nvo};
   auto go = [&](auto kern) -> hipError_t {
     if (lds && bytes > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), bytes, st, x, v, p, w, np, lx,
-                       vmax, nxo, nvo, out, partial);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), bytes, st, x, v, p, w, np, dg, out,
+                       partial);
     return hipGetLastError();
   };
   if (lds) return deltaf ? go(k_ptcldist<true, true>) : go(k_ptcldist<true, false>);

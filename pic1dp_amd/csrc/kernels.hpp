@@ -30,6 +30,10 @@ struct GridConst {
   int nx;
   int fast_div;  // 1: x/lx by reciprocal + two FMA corrections (bit-identical), 0: hardware division
   int rcopies;   // copies of the workgroup's LDS rho tile (1, 2, 4, 8; lane l deposits into copy l % rcopies)
+  int gcopies, gstride;  // copies of the species accumulators in memory (power of two) and doubles between them:
+                         // workgroup b flushes into copy b % gcopies (fewer atomics per address), the field
+                         // kernels add the copies up
+  int debug_noflush;  // measurement only (PIC1DP_DEBUG_NOFLUSH=1): the LDS rho tiles are not flushed (wrong charge)
 };
 
 // Marker storage.  The four arrays of a species (x, v, w, p) are NOT four separate
@@ -91,6 +95,12 @@ struct PushArgs {
   int iptcldist, deltaf, linear, irk;
 };
 
+// geometry of the output_ptcldist histograms (src/pic1dp_output.F90:203-205,243-247)
+struct DistGeom {
+  double lx, vmax;
+  int nxo, nvo;   // nx_opd, nv_opd
+};
+
 struct LaunchCfg {
   int threads;   // per workgroup
   int blocks;    // grid size
@@ -111,7 +121,15 @@ struct StepArgs {
   int iptcldist, deltaf, linear;
   int stream_nt;       // 1: non-temporal loads/stores (state larger than the Infinity Cache)
   double *t2;          // [np + 2] carry of -f0'/f0 from the first kernel to the second, or null (kernels.hip CARRY)
+  // full kernel only: take the diagnostics of output_all in the same pass (kernels.hip DIAG); dist_out null = no
+  DistGeom dg;
+  double *dist_out, *dist_partial;
 };
+// dynamic LDS of the DIAG variant beyond the grid tiles: histograms + reduction scratch
+inline size_t step_diag_lds_bytes(int nx, int rcopies, int nxo, int nvo) {
+  const size_t pad = ((static_cast<size_t>(nx) * rcopies + 1) & ~static_cast<size_t>(1)) - static_cast<size_t>(nx) * rcopies;
+  return sizeof(double) * (pad + 3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo) + 16);
+}
 // full = false: first sub-step (deposit of the half-step state, nothing stored)
 // full = true : second sub-step (recompute half-step state, push, deposit, store)
 hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStream_t st);
@@ -123,7 +141,8 @@ hipError_t launch_deposit(double *x, const double *q, double *rho, int64_t np, c
                           const LaunchCfg &lc, hipStream_t st);
 
 struct FieldArgs {
-  double *rho_sp;        // [nspecies][nx] raw per-species deposits (zeroed after use)
+  double *rho_sp;        // [rho_copies][nspecies][nx] raw per-species deposits (zeroed after use)
+  int rho_copies, rho_stride;  // copies the particle kernels flush into, doubles between them (GridConst::gcopies)
   double *charge;        // [nx] charge2 / charge1 (local sum, all-reduced in place)
   double *chargeden;     // [nx]
   double *E;             // [nx]

@@ -157,6 +157,10 @@ class Pic1dp:
         1: two fused sub-steps through the RK ping-pong sets"""
         check(self.L.pic1dp_hip_set_step_mode(self._ctx, mode))
 
+    def set_output_fusion(self, on=True):
+        """diagnostics of output_all taken inside the step that precedes it (no extra pass)"""
+        check(self.L.pic1dp_hip_set_output_fusion(self._ctx, int(on)))
+
     def set_field_solver(self, kind):
         """0: the reference's mode-filter solve (default); 1: opt-in finite-difference
         tridiagonal solve by parallel cyclic reduction (not in the reference)"""
@@ -341,6 +345,8 @@ class Pic1dp:
         and the RK2 time loop until check_termination, calling
         on_output(self) at step 0 and whenever the reference would call
         output_all.  Returns the number of steps taken."""
+        if on_output:
+            self.set_output_fusion(True)     # output steps take their diagnostics inside the step
         self.interaction_collect_charge()
         self.field_solve_electric()
         if on_output:

@@ -41,6 +41,8 @@ whole_step = (stat == 0 .and. buf(1:1) == '2')
 
 call pic1dp_hip_check(pic1dp_hip_particle_load(ctx), 'particle_load')
 call pic1dp_hip_check(pic1dp_hip_timers_enable(ctx, 1), 'timers_enable')
+! output_all is called at the reference's cadence below: steps it follows take its diagnostics along
+call pic1dp_hip_check(pic1dp_hip_set_output_fusion(ctx, 1), 'set_output_fusion')
 
 global_itime = 0
 global_time = 0.0_c_double

@@ -56,13 +56,15 @@ def agree(dist, ok):
 
 def bootstrap_comm(engine, dist=None):
     """Create the engine's RCCL communicator.  The bootstrap cannot leave a subset of
-    the ranks inside a collective: rank 0 ALWAYS broadcasts a payload (ok flag + the
-    128-byte unique id, zeros when it could not draw one), every rank adds whether it
-    can load librccl, and only when all agree does any rank enter ncclCommInitRank.
-    Returns None on success, or the reason (identical decision on every rank) why RCCL
-    is not used.  A failure INSIDE comm_init raises: by then the other ranks are in the
-    same call and the job has to be restarted (the caller exits non-zero so that the
-    launcher tears the job down).  No-op (None) for a single process."""
+    the ranks inside a collective of the host's process group: rank 0 ALWAYS broadcasts
+    a payload (ok flag + the 128-byte unique id, zeros when it could not draw one), every
+    rank adds whether it can load librccl, and only when all agree does any rank enter
+    ncclCommInitRank; afterwards the ranks agree once more on its outcome.  Returns None
+    on success, or the reason (the same decision on every rank) why RCCL is not used --
+    the caller then takes another charge sum on all ranks alike.  If ncclCommInitRank
+    fails on SOME ranks only, the others are still inside it: the failed ranks wait in
+    the agreement until the process group's timeout raises, and the launcher tears the
+    job down (bounded, never a silent hang).  No-op (None) for a single process."""
     if engine.nranks == 1:
         return None
     import torch
@@ -88,7 +90,12 @@ def bootstrap_comm(engine, dist=None):
             mine, reason = False, "rank %d cannot load librccl: %s" % (engine.rank, e)
     if not agree(dist, mine):
         return reason or "RCCL unavailable on another rank"
-    engine.comm_init(bytes(payload[1:].tolist()))
+    try:
+        engine.comm_init(bytes(payload[1:].tolist()))
+    except Exception as e:          # noqa: BLE001
+        mine, reason = False, "rank %d: %s" % (engine.rank, e)
+    if not agree(dist, mine):
+        return reason or "ncclCommInitRank failed on another rank"
     return None
 
 

@@ -106,6 +106,13 @@ def _worker(rank, world, port, q):
         for cls in (NoId, OneRankBlind):
             e = cls()
             assert parallel.bootstrap_comm(e, dist) is not None and e.got is None
+
+        class InitFailsEverywhere(FakeEngine):      # e.g. two ranks on one GPU: RCCL says "invalid usage"
+            def comm_init(self, uid):
+                raise RuntimeError("ncclCommInitRank: invalid usage")
+
+        why = parallel.bootstrap_comm(InitFailsEverywhere(), dist)
+        assert why is not None and "invalid usage" in why
         e = OneRankBlind()
         assert parallel.bootstrap_exchange(e, dist) is not None and not hasattr(e, "handles")
         q.put((rank, chargeden, int(cnt.item()), fe.got))

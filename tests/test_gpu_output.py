@@ -191,3 +191,55 @@ def test_fortran_host_drop_in(oracle_mod, amd, tmp_path):
         assert np.max(np.abs(dd.scalars[:, 1] / want[:, 1] - 1.0)) < 1e-10
         assert np.max(np.abs(dd.scalars[:, 2:] / want[:, 2:] - 1.0)) < 1e-9
         assert relerr(dd.electric[-1], sim.get_field()[0]) < 1e-10
+
+
+@pytest.mark.parametrize("kw,mode", [
+    (dict(), "step"), (dict(), "calls"), (dict(linear=1), "step"),
+    (dict(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0]), "step"),
+    (dict(iptcldist=3, species_temperature=[1.3], species_temperature2=[0.7], species_mass=[1.1]), "step"),
+    (dict(nparticle_max=150_001, species_nparticle_init=[140_000]), "step")],
+    ids=["default_step", "default_call_sites", "linear", "full_f", "general_constants_carry", "odd_with_tail_slots"])
+def test_output_diagnostics_inside_the_step(amd, kw, mode):
+    """with output fusion on, the step that precedes output_all takes the histograms of
+    output_ptcldist and the kinetic sums of output_field inside k_step_full (DIAG variant):
+    no separate pass over the markers, same numbers as the separate pass
+    (src/pic1dp_output.F90:126-151, :239-315) up to the order of the atomics"""
+    base = dict(nparticle_max=300_000, nx=128, output_interval=0.5)
+    base.update(kw)
+    engs = []
+    for fuse in (True, False):
+        e = amd.Pic1dp(amd.make_input(**base))
+        e.set_output_fusion(fuse)
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+        engs.append(e)
+    fused, plain = engs
+    nout = 0
+    for chunk in (10, 10, 7, 3):              # outputs fall due after steps 10, 20, 30 (dt 0.05, interval 0.5)
+        for e in engs:
+            if mode == "step":
+                e.step(chunk)
+            else:
+                for _ in range(chunk):
+                    for irk in (1, 2):
+                        e.interaction_push_particle(irk)
+                        e.interaction_collect_charge()
+                        e.field_solve_electric()
+                    e.set_time(e.itime + 1, e.time + e.inp.dt)
+        if not fused.output_due():
+            continue
+        nout += 1
+        before = fused.kernel_stats(5)[1]
+        a, b = fused.output_scalars(), plain.output_scalars()
+        assert np.max(np.abs(a / b - 1.0)) < 1e-12
+        pa, pb = fused.ptcldist(), plain.ptcldist()
+        for k in pa:
+            assert relerr(pa[k], pb[k]) < 1e-11, k
+        assert fused.kernel_stats(5)[1] == before          # no k_ptcldist pass was needed
+    assert nout == 3
+    assert plain.kernel_stats(5)[1] == 3 and fused.kernel_stats(5)[1] == 0
+    # and the markers are what they are without the fusion, bit for bit
+    ga, gb = fused.particles_download(), plain.particles_download()
+    for k in "xvw":
+        assert np.array_equal(ga[k], gb[k]), k

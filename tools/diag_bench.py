@@ -31,3 +31,18 @@ for name, fn in (("ptcldist (first use after a step)", lambda: eng.ptcldist(0)),
                  ("output_scalars + ptcldist = output_all", lambda: (eng.output_scalars(), eng.ptcldist(0)))):
     t = sample(lambda: (eng.step(1), eng.sync(), fn()))
     print("%-40s %.3f ms" % (name, t - t_step), flush=True)
+
+# the reference's cadence: ten steps, then output_all -- with the diagnostics taken inside the
+# tenth step (set_output_fusion) and as a separate pass
+eng.step(40)
+for fuse in (False, True, False, True):
+    eng.set_output_fusion(fuse)
+    eng.set_time(0, 0.0)
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        eng.step(10)
+        eng.output_scalars()
+        eng.ptcldist(0)
+    dt = (time.perf_counter() - t0) / 10 * 1e3
+    print("10 steps + output_all, fusion %-5s %.3f ms  (%.3f ms over 10 bare steps)" % (fuse, dt, dt - 10 * t_step), flush=True)
