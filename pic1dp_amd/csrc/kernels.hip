@@ -284,6 +284,33 @@ __device__ __forceinline__ One push_one(double x, double v, double w, double p, 
   return push_core<DIST, MODE, POW2, T2MODE>(v, w, p, xb, vb, wb, e, dt, s, dv, t2io);
 }
 
+// Measurement build only (-DPIC1DP_DEPOSIT_PREREDUCE=1, tools/ab_prereduce.sh): the wave-level
+// pre-reduction the north_star names -- lanes of a wave that hit the same cell combine their
+// values (shuffle butterfly) and ONE lane issues ONE ds_add_f64 per distinct cell.  gfx950 has no
+// lane-matching instruction, so the groups are peeled off one by one: leader = first lane still
+// to do, ballot of the lanes with its cell, wave sum of their values.  With unsorted markers a
+// wave holds ~55 distinct cells of 192 (~62 of 1024): ~60 rounds of ~20 instructions against two
+// atomics -- see DESIGN.md 3.3 for the measured table.
+#ifndef PIC1DP_DEPOSIT_PREREDUCE
+#define PIC1DP_DEPOSIT_PREREDUCE 0
+#endif
+#if PIC1DP_DEPOSIT_PREREDUCE
+__device__ __forceinline__ void lds_add_matched(double *sR, int ix, double val) {
+  const int lane = static_cast<int>(__lane_id());
+  unsigned long long todo = __ballot(1);
+  while (todo) {
+    const int lead = __ffsll(static_cast<long long>(todo)) - 1;
+    const int lix = __shfl(ix, lead, 64);
+    const bool mine = ix == lix && ((todo >> lane) & 1ULL);
+    const unsigned long long grp = __ballot(mine);
+    double v = mine ? val : 0.0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == lead) lds_add(&sR[lix], v);
+    todo &= ~grp;
+  }
+}
+#endif
+
 // wrap + linear deposit of one marker into the LDS copy of rho,
 // src/pic1dp_interaction.F90:102-113; returns the wrapped position
 __device__ __forceinline__ double deposit_one(double x, double q, double *sR, const GridConst &g) {
@@ -291,10 +318,17 @@ __device__ __forceinline__ double deposit_one(double x, double q, double *sR, co
   int ix;
   double wl;
   locate(px, g, ix, wl);
+#if PIC1DP_DEPOSIT_PREREDUCE
+  lds_add_matched(sR, ix, wl * q);
+  ix = ix + 1;
+  if (ix > g.nx - 1) ix = 0;
+  lds_add_matched(sR, ix, (1.0 - wl) * q);
+#else
   lds_add(&sR[ix], wl * q);              // :110
   ix = ix + 1;
   if (ix > g.nx - 1) ix = 0;
   lds_add(&sR[ix], (1.0 - wl) * q);      // :113
+#endif
   return px;
 }
 

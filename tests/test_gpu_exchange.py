@@ -42,6 +42,9 @@ def test_exchange_ranks_share_the_gpu(amd, tmp_path, nproc, mode):
             assert np.array_equal(r["fields"], ranks[0]["fields"])
     expect = 1 + 2 * steps
     assert all(int(r["exchanges"]) == expect for r in ranks)
+    # the exchange areas are fine-grained device memory (coherent across agents inside a kernel),
+    # not one of the fall-backs
+    assert all(int(r["memkind"]) == 1 for r in ranks)
     # one process, the same reference rank blocks as virtual ranks
     eng = amd.Pic1dp(amd.make_input(**kw), npe=nproc)
     eng.particle_load()

@@ -239,7 +239,8 @@ def test_output_diagnostics_inside_the_step(amd, kw, mode):
         assert fused.kernel_stats(5)[1] == before          # no k_ptcldist pass was needed
     assert nout == 3
     assert plain.kernel_stats(5)[1] == 3 and fused.kernel_stats(5)[1] == 0
-    # and the markers are what they are without the fusion, bit for bit
+    # and the markers are what they are without the fusion (two runs differ in the order of their
+    # charge atomics, so not bit for bit)
     ga, gb = fused.particles_download(), plain.particles_download()
     for k in "xvw":
-        assert np.array_equal(ga[k], gb[k]), k
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-10 * max(1.0, np.max(np.abs(gb[k]))), k
