@@ -346,7 +346,9 @@ def main():
 
     def kernel_table(e):
         names = ("k_push_fused", "k_push", "k_deposit", "k_step_half", "k_step_full")
-        return {nm: e.kernel_stats(k) for k, nm in enumerate(names)}
+        tab = {nm: e.kernel_stats(k) for k, nm in enumerate(names)}
+        tab["k_step_one"] = e.kernel_stats(6)
+        return tab
 
     def attribution(j, nsteps=10):
         """device time per step under the reference's timer ids (HIP events on the stream),
@@ -416,8 +418,7 @@ def main():
             s_energy = sjob.eng.field_energy()
             strong = {"value": a.strong_total * 2.0 * a.steps / s_el, "ms_per_step": s_el / a.steps * 1e3,
                       "same_run_as_headline": False,
-                      "step_half_kernel_avg_ms": stab["k_step_half"][0] / max(stab["k_step_half"][1], 1),
-                      "step_full_kernel_avg_ms": stab["k_step_full"][0] / max(stab["k_step_full"][1], 1),
+                      "particle_kernel_avg_ms": {k: v[0] / v[1] for k, v in stab.items() if v[1]},
                       "field_energy_end": s_energy, "attribution": attribution(sjob)}
         strong.update({"unit": "updates/s", "scaling": "strong", "particles_total": a.strong_total,
                        "particles_per_gpu": a.strong_total // world, "allreduce": job.kind,
@@ -478,7 +479,19 @@ def main():
         wr = 8.0 * (1 + (0 if linear else 1) + deltaf)  # x (+ v) (+ w) written by the second one
         half_ms, half_n = ktab["k_step_half"]
         full_ms, full_n = ktab["k_step_full"]
-        if full_n:
+        one_ms, one_n = ktab["k_step_one"]
+        # k_step_one hands -f0'/f0 of the new velocity to the next step through memory (8 B written,
+        # 8 B read per marker) unless PIC1DP_CARRY=0
+        carry_b = 16.0 if (deltaf and os.environ.get("PIC1DP_CARRY", "1") != "0") else 0.0
+        if one_n:
+            kname = ("k_step_one (one pass per step: recompute half-step state, push+gather, wrap, deposit, store in "
+                     "place, and the deposits that predict the next step's first-sub-step charge)")
+            kms, kn, kbytes = one_ms, one_n, rd + wr + carry_b
+            path = ("one pass over the markers per step (k_step_one; the first sub-step's charge is predicted by the "
+                    "previous step's kernel as coefficients of the kept field modes)")
+            if a.unfused:
+                path += ", reached through the three reference call sites per sub-step (lazy call sites)"
+        elif full_n:
             kname = "k_step_full (2nd sub-step: recompute half-step state, push+gather, wrap, deposit, store in place)"
             kms, kn, kbytes = full_ms, full_n, rd + wr
             path = "whole-step kernels k_step_half + k_step_full (half-step state recomputed, not stored)"
@@ -512,7 +525,10 @@ def main():
         probe_n = int(min(np_local, 10**8))
         copy_gbs = max(eng.stream_probe(1, 1, probe_n, 10) for _ in range(3))
         shape_gbs = max(eng.stream_probe(4, 3, probe_n, 10) for _ in range(3))
-        step_bytes = (2 * rd + wr) * np_local if full_n else None
+        # bytes the timed steps had to move: every launch of the three whole-step kernels at its own price
+        step_bytes = None
+        if full_n or one_n:
+            step_bytes = (half_n * rd + full_n * (rd + wr) + one_n * (rd + wr + carry_b)) * np_local / a.steps
         out = {
             "metric": "particle-updates/sec", "value": value, "unit": "updates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "warmup_effective": a.warmup + settle,
@@ -537,19 +553,22 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kname, "avg_launch_ms": avg_ms, "launches": kn,
                 "bytes_per_marker": kbytes, "bytes_per_marker_note":
-                    "compulsory traffic of THIS kernel: %g B read (x, v, w, p) + %g B written (x, v, w); "
-                    "one launch = one particle-update per marker" % (rd, wr),
-                "updates_per_launch": np_local,
+                    "traffic THIS kernel has to move: %g B read (x, v, w, p) + %g B written (x, v, w)%s"
+                    % (rd, wr, (" + %g B carry of -f0'/f0 (8 read, 8 written); one launch = one whole time step "
+                                "(two particle-updates) per marker" % carry_b) if one_n else
+                       "; one launch = one particle-update per marker"),
+                "updates_per_launch": np_local * (2 if one_n else 1),
                 "step_half_kernel_avg_ms": half_ms / half_n if half_n else None,
                 "step_half_kernel_GBs": (rd * np_local / (half_ms / half_n * 1e-3) / 1e9) if half_n else None,
                 "whole_step_bytes": step_bytes,
                 "whole_step_GBs": (step_bytes / (elapsed / a.steps) / 1e9) if step_bytes else None,
                 "whole_step_frac": (step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS) if step_bytes else None,
-                "reference_priced_GBs": PRICED_BYTES_PER_UPDATE * np_local / (avg_ms * 1e-3) / 1e9 if kn else None,
+                "reference_priced_GBs": PRICED_BYTES_PER_UPDATE * np_local * (2 if one_n else 1) / (avg_ms * 1e-3) / 1e9
+                                        if kn else None,
                 "reference_priced_note": "SURVEY 8(d) prices a push+gather sub-step that stores and reloads the RK "
-                                         "state at 80 B per update; this design moves %g B in the second sub-step and "
-                                         "%g B in the first -- how far the restructuring beats the priced data flow, "
-                                         "not an HBM fraction" % (rd + wr, rd),
+                                         "state at 80 B per update (160 B per marker and step); this design moves %g B per "
+                                         "marker and step -- how far the restructuring beats the priced data flow, "
+                                         "not an HBM fraction" % (step_bytes / np_local if step_bytes else rd + wr),
                 "measured_copy_GBs": copy_gbs, "measured_4read_3write_GBs": shape_gbs,
                 "frac_of_measured_4read_3write": achieved / shape_gbs if shape_gbs else None,
                 "traffic_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and kn) else None,

@@ -443,7 +443,9 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
  * launch count of the fused push+deposit kernel (which=0), the separate push
  * kernel (1), the separate deposit kernel (2), and the whole-step kernels:
  * first sub-step k_step_half (3), second sub-step k_step_full (4); which = 5: number
- * of separate diagnostics passes (k_ptcldist) launched so far, *ms = 0 */
+ * of separate diagnostics passes (k_ptcldist) launched so far, *ms = 0; which = 6: the
+ * one-pass-per-step kernel k_step_one (second sub-step + prediction of the next first
+ * sub-step's charge) */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

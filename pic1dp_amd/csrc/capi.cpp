@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/pic1dp_hip.h"
@@ -50,7 +51,7 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr double kPi = 3.14159265358979323846264;        // PETSC_PI
 constexpr double kSqrtEps = 1.490116119384766e-08;       // PETSC_SQRT_MACHINE_EPSILON
-constexpr int kTagFused = 100, kTagPush = 101, kTagDeposit = 102, kTagStepHalf = 103, kTagStepFull = 104,
+constexpr int kTagFused = 100, kTagPush = 101, kTagDeposit = 102, kTagStepHalf = 103, kTagStepFull = 104, kTagStepOne = 106,
               kNumTags = 128;
 constexpr int64_t kHistCap = 1 << 20;
 constexpr int kEnergyBlocks = 1024;
@@ -67,7 +68,8 @@ struct Species {
   int64_t nalloc = 0, np = 0;
   PSet set[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   double *p = nullptr;
-  double *t2 = nullptr;   // carry of -f0'/f0 between the whole-step kernels (general species constants only)
+  double *t2 = nullptr;   // carry of -f0'/f0 between the whole-step kernels
+  uint64_t t2_version = 0;  // state_version whose step-start velocities the values in t2 belong to (0: none)
   double *slab[2] = {nullptr, nullptr};  // tiled storage of set 0 (+ p) and of the RK ping-pong set (kernels.hpp)
   double *rho = nullptr;  // slice of rho_sp
   SpeciesConst sc{};
@@ -99,6 +101,14 @@ struct pic1dp_ctx {
   double *d_rho_sp = nullptr, *d_charge = nullptr, *d_chargeden = nullptr, *d_E = nullptr;
   double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
   double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
+  // one pass per step (kernels.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
+  // prediction accumulators [nspecies][1 + 2 nm][nx], the combined half-step charge density
+  double *d_tabA = nullptr, *d_tabB = nullptr, *d_pred = nullptr, *d_cd_h = nullptr, *d_mode_h = nullptr;
+  double *d_Ehn = nullptr;         // half-step field predicted for the NEXT step (d_Eh stays the last step's)
+  int predict = 1;                 // PIC1DP_PREDICT=0: always two passes per step
+  uint64_t pred_version = 0;       // state_version the accumulators in d_pred belong to (0: none)
+  uint64_t eh_version = 0;         // state_version d_Eh has been predicted for (step() path)
+  uint64_t field_version = 1, eh_field_version = 0, modes_field_version = 0;  // who wrote d_E last
   double *d_stage = nullptr;  // contiguous staging buffer between host arrays and the tiled marker arrays
   double *d_Eh = nullptr;  // field after the first sub-step of the last whole-step call
   // The reference's three call sites at whole-step cost (see "lazy call sites"
@@ -587,10 +597,15 @@ int pic1dp_hip_host_div_check(double lx, int32_t nx, int64_t n, uint64_t seed, i
 }
 
 static bool step_recompute_ok(const pic1dp_ctx *c);
-static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag = false);
+static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag = false,
+                          bool pred = false);
+static bool predict_capable(const pic1dp_ctx *c);
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full);
 static size_t step_lds_bytes(int nx, bool full, int rcopies);
 static bool output_follows(const pic1dp_ctx *c);
+static void field_written(pic1dp_ctx *c, bool by_solve);
+static bool pred_usable(const pic1dp_ctx *c);
+static int pred_to_charge(pic1dp_ctx *c);
 static int diag_buffers(pic1dp_ctx *c);
 static int diag_max_blocks(const pic1dp_ctx *c);
 static size_t dist_len(const pic1dp_input &in);
@@ -719,6 +734,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMalloc(&c->d_rho_dummy, sizeof(double) * rho_doubles));
   if (const char *e = std::getenv("PIC1DP_LAZY_CALLS")) c->lazy_calls = std::atoi(e) != 0;
   if (const char *e = std::getenv("PIC1DP_CARRY")) c->carry = std::atoi(e);
+  if (const char *e = std::getenv("PIC1DP_PREDICT")) c->predict = std::atoi(e);
   HIP_TRY_C(hipMalloc(&c->d_mode_re, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_mode_im, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_fre, sizeof(double) * nm * nx));
@@ -748,6 +764,20 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
         const double th = 2.0 * kPi / static_cast<double>(nx) * mode * static_cast<double>(ix);  // :196
         fim[static_cast<size_t>(m) * nx + ix] = -sin_fn(th);
       }
+    }
+    if (nm <= PRED_MAX_MODES) {  // k_step_one's tables: E = 2*(cos re + (-sin) im) (src/pic1dp_field.F90:251-257)
+      std::vector<double> ta(fre.size()), tb(fim.size());
+      for (size_t i = 0; i < fre.size(); ++i) ta[i] = 2.0 * fre[i], tb[i] = 2.0 * fim[i];
+      const size_t pred_doubles = static_cast<size_t>(ns) * (1 + 2 * nm) * nx;
+      HIP_TRY_C(hipMalloc(&c->d_tabA, sizeof(double) * nm * nx));
+      HIP_TRY_C(hipMalloc(&c->d_tabB, sizeof(double) * nm * nx));
+      HIP_TRY_C(hipMalloc(&c->d_pred, sizeof(double) * pred_doubles));
+      HIP_TRY_C(hipMalloc(&c->d_cd_h, sizeof(double) * nx));
+      HIP_TRY_C(hipMalloc(&c->d_Ehn, sizeof(double) * nx));
+      HIP_TRY_C(hipMalloc(&c->d_mode_h, sizeof(double) * 2 * nm));
+      HIP_TRY_C(hipMemcpy(c->d_tabA, ta.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
+      HIP_TRY_C(hipMemcpy(c->d_tabB, tb.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
+      HIP_TRY_C(hipMemset(c->d_pred, 0, sizeof(double) * pred_doubles));
     }
     HIP_TRY_C(hipMemcpy(c->d_fre, fre.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
     HIP_TRY_C(hipMemcpy(c->d_fim, fim.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
@@ -803,7 +833,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     (void)hipFree(S.t2);
   }
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
-                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage};
+                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred, c->d_cd_h, c->d_mode_h, c->d_Ehn};
   for (double *b : bufs) (void)hipFree(b);
   for (double *b : c->probe_keep) (void)hipFree(b);
   for (auto &e : c->evpool) {
@@ -1081,7 +1111,8 @@ static int deposit_or_step(pic1dp_ctx *c) {
   }
   if (c->lz == LZ_PUSH2) {
     c->state_version++;
-    if (int rc = step_particles(c, true, c->d_E0, c->d_E, c->fuse_output && output_follows(c))) return rc;
+    const bool diag = c->fuse_output && output_follows(c);
+    if (int rc = step_particles(c, true, c->d_E0, c->d_E, diag, !diag)) return rc;
     c->lz = LZ_CLEAN;
     return 0;
   }
@@ -1094,6 +1125,16 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   if (int rc = require_loaded_keep_lazy(c)) return rc;
   // a whole-step kernel run for a noted push is booked under "push particle"
   // (step_particles); "collect charge" then covers the reduction and scaling only
+  // after a noted push(1) whose charge the previous step's kernel has predicted (k_step_one): no
+  // pass over the markers at all -- combine, reduce, scale
+  if (c->lz == LZ_PUSH1 && pred_usable(c)) {
+    HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
+    c->lz = LZ_HALF;
+    Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
+    if (int rc = pred_to_charge(c)) return rc;
+    HIP_TRY(launch_chargeden(c->fa, false, c->st));
+    return tm.end();
+  }
   const bool noted = c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2;
   if (noted)
     if (int rc = deposit_or_step(c)) return rc;
@@ -1105,6 +1146,12 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
     if (int rc = reduce_charge(c)) return rc;
   HIP_TRY(launch_chargeden(c->fa, !multi, c->st));
   return tm.end();
+}
+
+// d_E has been written: by the mode-filter solve (the kept modes describe it) or by something else
+static void field_written(pic1dp_ctx *c, bool by_solve) {
+  c->field_version++;
+  if (by_solve && c->field_solver == 0) c->modes_field_version = c->field_version;
 }
 
 // field_solve_electric: the reference's mode-filter solve, optionally followed by
@@ -1136,6 +1183,7 @@ int pic1dp_hip_solve_field(pic1dp_ctx *c) {
   Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
   if (int rc = enqueue_field_solve(c, f, false, true)) return rc;
+  field_written(c, true);
   return tm.end();
 }
 
@@ -1302,6 +1350,7 @@ static int substep_impl(pic1dp_ctx *c, int irk, bool record) {
   } else if (int rc = enqueue_field_solve(c, f, !multi, false)) {
     return rc;
   }
+  field_written(c, true);
   return tm.end();
 }
 
@@ -1357,7 +1406,18 @@ static bool output_follows(const pic1dp_ctx *c) {
   return std::fmod(t + kSqrtEps, in.output_interval) < std::fmod(t + kSqrtEps - in.dt, in.output_interval);
 }
 
-static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag) {
+// One pass per step (kernels.hip k_step_one) needs: the mode-filter solver (the kept modes must
+// describe E), few kept modes, and LDS for E0, Eh, the mode tables and the four accumulators
+static bool predict_capable(const pic1dp_ctx *c) {
+  return c->predict && c->d_pred && c->field_solver == 0 && step_recompute_ok(c) && c->in.nmode <= PRED_MAX_MODES &&
+         step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode) <= 160 * 1024;
+}
+
+// full = true: the caller has bumped state_version for this step; the state the kernel READS is version - 1
+static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag, bool pred) {
+  if (pred && (!full || diag || !predict_capable(c))) pred = false;
+  if (pred && c->pred_version != 0)  // a prediction nobody used: the accumulators start from zero
+    HIP_TRY(hipMemsetAsync(c->d_pred, 0, sizeof(double) * c->in.nspecies * (1 + 2 * c->in.nmode) * c->in.nx, c->st));
   // the diagnostics of output_all inside k_step_full: when asked for, the LDS holds them, and the
   // tuning build of the marker loop is the default one
   if (diag) {
@@ -1404,11 +1464,36 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     // (tools/ab_pipe_carry.sh): bump-on-tail with T = 1.3, T2 = 0.7, m = 1.1 8.9e10 -> 9.85e10
     // updates/s; two-stream2 (one division fewer per exp pair) 1.05e11 either way, so only
     // bump-on-tail carries.  PIC1DP_CARRY=0 switches it off, 2 also carries for two-stream2.
-    if (c->carry && c->in.deltaf && !S.sc.pow2 && (c->in.iptcldist == 3 || (c->carry == 2 && c->in.iptcldist == 2))) {
+    const uint64_t read_version = full ? c->state_version - 1 : c->state_version;
+    const bool carry2 = c->carry && c->in.deltaf && !S.sc.pow2 && (c->in.iptcldist == 3 || (c->carry == 2 && c->in.iptcldist == 2));
+    if (carry2 && !pred) {
       if (!S.t2) HIP_TRY(hipMalloc(&S.t2, sizeof(double) * static_cast<size_t>(S.nalloc + 2)));
-      a.t2 = S.t2;
+      // the second kernel may only load what the first one stored for these very markers
+      if (!full || S.t2_version == read_version) a.t2 = S.t2;
+      if (!full) S.t2_version = c->state_version;
     }
     LaunchCfg lc = step_launch(c, S.np, full);
+    if (pred) {  // k_step_one: the full step + the prediction of the next first sub-step's charge
+      a.tabA = c->d_tabA;
+      a.tabB = c->d_tabB;
+      a.pred = c->d_pred + static_cast<size_t>(s) * (1 + 2 * c->in.nmode) * c->in.nx;
+      a.pred_nm = c->in.nmode;
+      // -f0'/f0 at the new velocity is what the NEXT step's recomputation of the half-step state
+      // needs: it goes there through memory (16 B per marker and step; k_step_one 1.45 -> 1.33 ms at
+      // 1e8 markers, tools/ab_pred.sh).  PIC1DP_CARRY=0: evaluated again instead.
+      if (c->carry && c->in.deltaf) {
+        if (!S.t2) HIP_TRY(hipMalloc(&S.t2, sizeof(double) * static_cast<size_t>(S.nalloc + 2)));
+        a.t2 = S.t2;
+        a.t2_mode = S.t2_version == read_version ? 2 : 1;
+        S.t2_version = c->state_version;
+      }
+      lc.lds = step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode);
+      const bool two = 2 * lc.lds <= 160 * 1024;
+      lc.threads = c->threads_req > 0 ? c->threads_req : (two ? 768 : 1024);
+      const int bpc = c->bpc_req > 0 ? c->bpc_req : (two ? 2 : 1);
+      const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
+      lc.blocks = static_cast<int>(std::max<int64_t>(1, std::min(static_cast<int64_t>(c->num_cu) * bpc, need)));
+    }
     if (diag) {  // one workgroup of 1024 threads per CU: grid tiles + histograms in its LDS
       const size_t ntot = dist_len(c->in);
       a.dg = DistGeom{c->in.lx, c->in.v_max, c->in.nx_opd, c->in.nv_opd};
@@ -1425,18 +1510,59 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       c->diag_version[s] = c->state_version;  // the caller has bumped it for this step already
     }
     Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
-    Span ks(c, full ? kTagStepFull : kTagStepHalf, c->stats_on);
+    Span ks(c, pred ? kTagStepOne : (full ? kTagStepFull : kTagStepHalf), c->stats_on);
     HIP_TRY(launch_step(a, full, lc, c->st));
     if (int rc = ks.end()) return rc;
     if (int rc = tm.end()) return rc;
   }
+  if (pred) c->pred_version = c->state_version;
   return 0;
 }
 
+// the prediction in d_pred describes the next first sub-step of the markers as they are, and the kept
+// modes describe the field as it is
+static bool pred_usable(const pic1dp_ctx *c) {
+  return c->pred_version != 0 && c->pred_version == c->state_version && c->modes_field_version == c->field_version &&
+         predict_capable(c);
+}
+
+// prediction -> charge1 of the next first sub-step in d_charge (combined locally, summed over ranks)
+static int pred_to_charge(pic1dp_ctx *c) {
+  HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
+  c->pred_version = 0;  // consumed: the accumulators are zero again
+  const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
+  if (!multi) return 0;
+  if (xchg_active(c)) {
+    Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
+    XchgArgs x = next_xchg_args(c);
+    x.local_in_charge = 1;
+    HIP_TRY(launch_charge_exchange(c->fa, x, c->st));
+    return sp.end();
+  }
+  return allreduce_charge(c);
+}
+
+// step() path: Eh of the NEXT step from the prediction, right after the field of the new state is solved
+static int predict_half_field(pic1dp_ctx *c) {
+  if (int rc = pred_to_charge(c)) return rc;
+  Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
+  FieldArgs f = c->fa;
+  f.chargeden = c->d_cd_h;
+  HIP_TRY(launch_chargeden(f, false, c->st));
+  f.E = c->d_Ehn;
+  f.mode_re = c->d_mode_h;
+  f.mode_im = c->d_mode_h + c->in.nmode;
+  f.history = nullptr;
+  HIP_TRY(launch_field_solve(f, false, true, c->st));
+  c->eh_version = c->state_version;
+  c->eh_field_version = c->field_version;
+  return tm.end();
+}
+
 // sub-step of the whole-step path: particle kernel(s), charge, field into Eout
-static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool diag = false) {
+static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool diag = false, bool pred = false) {
   if (full) c->state_version++;
-  if (int rc = step_particles(c, full, c->d_E, c->d_Eh, diag)) return rc;
+  if (int rc = step_particles(c, full, c->d_E, c->d_Eh, diag, pred)) return rc;
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   const bool fused_xchg = xchg_active(c) && c->field_solver == 0;  // exchange inside the solve's launch
   if (multi && !fused_xchg)
@@ -1445,11 +1571,32 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool 
   FieldArgs f = c->fa;
   f.E = Eout;
   if (record && c->hist_count < kHistCap) f.history = c->d_hist + c->hist_count++;
+  // one-pass step on one rank or with the exchange: both fields (the new state's, and the next step's
+  // half-step field from the prediction) in ONE launch
+  const bool pair = pred && c->pred_version == c->state_version && (!multi || fused_xchg) && c->field_solver == 0 &&
+                    2 * c->in.nmode <= 256 && Eout == c->d_E;
+  if (pair) {
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h};
+    if (fused_xchg) {
+      const XchgArgs x1 = next_xchg_args(c);
+      XchgArgs x2 = next_xchg_args(c);
+      x2.local_in_charge = 1;
+      HIP_TRY(launch_field_solve_pair(f, pa, &x1, &x2, c->st));
+    } else {
+      HIP_TRY(launch_field_solve_pair(f, pa, nullptr, nullptr, c->st));
+    }
+    field_written(c, true);
+    c->pred_version = 0;  // consumed
+    c->eh_version = c->state_version;
+    c->eh_field_version = c->field_version;
+    return tm.end();
+  }
   if (fused_xchg) {
     HIP_TRY(launch_field_solve_xchg(f, next_xchg_args(c), c->st));
   } else if (int rc = enqueue_field_solve(c, f, !multi, false)) {
     return rc;
   }
+  if (Eout == c->d_E) field_written(c, true);
   return tm.end();
 }
 
@@ -1462,10 +1609,21 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
     // a step in which a marker optimisation is due goes through the sub-steps
     if (recompute && !optimize_due_any(c)) {
       // E0 = d_E stays untouched until the second solve overwrites it
-      if (int rc = step_phase(c, false, c->d_Eh, false)) return rc;
+      // Eh of this step: predicted by the previous step's kernel (one pass per step), or from a
+      // first-sub-step pass over the markers
+      const bool pc = predict_capable(c);
+      const bool have_eh = pc && c->eh_version == c->state_version && c->eh_field_version == c->field_version;
+      if (have_eh) {
+        std::swap(c->d_Eh, c->d_Ehn);  // d_Eh: the half-step field of the step being taken
+      } else if (int rc = step_phase(c, false, c->d_Eh, false)) {
+        return rc;
+      }
       // the host can only call output_all after the last step of this call
       const bool diag = c->fuse_output && it == nsteps - 1 && output_follows(c);
-      if (int rc = step_phase(c, true, c->d_E, true, diag)) return rc;
+      const bool pred = pc && !diag;
+      if (int rc = step_phase(c, true, c->d_E, true, diag, pred)) return rc;
+      if (pred && c->pred_version == c->state_version)  // not already turned into Eh by the paired solve
+        if (int rc = predict_half_field(c)) return rc;
     } else {
       if (int rc = substep_impl(c, 1, false)) return rc;
       HIP_TRY(hipMemcpyAsync(c->d_Eh, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
@@ -1560,6 +1718,7 @@ int pic1dp_hip_set_electric(pic1dp_ctx *c, const double *E) {
     if (int rc = materialize(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(c->d_E, E, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
+  field_written(c, false);
   return 0;
 }
 
@@ -1982,8 +2141,15 @@ int pic1dp_hip_charge_local(pic1dp_ctx *c, double *charge2) {
   CHECK_CTX(c);
   if (!charge2) return fail(PIC1DP_ERR_ARG, "null array");
   if (int rc = require_loaded_keep_lazy(c)) return rc;
-  if (int rc = deposit_or_step(c)) return rc;
-  HIP_TRY(launch_charge_local(c->fa, c->st));
+  if (c->lz == LZ_PUSH1 && pred_usable(c)) {  // predicted by the previous step's kernel: no marker pass
+    HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
+    c->lz = LZ_HALF;
+    HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
+    c->pred_version = 0;
+  } else {
+    if (int rc = deposit_or_step(c)) return rc;
+    HIP_TRY(launch_charge_local(c->fa, c->st));
+  }
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(charge2, c->d_charge, sizeof(double) * c->in.nx, hipMemcpyDeviceToHost));
   c->charge_pending = true;
@@ -2178,15 +2344,16 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 5) return fail(PIC1DP_ERR_ARG, "which must be 0..5");
+  if (which < 0 || which > 6) return fail(PIC1DP_ERR_ARG, "which must be 0..6");
   if (which == 5) {  // separate diagnostics passes (k_ptcldist): a count, no time
     if (ms) *ms = 0.0;
     if (launches) *launches = c->diag_passes;
     return 0;
   }
   if (int rc = ev_resolve(c)) return rc;
-  if (ms) *ms = c->acc_ms[kTagFused + which];
-  if (launches) *launches = c->acc_n[kTagFused + which];
+  const int tag = which == 6 ? kTagStepOne : kTagFused + which;
+  if (ms) *ms = c->acc_ms[tag];
+  if (launches) *launches = c->acc_n[tag];
   return 0;
 }
 

@@ -574,6 +574,10 @@ struct StepArgsDev {
   DistGeom dg;
   double *dist_out;      // histograms [3*nxo*nvo + 3*nvo] of this species (accumulated with atomics), or null
   double *dist_partial;  // [gridDim][3] kinetic sums per workgroup
+  // k_step_one: prediction of the next step's first-sub-step charge
+  const double *tabA, *tabB;  // [pred_nm][nx]
+  double *pred;               // [1 + 2*pred_nm][nx]
+  int pred_nm, t2_mode;
 };
 
 // CARRY: a species whose divisor constants are general numbers spends most of either kernel
@@ -791,6 +795,174 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   if constexpr (DIAG) ptcldist_finish<true, HAS_W>(a.dg, bins, sums, sH + ntot, a.dist_out, a.dist_partial);
 }
 
+// ---------------------------------------------------------------------------
+// k_step_one: ONE pass over the markers per time step.
+// The first sub-step's kernel exists only to deposit the half-step charge, from which the
+// half-step field Eh follows.  But the half push is LINEAR in the field it sees:
+//     x' = x + dt/2 v                                     (no field at all, :261)
+//     w' = w + dt/2 (p - w) (-f0'/f0)(v) Z/m * E(x)        (:268-329; linear: p instead of p - w)
+// and the field is the kept modes' amplitudes times fixed tables (src/pic1dp_field.F90:251-257):
+//     E(x) = sum_m  re_m A_m(x) + im_m B_m(x),   A_m = gather of 2 cos, B_m = gather of -2 sin.
+// Hence the charge the NEXT step's first sub-step would deposit is
+//     rho_h = R0 + sum_m re_m RA_m + im_m RB_m,
+//     R0 = deposit of w at x',  RA_m = deposit of c A_m(x) at x',  RB_m likewise,
+//     c = dt/2 (p - w)(-f0'/f0)(v) Z/m,
+// and R0, RA_m, RB_m depend on the markers only -- this kernel, which has just computed the new
+// (x, v, w), deposits them as well.  When the field of the new state is solved (re, im known),
+// rho_h is one small combination (k_pred_combine), Eh one more solve, and the next step needs no
+// first-sub-step pass: 56 B per marker and step instead of 88.  The second sub-step's push is
+// untouched (same operations, same order as the reference given E0 and Eh); rho_h differs from a
+// marker-by-marker deposit of w' by rounding only (same algebra, different grouping: ~1e-15 relative,
+// the order of magnitude the atomics' order contributes anyway).  Full-f: rho_h = R0 (p at x').
+// Falls back to k_step_half + k_step_full when nmode > PRED_MAX_MODES or the tiles outgrow the LDS.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void flush_tile(const double *sT, double *dst, int nx) {
+  const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    int j = i + rot;
+    if (j >= nx) j -= nx;
+    const double val = sT[j];
+    if (val != 0.0) glb_add(&dst[j], val);
+  }
+}
+
+// c = dt/2 * (p - w) * (-f0'/f0)(v) * Z / m  (linear: p), and -f0'/f0(v) itself for the carry
+template <int DIST, int MODE, int POW2, class D>
+__device__ __forceinline__ double pred_coef_core(double v, double w, double p, double dt, const SpeciesConst &s, D &dv,
+                                                 double &t2) {
+  const double tmp1 = (MODE == MODE_DF_LIN) ? p : (p - w);
+  t2 = dlnf0<DIST, POW2>(v, s, dv);
+  return divc<POW2>(dt * tmp1 * t2 * s.Z, s.m, s.r_m, dv);
+}
+template <int DIST, int MODE, int POW2>
+__device__ __forceinline__ double pred_coef(double v, double w, double p, double dt, const SpeciesConst &s, double &t2) {
+  if constexpr (POW2 == 0) {
+    if (s.fastc) {
+      DivFast dv;
+      const double c = pred_coef_core<DIST, MODE, POW2>(v, w, p, dt, s, dv, t2);
+      if (dv.ok()) return c;
+    }
+  }
+  DivTrue dv;
+  return pred_coef_core<DIST, MODE, POW2>(v, w, p, dt, s, dv, t2);
+}
+
+// the prediction deposits of one marker in its NEW state n (x wrapped); returns -f0'/f0(n.v)
+template <int DIST, int MODE, int POW2>
+__device__ __forceinline__ double pred_one(const One &n, double p, const double *sA, const double *sB, int ne,
+                                           double *sP, const StepArgsDev &a) {
+  const int nx = a.g.nx, nm = a.pred_nm;
+  int ix;
+  double wl;
+  locate(n.x, a.g, ix, wl);                       // where the next step gathers its field (:250-257)
+  double xh = n.x + a.dt_half * n.v;              // the next step's half push of x (:261)
+  xh = wrap(xh, a.g.lx);                          // and the wrap + cell of its deposit (:102-108)
+  int ih;
+  double wh;
+  locate(xh, a.g, ih, wh);
+  int ih1 = ih + 1;
+  if (ih1 > nx - 1) ih1 = 0;
+  double t2 = 0.0;
+  if constexpr (MODE == MODE_FULLF) {
+    lds_add(&sP[ih], wh * p);
+    lds_add(&sP[ih1], (1.0 - wh) * p);
+  } else {
+    lds_add(&sP[ih], wh * n.w);
+    lds_add(&sP[ih1], (1.0 - wh) * n.w);
+    const double c = pred_coef<DIST, MODE, POW2>(n.v, n.w, p, a.dt_half, a.s, t2);
+    for (int m = 0; m < nm; ++m) {
+      const double *tA = sA + m * ne, *tB = sB + m * ne;
+      double A = tA[ix] * wl;
+      A = A + tA[ix + 1] * (1.0 - wl);
+      double B = tB[ix] * wl;
+      B = B + tB[ix + 1] * (1.0 - wl);
+      const double cA = c * A, cB = c * B;
+      double *RA = sP + static_cast<size_t>(1 + m) * nx, *RB = sP + static_cast<size_t>(1 + nm + m) * nx;
+      lds_add(&RA[ih], wh * cA);
+      lds_add(&RA[ih1], (1.0 - wh) * cA);
+      lds_add(&RB[ih], wh * cB);
+      lds_add(&RB[ih1], (1.0 - wh) * cB);
+    }
+  }
+  return t2;
+}
+
+// T2: 0 no carry of -f0'/f0; 1 this step evaluates it, the next step's value is stored; 2 this
+// step's value is loaded (stored by the previous k_step_one), the next step's stored
+template <int DIST, int MODE, int POW2, bool NT, int T2>
+__global__ void __launch_bounds__(1024) k_step_one(const StepArgsDev a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nx = a.g.nx, nm = a.pred_nm;
+  const int ne = (nx + 2) & ~1;
+  double *sE0 = reinterpret_cast<double *>(smem);
+  double *sEh = sE0 + ne;
+  double *sA = sEh + ne;
+  double *sB = sA + static_cast<size_t>(nm) * ne;
+  double *sR0 = sB + static_cast<size_t>(nm) * ne;
+  double *sP = sR0 + ((nx * a.g.rcopies + 1) & ~1);
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    sE0[i] = a.E0[i];
+    sEh[i] = a.Eh[i];
+  }
+  for (int i = threadIdx.x; i < nm * nx; i += blockDim.x) {
+    const int m = i / nx, c = i - m * nx;
+    sA[m * ne + c] = a.tabA[i];
+    sB[m * ne + c] = a.tabB[i];
+  }
+  zero_rho(sR0, a.g);
+  for (int i = threadIdx.x; i < (1 + 2 * nm) * nx; i += blockDim.x) sP[i] = 0.0;
+  if (threadIdx.x == 0) {
+    sE0[nx] = a.E0[0];
+    sEh[nx] = a.Eh[0];
+  }
+  if (threadIdx.x < nm) {
+    sA[threadIdx.x * ne + nx] = a.tabA[threadIdx.x * nx];
+    sB[threadIdx.x * ne + nx] = a.tabB[threadIdx.x * nx];
+  }
+  __syncthreads();
+  double *sR = my_rho_copy(sR0, a.g);
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
+  constexpr bool CARRY_IN = (T2 == 2) && HAS_W;
+  constexpr bool CARRY_OUT = (T2 != 0) && HAS_W;
+  const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double2 *x2 = reinterpret_cast<double2 *>(a.x);
+  double2 *v2 = reinterpret_cast<double2 *>(a.v);
+  double2 *w2 = reinterpret_cast<double2 *>(a.w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+  double2 *t2 = reinterpret_cast<double2 *>(a.t2);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+    const int64_t o = tidx2(j);
+    const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
+    double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
+    if constexpr (CARRY_IN) T = ld2t<NT>(t2 + j);
+    const One n0 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x);
+    const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y);
+    st2t<NT>(x2 + o, n0.x, n1.x);
+    if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
+    if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
+    const double u0 = pred_one<DIST, MODE, POW2>(n0, P.x, sA, sB, ne, sP, a);
+    const double u1 = pred_one<DIST, MODE, POW2>(n1, P.y, sA, sB, ne, sP, a);
+    if constexpr (CARRY_OUT) st2t<NT>(t2 + j, u0, u1);
+  }
+  if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = tidx(a.np - 1);
+    const double w = HAS_W ? a.w[i] : 0.0, p = a.p[i];
+    const One n = step_full_one<DIST, MODE, POW2, CARRY_IN>(a.x[i], a.v[i], w, p, sE0, sEh, sR, a,
+                                                            CARRY_IN ? a.t2[a.np - 1] : 0.0);
+    a.x[i] = n.x;
+    if constexpr (PUSH_V) a.v[i] = n.v;
+    if constexpr (HAS_W) a.w[i] = n.w;
+    const double u = pred_one<DIST, MODE, POW2>(n, p, sA, sB, ne, sP, a);
+    if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
+  }
+  __syncthreads();
+  flush_rho(sR0, a.rho, a.g);
+  for (int k = 0; k < 1 + 2 * nm; ++k) flush_tile(sP + static_cast<size_t>(k) * nx, a.pred + static_cast<size_t>(k) * nx, nx);
+}
+
 template <typename K>
 hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
   if (lc.lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (idempotent, cheap)
@@ -805,6 +977,17 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc,
 template <int DIST, int MODE, int POW2, bool CARRY = false>
 hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
 #if PIC1DP_STEP_PIPE == 0
+  if (full && d.pred) {  // one pass per step: also predicts the next step's first-sub-step charge
+    const int t2m = d.t2 ? d.t2_mode : 0;
+    if (d.nt) {
+      if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2>, d, lc, st);
+      if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1>, d, lc, st);
+      return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0>, d, lc, st);
+    }
+    if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2>, d, lc, st);
+    if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1>, d, lc, st);
+    return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0>, d, lc, st);
+  }
   if (full && d.dist_out)  // with the diagnostics of output_all
     return d.nt ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY, true>, d, lc, st)
                 : launch_step_kernel(k_step_full<DIST, MODE, POW2, false, CARRY, true>, d, lc, st);
@@ -944,6 +1127,11 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.dg = a.dg;
   d.dist_out = a.dist_out;
   d.dist_partial = a.dist_partial;
+  d.tabA = a.tabA;
+  d.tabB = a.tabB;
+  d.pred = a.pred;
+  d.pred_nm = a.pred_nm;
+  d.t2_mode = a.t2_mode;
   switch (a.iptcldist) {
     case 1: return launch_step_d<1>(d, a.deltaf, a.linear, full, lc, st);
     case 2: return launch_step_d<2>(d, a.deltaf, a.linear, full, lc, st);
@@ -1011,6 +1199,31 @@ template <bool WITH_LOCAL>
 __global__ void __launch_bounds__(FIELD_THREADS) k_chargeden(const FieldArgs f) {
   for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x)
     f.chargeden[ix] = chargeden_from(f, WITH_LOCAL ? charge_local_one(f, ix) : f.charge[ix]);
+}
+
+// k_step_one's prediction turned into this rank's charge2 of the next step's first sub-step:
+//   charge2_h = sum_s Z_s * (R0_s + sum_m re_m RA_sm + im_m RB_sm),   re / im = the kept modes of the
+// field the markers were just advanced to.  The accumulators are consumed (re-zeroed).  The caller
+// reduces f.charge over ranks and scales it (k_chargeden<false>) like any other charge2.
+__global__ void __launch_bounds__(FIELD_THREADS) k_pred_combine(const FieldArgs f, double *pred, int nm_pred) {
+  const int nx = f.nx, np1 = 1 + 2 * nm_pred;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+    double c2 = 0.0;
+    for (int s = 0; s < f.nspecies; ++s) {
+      double *r = pred + static_cast<size_t>(s) * np1 * nx + ix;
+      double c1 = r[0];
+      r[0] = 0.0;
+      for (int m = 0; m < nm_pred; ++m) {
+        double *ra = r + static_cast<size_t>(1 + m) * nx, *rb = r + static_cast<size_t>(1 + nm_pred + m) * nx;
+        c1 = c1 + f.mode_re[m] * *ra;
+        c1 = c1 + f.mode_im[m] * *rb;
+        *ra = 0.0;
+        *rb = 0.0;
+      }
+      c2 = c2 + c1 * f.Z[s];
+    }
+    f.charge[ix] = c2;
+  }
 }
 
 // field_solve_electric, src/pic1dp_field.F90:231-257, with the one-rank PETSc
@@ -1233,7 +1446,8 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
 
 __device__ __forceinline__ void exchange_charge(const FieldArgs &f, const XchgArgs &x, double *sC) {
   const int nx = f.nx, nr = x.nranks, par = static_cast<int>(x.epoch & 1);
-  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sC[ix] = charge_local_one(f, ix);
+  // this rank's charge2: from the species accumulators, or already formed in f.charge (k_pred_combine)
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sC[ix] = x.local_in_charge ? f.charge[ix] : charge_local_one(f, ix);
   // own values only: no barrier needed before re-reading sC[ix] below
   for (int k = 0; k < nr; ++k) {
     int q = x.rank + k;  // start with the own area, then the peers in ring order
@@ -1297,6 +1511,69 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_xchg(const FieldA
   }
   __syncthreads();
   solve_body(f, sCD, sMode, sScr, sTab);
+}
+
+// One launch for both fields of the one-pass-per-step scheme (k_step_one): the field of the new
+// state from its deposited charge (as k_field_solve / k_field_solve_xchg), then -- with the kept modes
+// just found -- the predicted charge of the next first sub-step (as k_pred_combine), summed over
+// ranks when XCHG, scaled, and solved into the half-step field of the NEXT step.
+template <bool XCHG>
+__global__ void __launch_bounds__(FIELD_THREADS)
+k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const XchgArgs x2, const PairArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sCD = reinterpret_cast<double *>(smem);
+  double *sMode = sCD + f.nx;
+  double *sScr = sMode + 2 * f.nmode;
+  double *sTab = sScr + 16;
+  const int nx = f.nx, nm = f.nmode;
+  if constexpr (XCHG) {
+    exchange_charge(f, x1, sCD);
+    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+      const double cd = chargeden_from(f, sCD[ix]);
+      f.chargeden[ix] = cd;
+      sCD[ix] = cd;
+    }
+  } else {
+    solve_fill_chargeden<true, false>(f, sCD);
+  }
+  __syncthreads();
+  solve_body(f, sCD, sMode, sScr, sTab);
+  __syncthreads();  // E, mode_re/im (also in sMode) are final; sCD and sTab are free again
+  const int np1 = 1 + 2 * nm;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+    double c2 = 0.0;
+    for (int s = 0; s < f.nspecies; ++s) {
+      double *r = pa.pred + static_cast<size_t>(s) * np1 * nx + ix;
+      double c1 = r[0];
+      r[0] = 0.0;
+      for (int m = 0; m < nm; ++m) {
+        double *ra = r + static_cast<size_t>(1 + m) * nx, *rb = r + static_cast<size_t>(1 + nm + m) * nx;
+        c1 = c1 + sMode[m] * *ra;
+        c1 = c1 + sMode[nm + m] * *rb;
+        *ra = 0.0;
+        *rb = 0.0;
+      }
+      c2 = c2 + c1 * f.Z[s];
+    }
+    if constexpr (XCHG) {
+      f.charge[ix] = c2;  // exchange_charge picks its own elements up again (local_in_charge)
+    } else {
+      sCD[ix] = c2;
+    }
+  }
+  if constexpr (XCHG) exchange_charge(f, x2, sCD);
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+    const double cd = chargeden_from(f, sCD[ix]);
+    pa.cd_h[ix] = cd;
+    sCD[ix] = cd;
+  }
+  __syncthreads();
+  FieldArgs g = f;
+  g.E = pa.E_h;
+  g.mode_re = pa.mode_h;
+  g.mode_im = pa.mode_h + nm;
+  g.history = nullptr;
+  solve_body(g, sCD, sMode, sScr, sTab);
 }
 
 // Many kept modes (2*nmode > FIELD_THREADS, up to the full spectrum nmode = nx/2,
@@ -1509,6 +1786,11 @@ hipError_t launch_field_solve(const FieldArgs &f, bool with_local, bool from_cha
   return hipGetLastError();
 }
 
+hipError_t launch_pred_combine(const FieldArgs &f, double *pred, int nm_pred, hipStream_t st) {
+  hipLaunchKernelGGL(k_pred_combine, dim3(1), dim3(FIELD_THREADS), 0, st, f, pred, nm_pred);
+  return hipGetLastError();
+}
+
 hipError_t launch_charge_exchange(const FieldArgs &f, const XchgArgs &x, hipStream_t st) {
   hipLaunchKernelGGL(k_charge_exchange, dim3(1), dim3(FIELD_THREADS), sizeof(double) * f.nx, st, f, x);
   return hipGetLastError();
@@ -1523,6 +1805,20 @@ hipError_t launch_field_solve_xchg(const FieldArgs &f, const XchgArgs &x, hipStr
   const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
                                        (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
   hipLaunchKernelGGL(k_field_solve_xchg, dim3(1), dim3(FIELD_THREADS), lds, st, f, x);
+  return hipGetLastError();
+}
+
+hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const XchgArgs *x1, const XchgArgs *x2,
+                                   hipStream_t st) {
+  if (2 * f.nmode > FIELD_THREADS) return hipErrorInvalidValue;
+  const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
+                                       (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
+  if (x1 && x2) {
+    hipLaunchKernelGGL(k_field_solve_pair<true>, dim3(1), dim3(FIELD_THREADS), lds, st, f, *x1, *x2, pa);
+  } else {
+    const XchgArgs none{};
+    hipLaunchKernelGGL(k_field_solve_pair<false>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, none, pa);
+  }
   return hipGetLastError();
 }
 

@@ -124,7 +124,21 @@ struct StepArgs {
   // full kernel only: take the diagnostics of output_all in the same pass (kernels.hip DIAG); dist_out null = no
   DistGeom dg;
   double *dist_out, *dist_partial;
+  // full kernel only: also predict the charge of the NEXT step's first sub-step (kernels.hip k_step_one);
+  // pred null = no.  tabA/tabB: [pred_nm][nx] mode tables with E = sum_m re_m*A_m + im_m*B_m;
+  // pred: [1 + 2*pred_nm][nx] accumulators of this species (R0, RA_m, RB_m); t2_mode: 0 no carry of
+  // -f0'/f0 through t2, 1 write it for the next step, 2 read this step's and write the next step's
+  const double *tabA, *tabB;
+  double *pred;
+  int pred_nm, t2_mode;
 };
+constexpr int PRED_MAX_MODES = 2;
+// dynamic LDS of k_step_one: E0, Eh, A_m, B_m tiles (with guard cell), rho copies, 1 + 2 nm prediction tiles
+inline size_t step_one_lds_bytes(int nx, int rcopies, int nm) {
+  const size_t ne = static_cast<size_t>((nx + 2) & ~1);
+  return sizeof(double) * ((2 + 2 * static_cast<size_t>(nm)) * ne + ((static_cast<size_t>(nx) * rcopies + 1) & ~static_cast<size_t>(1)) +
+                           (1 + 2 * static_cast<size_t>(nm)) * nx);
+}
 // dynamic LDS of the DIAG variant beyond the grid tiles: histograms + reduction scratch
 inline size_t step_diag_lds_bytes(int nx, int rcopies, int nxo, int nvo) {
   const size_t pad = ((static_cast<size_t>(nx) * rcopies + 1) & ~static_cast<size_t>(1)) - static_cast<size_t>(nx) * rcopies;
@@ -165,7 +179,22 @@ struct XchgArgs {
   unsigned long long epoch;                    // number of this exchange, from 1
   long long timeout_ticks;                     // wall_clock64 ticks (100 MHz) a rank waits for its peers
   int rank, nranks;
+  int local_in_charge;                         // 1: this rank's charge2 is already in FieldArgs::charge
 };
+// both fields of a one-pass step in one launch: the new state's field from its deposited charge, then the
+// NEXT step's half-step field from k_step_one's prediction (x1, x2: the two exchanges of a multi-rank
+// run, or both null for one rank)
+struct PairArgs {
+  double *pred;     // [nspecies][1 + 2 nmode][nx], consumed (re-zeroed)
+  double *E_h;      // [nx] half-step field of the next step
+  double *mode_h;   // [2 nmode] its kept modes (scratch)
+  double *cd_h;     // [nx] its charge density (scratch)
+};
+hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const XchgArgs *x1, const XchgArgs *x2,
+                                   hipStream_t st);
+// k_step_one's prediction accumulators [nspecies][1 + 2 nm][nx] + the field's kept modes -> this rank's
+// charge2 of the next first sub-step in f.charge; the accumulators are re-zeroed
+hipError_t launch_pred_combine(const FieldArgs &f, double *pred, int nm_pred, hipStream_t st);
 // local charge + exchange: the summed charge1 into f.charge
 hipError_t launch_charge_exchange(const FieldArgs &f, const XchgArgs &x, hipStream_t st);
 // local charge + exchange + chargeden + field solve in one launch

@@ -51,11 +51,13 @@ def test_bench_contract_line_small():
     assert abs(d["value"] - n * 2 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    # the fraction is priced at the bytes the kernel moves (56 B per marker), not at the 80-B reference price
-    assert r["bytes_per_marker"] == 56.0
-    assert abs(r["achieved"] - 56.0 * n / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    assert abs(r["reference_priced_GBs"] / r["achieved"] - 80.0 / 56.0) < 1e-9
-    assert r["whole_step_bytes"] == 88.0 * n
+    # the fraction is priced at the bytes the dominant kernel moves -- k_step_one: 32 B read + 24 B written
+    # + 16 B carry per marker and launch (= time step) -- not at the reference price of 80 B per update
+    assert "k_step_one" in r["kernel"] and r["bytes_per_marker"] == 72.0
+    assert abs(r["achieved"] - 72.0 * n / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert abs(r["reference_priced_GBs"] / r["achieved"] - 160.0 / 72.0) < 1e-9
+    assert r["whole_step_bytes"] == 72.0 * n          # every timed step was one k_step_one launch
+    assert r["whole_step_GBs"] <= r["peak"]
     assert d["strong_1e8_total"]["same_run_as_headline"] is True
     assert d["drop_in_call_sites"]["value"] > 0
     assert d["attribution"]["particle_kernels_ms_per_step"] > 0 and d["attribution"]["field_solve_ms_per_step"] > 0

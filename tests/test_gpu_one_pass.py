@@ -1,0 +1,127 @@
+"""One pass over the markers per time step (kernels.hip k_step_one): the second sub-step's
+kernel also deposits what the NEXT step's first sub-step would deposit, as coefficients of the
+kept field modes (the half push is linear in the field it sees, src/pic1dp_interaction.F90:261,
+268-329; the field is its kept modes times fixed tables, src/pic1dp_field.F90:251-257), so from
+the second step on no first-sub-step pass runs.  Against the two-pass engine (PIC1DP_PREDICT=0)
+and against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import DIST_CASES
+from util import relerr
+
+pytestmark = pytest.mark.gpu
+
+N = 200_001
+
+
+def engine(amd, monkeypatch, predict, **kw):
+    monkeypatch.setenv("PIC1DP_PREDICT", "1" if predict else "0")
+    e = amd.Pic1dp(amd.make_input(**kw))
+    e.particle_load()
+    e.interaction_collect_charge()
+    e.field_solve_electric()
+    return e
+
+
+MODES = [("df_nonlinear", dict()), ("df_linear", dict(linear=1)), ("full_f", dict(deltaf=0))]
+
+
+@pytest.mark.parametrize("name,kw", DIST_CASES, ids=[c[0] for c in DIST_CASES])
+@pytest.mark.parametrize("mname,mkw", MODES, ids=[m[0] for m in MODES])
+def test_one_pass_equals_two_passes(amd, monkeypatch, name, kw, mname, mkw):
+    if mkw.get("deltaf") == 0 and name != "maxwellian":
+        pytest.skip("full-f evaluates no f0 derivative: one distribution covers it")
+    kw = dict(kw, nparticle_max=N, nx=96, **mkw)
+    a = engine(amd, monkeypatch, True, **kw)
+    b = engine(amd, monkeypatch, False, **kw)
+    a.kernel_stats_enable(True)
+    b.kernel_stats_enable(True)
+    nsteps = 12
+    a.step(nsteps)
+    b.step(nsteps)
+    ea, eb = a.energy_history(), b.energy_history()
+    assert np.max(np.abs(ea / eb - 1.0)) < 1e-11
+    assert relerr(a.get_field_half(), b.get_field_half()) < 1e-11      # the predicted half-step field
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
+    # one first-sub-step pass (the very first step), then one kernel per step
+    assert a.kernel_stats(3)[1] == 1 and a.kernel_stats(6)[1] == nsteps and a.kernel_stats(4)[1] == 0
+    assert b.kernel_stats(3)[1] == nsteps and b.kernel_stats(4)[1] == nsteps and b.kernel_stats(6)[1] == 0
+
+
+def test_one_pass_against_oracle(oracle_mod, amd, monkeypatch):
+    """field energy at every step of a 300-step run within 1e-10 of the CPU arithmetic"""
+    kw = dict(nparticle_max=N, nx=64)
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    eng = engine(amd, monkeypatch, True, **kw)
+    eng.kernel_stats_enable(True)
+    eo = []
+    for _ in range(300):
+        sim.step(1)
+        eo.append(sim.field_energy())
+    eng.step(100)
+    eng.step(1)
+    eng.step(199)
+    assert np.max(np.abs(eng.energy_history() / np.array(eo) - 1.0)) < 1e-10
+    assert eng.kernel_stats(3)[1] == 1 and eng.kernel_stats(6)[1] == 300
+
+
+def test_one_pass_through_the_call_sites(amd, monkeypatch):
+    """the reference's three call sites: collect_charge after push(1) combines the prediction
+    (no marker pass), its chargeden is the eager deposit's to rounding; looking at the markers in
+    between still gives the eager state"""
+    kw = dict(nparticle_max=N, nx=96)
+    a = engine(amd, monkeypatch, True, **kw)
+    monkeypatch.setenv("PIC1DP_LAZY_CALLS", "0")
+    b = engine(amd, monkeypatch, False, **kw)
+    monkeypatch.delenv("PIC1DP_LAZY_CALLS")
+    b.set_electric(a.get_field()["electric"])
+    a.kernel_stats_enable(True)
+    for it in range(4):
+        for irk in (1, 2):
+            for e in (a, b):
+                e.interaction_push_particle(irk)
+                e.interaction_collect_charge()
+                e.field_solve_electric()
+            fa, fb = a.get_field(), b.get_field()
+            assert relerr(fa["chargeden"], fb["chargeden"]) < 1e-11, (it, irk)
+            assert relerr(fa["electric"], fb["electric"]) < 1e-11, (it, irk)
+            b.set_electric(fa["electric"])
+            a.set_electric(fa["electric"]) if False else None
+        ga, gb = a.particles_download(), b.particles_download()
+        for k in "xvw":
+            assert np.array_equal(ga[k], gb[k]), (k, it)
+    # step 1: half + one-pass kernel; after every look at the markers the prediction is still valid
+    # (downloads do not change them), so steps 2-4 need no first-sub-step pass
+    assert a.kernel_stats(3)[1] == 1 and a.kernel_stats(6)[1] == 4
+
+
+def test_prediction_is_dropped_when_it_no_longer_applies(amd, monkeypatch):
+    """a field set from outside, re-uploaded markers, another solver: the first-sub-step pass runs again"""
+    kw = dict(nparticle_max=N, nx=96)
+    a = engine(amd, monkeypatch, True, **kw)
+    b = engine(amd, monkeypatch, False, **kw)
+    a.kernel_stats_enable(True)
+    for e in (a, b):
+        e.step(3)
+    E = b.get_field()["electric"] * 1.5            # not what the kept modes say
+    for e in (a, b):
+        e.set_electric(E)
+        e.step(2)
+    g = b.particles_download()
+    for e in (a, b):
+        e.particles_upload(g["x"], g["v"], g["p"], g["w"])
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+        e.step(2)
+    assert abs(a.field_energy() / b.field_energy() - 1.0) < 1e-11
+    # first-sub-step passes: step 1, the step after set_electric, the step after the upload
+    assert a.kernel_stats(3)[1] == 3 and a.kernel_stats(6)[1] == 7
+    a.set_field_solver(1)                          # finite differences: E is not its kept modes
+    a.step(2)
+    assert a.kernel_stats(3)[1] == 5 and a.kernel_stats(4)[1] == 2
