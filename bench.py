@@ -514,7 +514,7 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("particles_per_gpu") == per_gpu and tj.get("nx") == phys["nx"]:
-                    key = "k_step_full" if full_n else "k_push"
+                    key = "k_step_one" if one_n else ("k_step_full" if full_n else "k_push")
                     traffic = tj.get("hbm_bytes_per_launch_by_kernel", {}).get(key)
                     traffic_src = "profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
                                   "this command (committed profile of the same workload, not measured in this run)"
@@ -546,6 +546,7 @@ def main():
                                "sub-step" % world,
                 "path": path, "allreduce": headline_kind, "rccl_ranks": world if headline_kind == "rccl" else 0,
                 "marker_layout": "x, v, w, p interleaved in 32 KiB tiles in one slab per species",
+                "kernel_launches_in_timed_steps": {k: v[1] for k, v in ktab.items() if v[1]},
                 "sync": sync_kind, "load_seconds": job.load_s,
             },
             "roofline": {

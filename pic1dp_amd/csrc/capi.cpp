@@ -227,7 +227,7 @@ LaunchCfg particle_launch(const pic1dp_ctx *c, int64_t np, bool with_E, bool wit
   LaunchCfg lc{};
   lc.lds = sizeof(double) * ((with_E ? static_cast<size_t>((nx + 2) & ~1) : 0) +
                              (with_rho ? static_cast<size_t>(nx) * c->grid.rcopies : 0));
-  const size_t lds_cap = 160 * 1024;
+  const size_t lds_cap = PARTICLE_LDS_CAP;
   int by_lds = lc.lds ? static_cast<int>(lds_cap / lc.lds) : 8;
   if (by_lds < 1) by_lds = 1;
   int threads = c->threads_req > 0 ? c->threads_req : 512;
@@ -1368,13 +1368,13 @@ static size_t step_lds_bytes(int nx, bool full, int rcopies = 1) {
 }
 
 static bool step_recompute_ok(const pic1dp_ctx *c) {
-  return c->step_mode == 0 && step_lds_bytes(c->in.nx, true) <= 160 * 1024;
+  return c->step_mode == 0 && step_lds_bytes(c->in.nx, true) <= PARTICLE_LDS_CAP;
 }
 
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
   LaunchCfg lc{};
   lc.lds = step_lds_bytes(c->in.nx, full, c->grid.rcopies);
-  int by_lds = static_cast<int>((160 * 1024) / lc.lds);
+  int by_lds = static_cast<int>(PARTICLE_LDS_CAP / lc.lds);
   if (by_lds < 1) by_lds = 1;
   // two workgroups of 768 threads per CU (24 waves): measured inside one process
   // (tools/ab_launch.py) best or within 1 % of best from 6.4e6 to 1e8 markers --
@@ -1410,7 +1410,7 @@ static bool output_follows(const pic1dp_ctx *c) {
 // describe E), few kept modes, and LDS for E0, Eh, the mode tables and the four accumulators
 static bool predict_capable(const pic1dp_ctx *c) {
   return c->predict && c->d_pred && c->field_solver == 0 && step_recompute_ok(c) && c->in.nmode <= PRED_MAX_MODES &&
-         step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode) <= 160 * 1024;
+         step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode) <= PARTICLE_LDS_CAP;
 }
 
 // full = true: the caller has bumped state_version for this step; the state the kernel READS is version - 1
@@ -1423,7 +1423,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
   if (diag) {
     const size_t need = step_lds_bytes(c->in.nx, true, c->grid.rcopies) +
                         step_diag_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nx_opd, c->in.nv_opd);
-    if (!full || c->in.nx_opd < 1 || c->in.nv_opd < 2 || need > 160 * 1024) diag = false;
+    if (!full || c->in.nx_opd < 1 || c->in.nv_opd < 2 || need > PARTICLE_LDS_CAP) diag = false;
   }
   if (diag)
     if (int rc = diag_buffers(c)) return rc;
@@ -1488,7 +1488,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
         S.t2_version = c->state_version;
       }
       lc.lds = step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode);
-      const bool two = 2 * lc.lds <= 160 * 1024;
+      const bool two = 2 * lc.lds <= PARTICLE_LDS_CAP;
       lc.threads = c->threads_req > 0 ? c->threads_req : (two ? 768 : 1024);
       const int bpc = c->bpc_req > 0 ? c->bpc_req : (two ? 2 : 1);
       const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;

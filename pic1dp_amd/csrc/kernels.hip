@@ -52,12 +52,21 @@ __device__ __forceinline__ void glb_add(double *p, double v) {
 #ifndef PIC1DP_NT
 #define PIC1DP_NT 1
 #endif
+// the whole-step kernels run two workgroups of 768 threads per CU = 6 waves per SIMD: the register
+// allocator must stay within 512 / 6 VGPRs (it would otherwise trade occupancy for interleaving the two
+// markers of a pair)
+#ifndef PIC1DP_WAVES_PER_EU
+#define PIC1DP_WAVES_PER_EU 6
+#endif
+#define PIC1DP_SIX_WAVES __attribute__((amdgpu_waves_per_eu(PIC1DP_WAVES_PER_EU)))
 // tuning builds of the whole-step kernels' marker loop: 0 one pair per lane per trip (default),
 // 1 next trip's loads before this trip's arithmetic (k_step_full), 2 two pairs per trip
 #ifndef PIC1DP_STEP_PIPE
 #define PIC1DP_STEP_PIPE 0
 #endif
 typedef double v2d __attribute__((ext_vector_type(2)));
+// scheduling fence: independent instruction chains on either side are not interleaved (register pressure)
+#define PAIR_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <bool NT>
 __device__ __forceinline__ double2 ld2t(const double2 *p) {
@@ -180,8 +189,23 @@ __device__ __forceinline__ double div_lx(double x, const GridConst &g) {
 // cell index and left weight of position x (already inside [0, lx]):
 // sx = x/lx*nx; ix = floor(sx); wl = 1 - (sx - ix)
 // src/pic1dp_interaction.F90:106-108 and :250-252
+// The division skips div_lx's range test (one compare chain and branch per locate, four locates per
+// marker in k_step_one): positions reaching locate are wrapped into [0, lx] or come from memory in that
+// range, and outside the theorem's range the outcome cannot change anyway -- for |x| < 2^-500 (0, -0,
+// subnormals included) any quotient within a few ulp gives s < 2^-490, hence ix = 0 and wl = 1 exactly
+// as the IEEE quotient does; NaN stays NaN and folds to cell 0 below like NaN / lx; |x| > 2^500 would
+// index outside the grid in the reference and folds to cell 0 here either way.
+__device__ __forceinline__ double div_lx_unchecked(double x, const GridConst &g) {
+  if (!g.fast_div) return x / g.lx;
+  const double y = g.rlx;
+  const double q0 = x * y;
+  const double r0 = fma(-g.lx, q0, x);
+  const double q1 = fma(r0, y, q0);
+  const double r1 = fma(-g.lx, q1, x);
+  return fma(r1, y, q1);
+}
 __device__ __forceinline__ void locate(double x, const GridConst &g, int &ix, double &wl) {
-  const double s = div_lx(x, g) * g.dnx;
+  const double s = div_lx_unchecked(x, g) * g.dnx;
   const double fl = floor(s);
   ix = static_cast<int>(fl);
   wl = 1.0 - (s - fl);
@@ -204,6 +228,104 @@ __device__ __forceinline__ double wrap(double x, double lx) {
   return r;
 }
 
+// exp(x) for the weight equation's arguments x = -(v -+ v0)^2 / (2T/m) <= 0 (src/pic1dp_interaction.F90:
+// 278-321).  The library exp costs ~25 FP64 instructions, and the one-pass kernel evaluates four per
+// marker at an FP64-issue-bound pace.  Table-driven instead: x = n ln2/64 + r, |r| <= ln2/128,
+// e^x = 2^(n>>6) * T[n&63] * e^r with T[j] = 2^(j/64) as a correctly rounded hi + lo pair (LDS, 1 KiB
+// per workgroup) and e^r - 1 by its Taylor polynomial of degree 5 (truncation 3.5e-17): 13 VALU
+// instructions + one ds_read_b128, within 1 ulp of libm on [-745, 0] (test_device_exp_against_libm;
+// 97 % of arguments bit-identical) -- the same distance the library exp keeps.  Arguments below -750
+// (a run that has blown up) are clamped: the result underflows to 0 either way.
+__device__ const double2 kExpTab[64] = {
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.02c9a3e778061p+0, -0x1.19083535b085dp-56},
+    {0x1.059b0d3158574p+0, 0x1.d73e2a475b465p-55},
+    {0x1.0874518759bc8p+0, 0x1.186be4bb284ffp-57},
+    {0x1.0b5586cf9890fp+0, 0x1.8a62e4adc610bp-54},
+    {0x1.0e3ec32d3d1a2p+0, 0x1.03a1727c57b53p-59},
+    {0x1.11301d0125b51p+0, -0x1.6c51039449b3ap-54},
+    {0x1.1429aaea92de0p+0, -0x1.32fbf9af1369ep-54},
+    {0x1.172b83c7d517bp+0, -0x1.19041b9d78a76p-55},
+    {0x1.1a35beb6fcb75p+0, 0x1.e5b4c7b4968e4p-55},
+    {0x1.1d4873168b9aap+0, 0x1.e016e00a2643cp-54},
+    {0x1.2063b88628cd6p+0, 0x1.dc775814a8495p-55},
+    {0x1.2387a6e756238p+0, 0x1.9b07eb6c70573p-54},
+    {0x1.26b4565e27cddp+0, 0x1.2bd339940e9d9p-55},
+    {0x1.29e9df51fdee1p+0, 0x1.612e8afad1255p-55},
+    {0x1.2d285a6e4030bp+0, 0x1.0024754db41d5p-54},
+    {0x1.306fe0a31b715p+0, 0x1.6f46ad23182e4p-55},
+    {0x1.33c08b26416ffp+0, 0x1.32721843659a6p-54},
+    {0x1.371a7373aa9cbp+0, -0x1.63aeabf42eae2p-54},
+    {0x1.3a7db34e59ff7p+0, -0x1.5e436d661f5e3p-56},
+    {0x1.3dea64c123422p+0, 0x1.ada0911f09ebcp-55},
+    {0x1.4160a21f72e2ap+0, -0x1.ef3691c309278p-58},
+    {0x1.44e086061892dp+0, 0x1.89b7a04ef80d0p-59},
+    {0x1.486a2b5c13cd0p+0, 0x1.3c1a3b69062f0p-56},
+    {0x1.4bfdad5362a27p+0, 0x1.d4397afec42e2p-56},
+    {0x1.4f9b2769d2ca7p+0, -0x1.4b309d25957e3p-54},
+    {0x1.5342b569d4f82p+0, -0x1.07abe1db13cadp-55},
+    {0x1.56f4736b527dap+0, 0x1.9bb2c011d93adp-54},
+    {0x1.5ab07dd485429p+0, 0x1.6324c054647adp-54},
+    {0x1.5e76f15ad2148p+0, 0x1.ba6f93080e65ep-54},
+    {0x1.6247eb03a5585p+0, -0x1.383c17e40b497p-54},
+    {0x1.6623882552225p+0, -0x1.bb60987591c34p-54},
+    {0x1.6a09e667f3bcdp+0, -0x1.bdd3413b26456p-54},
+    {0x1.6dfb23c651a2fp+0, -0x1.bbe3a683c88abp-57},
+    {0x1.71f75e8ec5f74p+0, -0x1.16e4786887a99p-55},
+    {0x1.75feb564267c9p+0, -0x1.0245957316dd3p-54},
+    {0x1.7a11473eb0187p+0, -0x1.41577ee04992fp-55},
+    {0x1.7e2f336cf4e62p+0, 0x1.05d02ba15797ep-56},
+    {0x1.82589994cce13p+0, -0x1.d4c1dd41532d8p-54},
+    {0x1.868d99b4492edp+0, -0x1.fc6f89bd4f6bap-54},
+    {0x1.8ace5422aa0dbp+0, 0x1.6e9f156864b27p-54},
+    {0x1.8f1ae99157736p+0, 0x1.5cc13a2e3976cp-55},
+    {0x1.93737b0cdc5e5p+0, -0x1.75fc781b57ebcp-57},
+    {0x1.97d829fde4e50p+0, -0x1.d185b7c1b85d1p-54},
+    {0x1.9c49182a3f090p+0, 0x1.c7c46b071f2bep-56},
+    {0x1.a0c667b5de565p+0, -0x1.359495d1cd533p-54},
+    {0x1.a5503b23e255dp+0, -0x1.d2f6edb8d41e1p-54},
+    {0x1.a9e6b5579fdbfp+0, 0x1.0fac90ef7fd31p-54},
+    {0x1.ae89f995ad3adp+0, 0x1.7a1cd345dcc81p-54},
+    {0x1.b33a2b84f15fbp+0, -0x1.2805e3084d708p-57},
+    {0x1.b7f76f2fb5e47p+0, -0x1.5584f7e54ac3bp-56},
+    {0x1.bcc1e904bc1d2p+0, 0x1.23dd07a2d9e84p-55},
+    {0x1.c199bdd85529cp+0, 0x1.11065895048ddp-55},
+    {0x1.c67f12e57d14bp+0, 0x1.2884dff483cadp-54},
+    {0x1.cb720dcef9069p+0, 0x1.503cbd1e949dbp-56},
+    {0x1.d072d4a07897cp+0, -0x1.cbc3743797a9cp-54},
+    {0x1.d5818dcfba487p+0, 0x1.2ed02d75b3707p-55},
+    {0x1.da9e603db3285p+0, 0x1.c2300696db532p-54},
+    {0x1.dfc97337b9b5fp+0, -0x1.1a5cd4f184b5cp-54},
+    {0x1.e502ee78b3ff6p+0, 0x1.39e8980a9cc8fp-55},
+    {0x1.ea4afa2a490dap+0, -0x1.e9c23179c2893p-54},
+    {0x1.efa1bee615a27p+0, 0x1.dc7f486a4b6b0p-54},
+    {0x1.f50765b6e4540p+0, 0x1.9d3e12dd8a18bp-54},
+    {0x1.fa7c1819e90d8p+0, 0x1.74853f3a5931ep-55}};
+
+__device__ __forceinline__ double2 *exp_table() {
+  __shared__ __attribute__((aligned(16))) double2 sExpT[64];
+  return sExpT;
+}
+// every kernel that evaluates -f0'/f0 calls this before its first workgroup barrier
+__device__ __forceinline__ void exp_table_init() {
+  if (threadIdx.x < 64) exp_table()[threadIdx.x] = kExpTab[threadIdx.x];
+}
+__device__ __forceinline__ double pexp(double x) {
+  x = fmax(x, -750.0);
+  const double fn = rint(x * 0x1.71547652b82fep+6);            // n = round(x * 64/ln2)
+  const int n = static_cast<int>(fn);
+  double r = fma(-fn, 0x1.62e42fefa0000p-7, x);               // x - n ln2/64, ln2/64 as hi (36 bits) + lo
+  r = fma(-fn, 0x1.cf79abc9e3b3ap-46, r);
+  double q = 0x1.1111111111111p-7;                            // 1/120
+  q = fma(q, r, 0x1.5555555555555p-5);                        // 1/24
+  q = fma(q, r, 0x1.5555555555555p-3);                        // 1/6
+  q = fma(q, r, 0.5);
+  q = fma(q, r, 1.0);
+  const double p = q * r;                                     // e^r - 1
+  const double2 t = exp_table()[n & 63];
+  return ldexp(t.x + fma(t.x, p, t.y), n >> 6);
+}
+
 // -(d f0/dv)/f0 at v, src/pic1dp_interaction.F90:274-326
 template <int DIST, int POW2, class D>
 __device__ __forceinline__ double dlnf0(double v, const SpeciesConst &c, D &dv) {
@@ -211,14 +333,16 @@ __device__ __forceinline__ double dlnf0(double v, const SpeciesConst &c, D &dv) 
     return v - 2.0 / v;
   } else if constexpr (DIST == 2) {  // two-stream2 :278-292
     const double vp = v + c.v0, vm = v - c.v0;
-    const double ep = exp(-divh<POW2>(vp * vp, c.two_tm, c.r_two_tm, dv));
-    const double em = exp(-divh<POW2>(vm * vm, c.two_tm, c.r_two_tm, dv));
+    const double ep = pexp(-divh<POW2>(vp * vp, c.two_tm, c.r_two_tm, dv));
+    PAIR_FENCE();
+    const double em = pexp(-divh<POW2>(vm * vm, c.two_tm, c.r_two_tm, dv));
     const double q = (vp * ep + vm * em) / (ep + em);
     return divc<POW2>(q * c.m, c.T, c.r_T, dv);
   } else if constexpr (DIST == 3) {  // bump-on-tail :294-321
     const double vm = v - c.v0;
-    const double e1 = exp(-divh<POW2>(v * v, c.two_tm, c.r_two_tm, dv));
-    const double e2 = exp(-divh<POW2>(vm * vm, c.two_tm2, c.r_two_tm2, dv));
+    const double e1 = pexp(-divh<POW2>(v * v, c.two_tm, c.r_two_tm, dv));
+    PAIR_FENCE();
+    const double e2 = pexp(-divh<POW2>(vm * vm, c.two_tm2, c.r_two_tm2, dv));
     const double a = divc<POW2>(divc<POW2>(c.den * v, c.tm, c.r_tm, dv) * e1, c.stm, c.r_stm, dv);
     const double b = divc<POW2>(divc<POW2>(c.beam * vm, c.tm2, c.r_tm2, dv) * e2, c.stm2, c.r_stm2, dv);
     const double cc = divc<POW2>(c.den * e1, c.stm, c.r_stm, dv);
@@ -313,11 +437,16 @@ __device__ __forceinline__ void lds_add_matched(double *sR, int ix, double val) 
 
 // wrap + linear deposit of one marker into the LDS copy of rho,
 // src/pic1dp_interaction.F90:102-113; returns the wrapped position
-__device__ __forceinline__ double deposit_one(double x, double q, double *sR, const GridConst &g) {
+__device__ __forceinline__ double deposit_one(double x, double q, double *sR, const GridConst &g, int *ix_out = nullptr,
+                                              double *wl_out = nullptr) {
   const double px = wrap(x, g.lx);
   int ix;
   double wl;
   locate(px, g, ix, wl);
+  if (ix_out) {  // cell and left weight of the wrapped position, for a caller that gathers there next
+    *ix_out = ix;
+    *wl_out = wl;
+  }
 #if PIC1DP_DEPOSIT_PREREDUCE
   lds_add_matched(sR, ix, wl * q);
   ix = ix + 1;
@@ -360,6 +489,7 @@ __device__ __forceinline__ void flush_rho(const double *sR, double *rho, const G
 template <int DIST, int MODE, int POW2, bool IRK2, bool FUSED>
 __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  exp_table_init();
   double *sE = reinterpret_cast<double *>(smem);
   const int nx = a.g.nx;
   double *sR0 = sE + ((nx + 2) & ~1);
@@ -591,8 +721,9 @@ struct StepArgsDev {
 // accesses keep the state cache-resident between the two kernels of a step
 // (+5 % at the reference's default 6.4e6 markers).  Chosen per launch.
 template <int DIST, int MODE, int POW2, bool NT, bool CARRY>
-__global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
+__global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_half(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  exp_table_init();
   double *sE = reinterpret_cast<double *>(smem);
   const int nx = a.g.nx;
   double *sR0 = sE + ((nx + 2) & ~1);
@@ -641,10 +772,11 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
     if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
     double t0 = 0.0, t1 = 0.0;
     const One h0 = push_one<DIST, MODE, POW2, CARRY ? 1 : 0>(X.x, V.x, W.x, P.x, X.x, V.x, W.x, sE, a.dt_half, a.g, a.s, &t0);
-    const One h1 = push_one<DIST, MODE, POW2, CARRY ? 1 : 0>(X.y, V.y, W.y, P.y, X.y, V.y, W.y, sE, a.dt_half, a.g, a.s, &t1);
-    if constexpr (CARRY) st2t<NT>(reinterpret_cast<double2 *>(a.t2) + j, t0, t1);
     deposit_one(h0.x, HAS_W ? h0.w : P.x, sR, a.g);
+    PAIR_FENCE();
+    const One h1 = push_one<DIST, MODE, POW2, CARRY ? 1 : 0>(X.y, V.y, W.y, P.y, X.y, V.y, W.y, sE, a.dt_half, a.g, a.s, &t1);
     deposit_one(h1.x, HAS_W ? h1.w : P.y, sR, a.g);
+    if constexpr (CARRY) st2t<NT>(reinterpret_cast<double2 *>(a.t2) + j, t0, t1);
   }
 #endif
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -663,14 +795,15 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
 // one marker through the second half of the time step
 template <int DIST, int MODE, int POW2, bool CARRY = false>
 __device__ __forceinline__ One step_full_one(double x, double v, double w, double p, const double *sE0,
-                                             const double *sEh, double *sR, const StepArgsDev &a, double t2 = 0.0) {
+                                             const double *sEh, double *sR, const StepArgsDev &a, double t2 = 0.0,
+                                             int *ix_out = nullptr, double *wl_out = nullptr) {
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   // sub-step 1 again (identical arithmetic), with the wrap the deposit applied
   One h = push_one<DIST, MODE, POW2, CARRY ? 2 : 0>(x, v, w, p, x, v, w, sE0, a.dt_half, a.g, a.s, &t2);
   h.x = wrap(h.x, a.g.lx);
   // sub-step 2: derivatives at the half-step state, base = step-start state
   One n = push_one<DIST, MODE, POW2>(h.x, h.v, h.w, p, x, v, w, sEh, a.dt_full, a.g, a.s);
-  n.x = deposit_one(n.x, HAS_W ? n.w : p, sR, a.g);
+  n.x = deposit_one(n.x, HAS_W ? n.w : p, sR, a.g, ix_out, wl_out);
   return n;
 }
 
@@ -679,8 +812,9 @@ __device__ __forceinline__ One step_full_one(double x, double v, double w, doubl
 // the state just computed, into an LDS copy of the histograms next to the grid tiles (one workgroup
 // of 1024 threads per CU then).
 template <int DIST, int MODE, int POW2, bool NT, bool CARRY, bool DIAG>
-__global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
+__global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_full(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  exp_table_init();
   const int nx = a.g.nx;
   const int ne = (nx + 2) & ~1;
   double *sE0 = reinterpret_cast<double *>(smem);
@@ -770,6 +904,7 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
     double2 T = make_double2(0.0, 0.0);
     if constexpr (CARRY) T = ld2t<NT>(reinterpret_cast<const double2 *>(a.t2) + j);
     const One n0 = step_full_one<DIST, MODE, POW2, CARRY>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x);
+    PAIR_FENCE();
     const One n1 = step_full_one<DIST, MODE, POW2, CARRY>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y);
     st2t<NT>(x2 + o, n0.x, n1.x);
     if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
@@ -848,13 +983,12 @@ __device__ __forceinline__ double pred_coef(double v, double w, double p, double
 }
 
 // the prediction deposits of one marker in its NEW state n (x wrapped); returns -f0'/f0(n.v)
+// (ix, wl): cell and left weight of n.x, where the next step gathers its field (:250-257) -- the deposit
+// of the new state has just computed them
 template <int DIST, int MODE, int POW2>
-__device__ __forceinline__ double pred_one(const One &n, double p, const double *sA, const double *sB, int ne,
-                                           double *sP, const StepArgsDev &a) {
+__device__ __forceinline__ double pred_one(const One &n, double p, int ix, double wl, const double *sA, const double *sB,
+                                           int ne, double *sP, const StepArgsDev &a) {
   const int nx = a.g.nx, nm = a.pred_nm;
-  int ix;
-  double wl;
-  locate(n.x, a.g, ix, wl);                       // where the next step gathers its field (:250-257)
   double xh = n.x + a.dt_half * n.v;              // the next step's half push of x (:261)
   xh = wrap(xh, a.g.lx);                          // and the wrap + cell of its deposit (:102-108)
   int ih;
@@ -890,8 +1024,9 @@ __device__ __forceinline__ double pred_one(const One &n, double p, const double 
 // T2: 0 no carry of -f0'/f0; 1 this step evaluates it, the next step's value is stored; 2 this
 // step's value is loaded (stored by the previous k_step_one), the next step's stored
 template <int DIST, int MODE, int POW2, bool NT, int T2>
-__global__ void __launch_bounds__(1024) k_step_one(const StepArgsDev a) {
+__global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  exp_table_init();
   const int nx = a.g.nx, nm = a.pred_nm;
   const int ne = (nx + 2) & ~1;
   double *sE0 = reinterpret_cast<double *>(smem);
@@ -938,24 +1073,31 @@ __global__ void __launch_bounds__(1024) k_step_one(const StepArgsDev a) {
     double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);
     if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
     if constexpr (CARRY_IN) T = ld2t<NT>(t2 + j);
-    const One n0 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x);
-    const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y);
+    int i0, i1;
+    double l0, l1;
+    // the two markers of a pair one after the other (PAIR_FENCE): interleaving their four exp chains
+    // costs more registers than six waves per SIMD leave
+    const One n0 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x, &i0, &l0);
+    const double u0 = pred_one<DIST, MODE, POW2>(n0, P.x, i0, l0, sA, sB, ne, sP, a);
+    PAIR_FENCE();
+    const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y, &i1, &l1);
+    const double u1 = pred_one<DIST, MODE, POW2>(n1, P.y, i1, l1, sA, sB, ne, sP, a);
     st2t<NT>(x2 + o, n0.x, n1.x);
     if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
     if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
-    const double u0 = pred_one<DIST, MODE, POW2>(n0, P.x, sA, sB, ne, sP, a);
-    const double u1 = pred_one<DIST, MODE, POW2>(n1, P.y, sA, sB, ne, sP, a);
     if constexpr (CARRY_OUT) st2t<NT>(t2 + j, u0, u1);
   }
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = tidx(a.np - 1);
     const double w = HAS_W ? a.w[i] : 0.0, p = a.p[i];
+    int ic;
+    double lc;
     const One n = step_full_one<DIST, MODE, POW2, CARRY_IN>(a.x[i], a.v[i], w, p, sE0, sEh, sR, a,
-                                                            CARRY_IN ? a.t2[a.np - 1] : 0.0);
+                                                            CARRY_IN ? a.t2[a.np - 1] : 0.0, &ic, &lc);
     a.x[i] = n.x;
     if constexpr (PUSH_V) a.v[i] = n.v;
     if constexpr (HAS_W) a.w[i] = n.w;
-    const double u = pred_one<DIST, MODE, POW2>(n, p, sA, sB, ne, sP, a);
+    const double u = pred_one<DIST, MODE, POW2>(n, p, ic, lc, sA, sB, ne, sP, a);
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
   }
   __syncthreads();
@@ -967,7 +1109,7 @@ template <typename K>
 hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
   if (lc.lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (idempotent, cheap)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PARTICLE_LDS_CAP);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(kern, dim3(lc.blocks), dim3(lc.threads), lc.lds, st, d);
@@ -1058,7 +1200,7 @@ hipError_t launch_push_t(const PushArgs &a, const LaunchCfg &lc, hipStream_t st)
   static bool big_lds_ok = false;  // opt in once to > 64 KiB of dynamic LDS (nx >= 4096)
   if (lc.lds > 64 * 1024 && !big_lds_ok) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PARTICLE_LDS_CAP);
     if (e != hipSuccess) return e;
     big_lds_ok = true;
   }
@@ -2185,8 +2327,10 @@ __global__ void k_divc_check(double c, double rc, uint64_t seed, int64_t n, unsi
 namespace {
 // the push's transcendental on its own (tests bound it against libm)
 __global__ void __launch_bounds__(256) k_exp_array(const double *x, double *y, int64_t n) {
+  exp_table_init();
+  __syncthreads();
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = exp(x[i]);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = pexp(x[i]);
 }
 }  // namespace
 

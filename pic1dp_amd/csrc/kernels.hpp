@@ -101,6 +101,9 @@ struct DistGeom {
   int nxo, nvo;   // nx_opd, nv_opd
 };
 
+// dynamic LDS a particle kernel may ask for: 160 KiB per CU minus the 1 KiB static exp table
+constexpr size_t PARTICLE_LDS_CAP = 159 * 1024;
+
 struct LaunchCfg {
   int threads;   // per workgroup
   int blocks;    // grid size

@@ -16,7 +16,7 @@ import json
 import re
 import sys
 
-PARTICLE_KERNELS = ("k_push", "k_step_half", "k_step_full", "k_deposit")
+PARTICLE_KERNELS = ("k_push", "k_step_half", "k_step_full", "k_step_one", "k_deposit")
 
 
 def short_name(full):
@@ -62,7 +62,7 @@ def main():
     if fused:
         by_kernel["k_push"] = sum(r["hbm_bytes"] * r["launches"] for r in fused) / sum(r["launches"] for r in fused)
     res = dict(particles_per_gpu=n, nx=nx, hbm_bytes_per_launch_by_kernel=by_kernel,
-               compulsory_bytes_per_marker=dict(k_step_half=32.0, k_step_full=56.0),
+               compulsory_bytes_per_marker=dict(k_step_half=32.0, k_step_full=56.0, k_step_one=72.0),
                reference_priced_bytes_per_update=80.0,
                correction="FETCH_SIZE x2 (gfx950 wide coalesced reads), WRITE_SIZE exact; KiB units",
                kernels=rows)

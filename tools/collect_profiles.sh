@@ -28,7 +28,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
     python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/bench_pmc_$lc.json" 2> "$OUT/pmc_$lc.err"
   # keep the particle and field kernels only (torch's own fill kernels are noise)
   f=$(find "$OUT/pmc_$lc" -name '*counter_collection.csv' | head -n 1)
-  (head -n 1 "$f"; grep -E 'k_step|k_push|k_deposit|k_field|k_charge' "$f" || true) > "$OUT/bench_c3_wholestep_pmc_$lc.csv"
+  (head -n 1 "$f"; grep -E 'k_step|k_push|k_deposit|k_field|k_charge|k_pred' "$f" || true) > "$OUT/bench_c3_wholestep_pmc_$lc.csv"
 done
 python3 "$R/profiles/summarize_pmc.py" "$OUT/bench_c3_wholestep_pmc_fetch_size.csv" \
   "$OUT/bench_c3_wholestep_pmc_write_size.csv" 1e8 1024 "$OUT/traffic_c3_wholestep.json"

@@ -33,8 +33,8 @@ for mode in (0, 1):
     eng.step(steps)
     eng.sync()
     dt = time.perf_counter() - t0
-    ks = [eng.kernel_stats(k) for k in range(5)]
-    names = ["fused", "push", "deposit", "step_half", "step_full"]
+    ks = [eng.kernel_stats(k) for k in (0, 1, 2, 3, 4, 6)]
+    names = ["fused", "push", "deposit", "step_half", "step_full", "step_one"]
     parts = ["%s %.4f ms" % (nm, ms / cnt) for nm, (ms, cnt) in zip(names, ks) if cnt]
     print("mode %d: %.4e updates/s  %.4f ms/step  | %s" % (mode, n * 2 * steps / dt, dt / steps * 1e3, ", ".join(parts)), flush=True)
     eng.kernel_stats_enable(False)
@@ -54,6 +54,6 @@ for _ in range(steps):
         eng.field_solve_electric()
 eng.sync()
 dt = time.perf_counter() - t0
-ks = [eng.kernel_stats(k) for k in range(5)]
+ks = [eng.kernel_stats(k) for k in (0, 1, 2, 3, 4, 6)]
 parts = ["%s %.4f ms" % (nm, ms / cnt) for nm, (ms, cnt) in zip(names, ks) if cnt]
 print("calls : %.4e updates/s  %.4f ms/step  | %s" % (n * 2 * steps / dt, dt / steps * 1e3, ", ".join(parts)), flush=True)
