@@ -105,6 +105,7 @@ struct pic1dp_ctx {
   // prediction accumulators [nspecies][1 + 2 nm][nx], the combined half-step charge density
   double *d_tabA = nullptr, *d_tabB = nullptr, *d_pred = nullptr, *d_cd_h = nullptr, *d_mode_h = nullptr;
   double *d_Ehn = nullptr;         // half-step field predicted for the NEXT step (d_Eh stays the last step's)
+  double *d_pack = nullptr;        // [2 + 2 nmode][nx] one all-reduce per one-pass step (RCCL path)
   int predict = 1;                 // PIC1DP_PREDICT=0: always two passes per step
   uint64_t pred_version = 0;       // state_version the accumulators in d_pred belong to (0: none)
   uint64_t eh_version = 0;         // state_version d_Eh has been predicted for (step() path)
@@ -774,6 +775,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
       HIP_TRY_C(hipMalloc(&c->d_pred, sizeof(double) * pred_doubles));
       HIP_TRY_C(hipMalloc(&c->d_cd_h, sizeof(double) * nx));
       HIP_TRY_C(hipMalloc(&c->d_Ehn, sizeof(double) * nx));
+      HIP_TRY_C(hipMalloc(&c->d_pack, sizeof(double) * (2 + 2 * nm) * nx));
       HIP_TRY_C(hipMalloc(&c->d_mode_h, sizeof(double) * 2 * nm));
       HIP_TRY_C(hipMemcpy(c->d_tabA, ta.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
       HIP_TRY_C(hipMemcpy(c->d_tabB, tb.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
@@ -833,7 +835,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     (void)hipFree(S.t2);
   }
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
-                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred, c->d_cd_h, c->d_mode_h, c->d_Ehn};
+                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred, c->d_cd_h, c->d_mode_h, c->d_Ehn, c->d_pack};
   for (double *b : bufs) (void)hipFree(b);
   for (double *b : c->probe_keep) (void)hipFree(b);
   for (auto &e : c->evpool) {
@@ -1565,19 +1567,33 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool 
   if (int rc = step_particles(c, full, c->d_E, c->d_Eh, diag, pred)) return rc;
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   const bool fused_xchg = xchg_active(c) && c->field_solver == 0;  // exchange inside the solve's launch
-  if (multi && !fused_xchg)
+  // RCCL path of a one-pass step: everything the two charge sums of the step need in one all-reduce
+  const bool will_pack = pred && c->pred_version == c->state_version && multi && !fused_xchg && c->comm != nullptr &&
+                         !xchg_active(c) && c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
+  if (will_pack) {
+    HIP_TRY(launch_charge_pack(c->fa, c->d_pred, c->in.nmode, c->d_pack, c->st));
+    Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
+    ncclResult_t r = rccl().AllReduce(c->d_pack, c->d_pack, static_cast<size_t>(2 + 2 * c->in.nmode) * c->in.nx, ncclDouble,
+                                      ncclSum, c->comm, c->st);
+    if (r != ncclSuccess) return fail(PIC1DP_ERR_COMM, "ncclAllReduce: %s", rccl().GetErrorString(r));
+    if (int rc = sp.end()) return rc;
+  } else if (multi && !fused_xchg) {
     if (int rc = reduce_charge(c)) return rc;
+  }
   Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
   f.E = Eout;
   if (record && c->hist_count < kHistCap) f.history = c->d_hist + c->hist_count++;
   // one-pass step on one rank or with the exchange: both fields (the new state's, and the next step's
   // half-step field from the prediction) in ONE launch
-  const bool pair = pred && c->pred_version == c->state_version && (!multi || fused_xchg) && c->field_solver == 0 &&
-                    2 * c->in.nmode <= 256 && Eout == c->d_E;
+  const bool pair = pred && c->pred_version == c->state_version && (!multi || fused_xchg || will_pack) &&
+                    c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (pair) {
-    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h};
-    if (fused_xchg) {
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr};
+    if (will_pack) {  // both charge sums of the step came in ONE all-reduce of (2 + 2 nmode) nx doubles
+      pa.pack = c->d_pack;
+      HIP_TRY(launch_field_solve_pair(f, pa, nullptr, nullptr, c->st));
+    } else if (fused_xchg) {
       const XchgArgs x1 = next_xchg_args(c);
       XchgArgs x2 = next_xchg_args(c);
       x2.local_in_charge = 1;

@@ -1368,6 +1368,25 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_pred_combine(const FieldArgs 
   }
 }
 
+// RCCL path of a one-pass step: everything this rank contributes to the two charge sums of the step,
+// packed for ONE all-reduce: pack[0] = charge2 of the new state, pack[1 + k] = sum_s Z_s * (R0, RA_m, RB_m)_s
+// (the combination with the kept modes is linear, so the species sum and the sum over ranks commute with it).
+__global__ void __launch_bounds__(FIELD_THREADS) k_charge_pack(const FieldArgs f, double *pred, int nm_pred, double *pack) {
+  const int nx = f.nx, np1 = 1 + 2 * nm_pred;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+    pack[ix] = charge_local_one(f, ix);
+    for (int k = 0; k < np1; ++k) {
+      double c2 = 0.0;
+      for (int s = 0; s < f.nspecies; ++s) {
+        double *r = pred + (static_cast<size_t>(s) * np1 + k) * nx + ix;
+        c2 = c2 + *r * f.Z[s];
+        *r = 0.0;
+      }
+      pack[static_cast<size_t>(1 + k) * nx + ix] = c2;
+    }
+  }
+}
+
 // field_solve_electric, src/pic1dp_field.F90:231-257, with the one-rank PETSc
 // summation order: forward sums run over ascending ix in ONE thread per
 // (mode, re/im) so the result is bit-identical to the sequential CPU loop.
@@ -1659,7 +1678,10 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_xchg(const FieldA
 // state from its deposited charge (as k_field_solve / k_field_solve_xchg), then -- with the kept modes
 // just found -- the predicted charge of the next first sub-step (as k_pred_combine), summed over
 // ranks when XCHG, scaled, and solved into the half-step field of the NEXT step.
-template <bool XCHG>
+// SRC: 0 one rank (charges from the local accumulators), 1 one-hop exchange (two exchanges inside this
+// launch), 2 packed (pa.pack holds the rank-summed charge2 and Z-weighted prediction slices, k_charge_pack +
+// one all-reduce)
+template <int SRC>
 __global__ void __launch_bounds__(FIELD_THREADS)
 k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const XchgArgs x2, const PairArgs pa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1668,10 +1690,18 @@ k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const XchgArgs x2, cons
   double *sScr = sMode + 2 * f.nmode;
   double *sTab = sScr + 16;
   const int nx = f.nx, nm = f.nmode;
-  if constexpr (XCHG) {
+  if constexpr (SRC == 1) {
     exchange_charge(f, x1, sCD);
     for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
       const double cd = chargeden_from(f, sCD[ix]);
+      f.chargeden[ix] = cd;
+      sCD[ix] = cd;
+    }
+  } else if constexpr (SRC == 2) {
+    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+      const double c = pa.pack[ix];
+      f.charge[ix] = c;
+      const double cd = chargeden_from(f, c);
       f.chargeden[ix] = cd;
       sCD[ix] = cd;
     }
@@ -1684,26 +1714,35 @@ k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const XchgArgs x2, cons
   const int np1 = 1 + 2 * nm;
   for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
     double c2 = 0.0;
-    for (int s = 0; s < f.nspecies; ++s) {
-      double *r = pa.pred + static_cast<size_t>(s) * np1 * nx + ix;
-      double c1 = r[0];
-      r[0] = 0.0;
+    if constexpr (SRC == 2) {
+      const double *r = pa.pack + nx + ix;  // Z-weighted, summed over species and ranks
+      c2 = r[0];
       for (int m = 0; m < nm; ++m) {
-        double *ra = r + static_cast<size_t>(1 + m) * nx, *rb = r + static_cast<size_t>(1 + nm + m) * nx;
-        c1 = c1 + sMode[m] * *ra;
-        c1 = c1 + sMode[nm + m] * *rb;
-        *ra = 0.0;
-        *rb = 0.0;
+        c2 = c2 + sMode[m] * r[static_cast<size_t>(1 + m) * nx];
+        c2 = c2 + sMode[nm + m] * r[static_cast<size_t>(1 + nm + m) * nx];
       }
-      c2 = c2 + c1 * f.Z[s];
+    } else {
+      for (int s = 0; s < f.nspecies; ++s) {
+        double *r = pa.pred + static_cast<size_t>(s) * np1 * nx + ix;
+        double c1 = r[0];
+        r[0] = 0.0;
+        for (int m = 0; m < nm; ++m) {
+          double *ra = r + static_cast<size_t>(1 + m) * nx, *rb = r + static_cast<size_t>(1 + nm + m) * nx;
+          c1 = c1 + sMode[m] * *ra;
+          c1 = c1 + sMode[nm + m] * *rb;
+          *ra = 0.0;
+          *rb = 0.0;
+        }
+        c2 = c2 + c1 * f.Z[s];
+      }
     }
-    if constexpr (XCHG) {
+    if constexpr (SRC == 1) {
       f.charge[ix] = c2;  // exchange_charge picks its own elements up again (local_in_charge)
     } else {
       sCD[ix] = c2;
     }
   }
-  if constexpr (XCHG) exchange_charge(f, x2, sCD);
+  if constexpr (SRC == 1) exchange_charge(f, x2, sCD);
   for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
     const double cd = chargeden_from(f, sCD[ix]);
     pa.cd_h[ix] = cd;
@@ -1955,12 +1994,19 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
   if (2 * f.nmode > FIELD_THREADS) return hipErrorInvalidValue;
   const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
                                        (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
+  const XchgArgs none{};
   if (x1 && x2) {
-    hipLaunchKernelGGL(k_field_solve_pair<true>, dim3(1), dim3(FIELD_THREADS), lds, st, f, *x1, *x2, pa);
+    hipLaunchKernelGGL(k_field_solve_pair<1>, dim3(1), dim3(FIELD_THREADS), lds, st, f, *x1, *x2, pa);
+  } else if (pa.pack) {
+    hipLaunchKernelGGL(k_field_solve_pair<2>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, none, pa);
   } else {
-    const XchgArgs none{};
-    hipLaunchKernelGGL(k_field_solve_pair<false>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, none, pa);
+    hipLaunchKernelGGL(k_field_solve_pair<0>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, none, pa);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_charge_pack(const FieldArgs &f, double *pred, int nm_pred, double *pack, hipStream_t st) {
+  hipLaunchKernelGGL(k_charge_pack, dim3(1), dim3(FIELD_THREADS), 0, st, f, pred, nm_pred, pack);
   return hipGetLastError();
 }
 

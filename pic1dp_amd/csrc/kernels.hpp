@@ -192,7 +192,10 @@ struct PairArgs {
   double *E_h;      // [nx] half-step field of the next step
   double *mode_h;   // [2 nmode] its kept modes (scratch)
   double *cd_h;     // [nx] its charge density (scratch)
+  double *pack;     // null, or [2 + 2 nmode][nx]: charge2 and the Z-weighted prediction slices, already summed over ranks
 };
+// this rank's charge2 and Z-weighted prediction slices packed for one all-reduce (accumulators re-zeroed)
+hipError_t launch_charge_pack(const FieldArgs &f, double *pred, int nm_pred, double *pack, hipStream_t st);
 hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const XchgArgs *x1, const XchgArgs *x2,
                                    hipStream_t st);
 // k_step_one's prediction accumulators [nspecies][1 + 2 nm][nx] + the field's kept modes -> this rank's
