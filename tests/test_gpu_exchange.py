@@ -17,9 +17,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(tmp_path, nproc, kw, steps, mode, port):
+def run_ranks(tmp_path, nproc, kw, steps, mode, port, timeout_ms="60000"):
     out = str(tmp_path / ("xchg_%s_%d" % (mode, nproc)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PIC1DP_XCHG_TIMEOUT_MS="60000")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PIC1DP_XCHG_TIMEOUT_MS=timeout_ms)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "xchg_worker.py"),
            out, json.dumps(kw), str(steps), mode]
@@ -62,3 +62,16 @@ def test_exchange_ranks_share_the_gpu(amd, tmp_path, nproc, mode):
     x = eng.particles_download()["x"]
     got = np.concatenate([r["x"] for r in ranks])
     assert np.max(np.abs(got - x)) < 1e-9
+
+
+def test_exchange_gives_up_on_a_missing_rank(amd, tmp_path):
+    """a peer that stops delivering: the waiting rank's kernels time out (PIC1DP_XCHG_TIMEOUT_MS), every
+    launch still finishes, and the next synchronising call returns PIC1DP_ERR_COMM naming the rank --
+    never a hang (the spin is bounded by a wall clock inside the kernel)"""
+    import time
+    t0 = time.time()
+    ranks = run_ranks(tmp_path, 2, dict(nparticle_max=400_000, nx=64), 3, "timeout", 29549, timeout_ms="1500")
+    assert time.time() - t0 < 120
+    e0, e1 = str(ranks[0]["err"]), str(ranks[1]["err"])
+    assert e0.startswith("5|") and "rank 1" in e0, e0        # PIC1DP_ERR_COMM on the rank that waited
+    assert e1 == ""                                          # the rank that stopped early saw nothing wrong

@@ -125,3 +125,27 @@ def test_prediction_is_dropped_when_it_no_longer_applies(amd, monkeypatch):
     a.set_field_solver(1)                          # finite differences: E is not its kept modes
     a.step(2)
     assert a.kernel_stats(3)[1] == 5 and a.kernel_stats(4)[1] == 2
+
+
+@pytest.mark.parametrize("kw,predicted", [
+    (dict(nmode=2, modes=[1, 3], init_nmode=2, init_mode=[1, 3], init_mode_cos=[0.0, 2e-6], init_mode_sin=[1e-5, 0.0]), True),
+    (dict(nmode=3, modes=[1, 2, 5]), False),                    # more kept modes than the tiles hold: two passes
+    (dict(nspecies=2, iptcldist=0, species_charge=[-1.0, 1.0], species_mass=[1.0, 25.0], species_temperature=[1.0, 0.5],
+          species_temperature2=[1.0, 1.0], species_density=[1.0, 1.0], species_v0=[0.0, 0.0], lx=4 * np.pi), True),
+    (dict(nx=4096), False),                                     # eight tiles of 32 KiB do not fit the LDS
+    (dict(nparticle_max=N + 1, species_nparticle_init=[N - 7]), True)],
+    ids=["two_modes", "three_modes_fall_back", "two_species", "nx4096_falls_back", "even_count_tail_slots"])
+def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted):
+    kw = dict(dict(nparticle_max=N, nx=96), **kw)
+    a = engine(amd, monkeypatch, True, **kw)
+    b = engine(amd, monkeypatch, False, **kw)
+    a.kernel_stats_enable(True)
+    a.step(8)
+    b.step(8)
+    assert np.max(np.abs(a.energy_history() / b.energy_history() - 1.0)) < 1e-11
+    assert relerr(a.get_field()["electric"], b.get_field()["electric"]) < 1e-11
+    ns = kw.get("nspecies", 1)
+    if predicted:
+        assert a.kernel_stats(3)[1] == ns and a.kernel_stats(6)[1] == 8 * ns and a.kernel_stats(4)[1] == 0
+    else:
+        assert a.kernel_stats(3)[1] == 8 * ns and a.kernel_stats(4)[1] == 8 * ns and a.kernel_stats(6)[1] == 0

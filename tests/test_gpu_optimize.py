@@ -146,3 +146,45 @@ def test_optimisation_needs_loader_stream_and_delta_f(amd):
     full_f.field_solve_electric()
     full_f.step(3)
     assert full_f.local_sizes()[1] == 2000            # "now only support optimization for delta f"
+
+
+def test_call_site_path_needs_the_library_clock(amd):
+    """a host that swaps only the call sites must hand its clock to the
+    library after every step (pic1dp_hip_set_time) -- particle_optimize compares the event times
+    with the library's time + dt like src/pic1dp_particle.F90:742-770 with global_time + dt.  With
+    the clock the merge fires in the same step as under pic1dp_hip_step; without it, never."""
+    kw = dict(nparticle_max=120000, species_nparticle_init=[90000], nx=32, nv=64, nmerge=1, tmerge=[0.2],
+              thshmerge=[0.3])
+
+    def fresh():
+        e = amd.Pic1dp(amd.make_input(**kw))
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+        return e
+
+    def drive(e, nsteps, clock):
+        fired = []
+        for it in range(nsteps):
+            for irk in (1, 2):
+                e.interaction_push_particle(irk)
+                if e.particle_optimize(irk):
+                    fired.append(it)
+                e.interaction_collect_charge()
+                e.field_solve_electric()
+            if clock:
+                e.set_time(e.itime + 1, e.time + e.inp.dt)
+        return fired
+
+    ref = fresh()
+    counts = []
+    for it in range(6):
+        ref.step(1)
+        counts.append(ref.local_sizes()[1])
+    step_fired = [it for it in range(6) if counts[it] != (counts[it - 1] if it else 90000)]
+    assert step_fired == [3]                    # the step that starts at t = 0.15: 0.15 + dt >= 0.2
+    with_clock = fresh()
+    assert drive(with_clock, 6, True) == step_fired
+    assert with_clock.local_sizes()[1] == counts[-1]
+    without = fresh()
+    assert drive(without, 6, False) == [] and without.local_sizes()[1] == 90000

@@ -28,6 +28,20 @@ def main():
     eng.field_solve_electric()
     e0 = eng.field_energy()
     fields = []
+    if mode == "timeout":
+        # rank 1 stops one step early: rank 0's kernels must give up waiting (bounded), finish, and
+        # the next synchronising call must report the missing rank
+        err = ""
+        try:
+            eng.step(steps if rank == 0 else steps - 1)
+            eng.sync()
+        except pic1dp_amd.Pic1dpError as e:
+            err = "%d|%s" % (e.code, e)
+        np.savez(out + ".rank%d.npz" % rank, err=err)
+        dist.barrier()
+        eng.close()
+        dist.destroy_process_group()
+        return
     if mode == "step":
         eng.step(steps)
     else:  # the reference's call sites
