@@ -482,7 +482,7 @@ def main():
         one_ms, one_n = ktab["k_step_one"]
         # k_step_one hands -f0'/f0 of the new velocity to the next step through memory (8 B written,
         # 8 B read per marker) unless PIC1DP_CARRY=0
-        carry_b = 16.0 if (deltaf and os.environ.get("PIC1DP_CARRY", "1") != "0") else 0.0
+        carry_b = 16.0 if (deltaf and phys.get("iptcldist", 3) in (2, 3) and os.environ.get("PIC1DP_CARRY", "1") != "0") else 0.0
         if one_n:
             kname = ("k_step_one (one pass per step: recompute half-step state, push+gather, wrap, deposit, store in "
                      "place, and the deposits that predict the next step's first-sub-step charge)")

@@ -1483,7 +1483,9 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       // -f0'/f0 at the new velocity is what the NEXT step's recomputation of the half-step state
       // needs: it goes there through memory (16 B per marker and step; k_step_one 1.45 -> 1.33 ms at
       // 1e8 markers, tools/ab_pred.sh).  PIC1DP_CARRY=0: evaluated again instead.
-      if (c->carry && c->in.deltaf) {
+      // Only where -f0'/f0 costs something: two-stream2 and bump-on-tail (two exp and a division);
+      // Maxwellian and two-stream1 evaluate it in one or two operations.
+      if (c->carry && c->in.deltaf && (c->in.iptcldist == 2 || c->in.iptcldist == 3)) {
         if (!S.t2) HIP_TRY(hipMalloc(&S.t2, sizeof(double) * static_cast<size_t>(S.nalloc + 2)));
         a.t2 = S.t2;
         a.t2_mode = S.t2_version == read_version ? 2 : 1;

@@ -52,9 +52,10 @@ __device__ __forceinline__ void glb_add(double *p, double v) {
 #ifndef PIC1DP_NT
 #define PIC1DP_NT 1
 #endif
-// the whole-step kernels run two workgroups of 768 threads per CU = 6 waves per SIMD: the register
-// allocator must stay within 512 / 6 VGPRs (it would otherwise trade occupancy for interleaving the two
-// markers of a pair)
+// k_step_one runs two workgroups of 768 threads per CU = 6 waves per SIMD: its register allocation is
+// held to 512 / 6 VGPRs (4 spilled registers; measured best, tools/ab_waves.sh).  k_step_half / k_step_full
+// are left alone: held to the same budget k_step_full spills 15-19 registers and runs 1.12-1.39 ms instead
+// of 0.96-0.98 ms (it then keeps 96 VGPRs and fewer waves).
 #ifndef PIC1DP_WAVES_PER_EU
 #define PIC1DP_WAVES_PER_EU 6
 #endif
@@ -721,7 +722,7 @@ struct StepArgsDev {
 // accesses keep the state cache-resident between the two kernels of a step
 // (+5 % at the reference's default 6.4e6 markers).  Chosen per launch.
 template <int DIST, int MODE, int POW2, bool NT, bool CARRY>
-__global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_half(const StepArgsDev a) {
+__global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   exp_table_init();
   double *sE = reinterpret_cast<double *>(smem);
@@ -812,7 +813,7 @@ __device__ __forceinline__ One step_full_one(double x, double v, double w, doubl
 // the state just computed, into an LDS copy of the histograms next to the grid tiles (one workgroup
 // of 1024 threads per CU then).
 template <int DIST, int MODE, int POW2, bool NT, bool CARRY, bool DIAG>
-__global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_full(const StepArgsDev a) {
+__global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   exp_table_init();
   const int nx = a.g.nx;
