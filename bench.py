@@ -194,7 +194,7 @@ class Job:
                     # comes up on some ranks only ends the job at the process group's timeout
                     self.rccl_why = parallel.bootstrap_comm(self.eng, dist)
                 self.have_rccl = self.rccl_why is None
-            if a.allreduce in ("auto", "p2p"):
+            if a.allreduce in ("auto", "p2p", "host"):   # "host": connected too, to be measured beside it
                 self.p2p_why = parallel.bootstrap_exchange(self.eng, dist)
                 self.have_p2p = self.p2p_why is None
             want = a.allreduce
@@ -428,7 +428,8 @@ def main():
     # ---- the one-hop exchange beside RCCL (measured LAST: a failed exchange leaves a run
     # that cannot go on, and everything else is already measured) -----------------------
     exchange = None
-    if world > 1 and job.kind == "rccl":
+    primary = "rccl" if job.kind == "rccl" else "host"
+    if world > 1 and not job.kind.startswith("one-hop"):
         if job.have_p2p and (sjob is None or sjob.have_p2p):
             exchange = {}
             from pic1dp_amd import parallel
@@ -461,14 +462,14 @@ def main():
                     exchange[label] = {"value": tot * 2.0 * a.steps / x_el, "unit": "updates/s",
                                        "ms_per_step": x_el / a.steps * 1e3, "attribution": x_attr,
                                        "field_energy_end": j.eng.field_energy()}
-                    j.use("rccl")
+                    j.use(primary)
                 else:
                     exchange[label] = {"error": err or "failed on another rank"}
                     break
             exchange["what"] = ("the same workloads with the charge summed by the library's one-hop exchange "
                                 "(pic1dp_hip_xchg_*: every GPU stores its charge into its slot on every peer, "
                                 "every GPU adds the slots in rank order inside the field solve's launch) instead "
-                                "of ncclAllReduce")
+                                "of the headline's sum (%s)" % headline_kind)
         else:
             exchange = {"unavailable": job.p2p_why or (sjob.p2p_why if sjob else None)}
 

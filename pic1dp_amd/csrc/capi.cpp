@@ -361,6 +361,7 @@ XchgArgs next_xchg_args(pic1dp_ctx *c) {
   x.timeout_ticks = c->xc.timeout_ticks;
   x.rank = c->lay.rank;
   x.nranks = c->lay.nranks;
+  x.vstride = XCHG_MAX_VEC * c->in.nx;
   return x;
 }
 
@@ -1594,14 +1595,12 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool 
     PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr};
     if (will_pack) {  // both charge sums of the step came in ONE all-reduce of (2 + 2 nmode) nx doubles
       pa.pack = c->d_pack;
-      HIP_TRY(launch_field_solve_pair(f, pa, nullptr, nullptr, c->st));
-    } else if (fused_xchg) {
+      HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));
+    } else if (fused_xchg) {  // ONE exchange: charge2 and the prediction slices travel together
       const XchgArgs x1 = next_xchg_args(c);
-      XchgArgs x2 = next_xchg_args(c);
-      x2.local_in_charge = 1;
-      HIP_TRY(launch_field_solve_pair(f, pa, &x1, &x2, c->st));
+      HIP_TRY(launch_field_solve_pair(f, pa, &x1, c->st));
     } else {
-      HIP_TRY(launch_field_solve_pair(f, pa, nullptr, nullptr, c->st));
+      HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));
     }
     field_written(c, true);
     c->pred_version = 0;  // consumed
@@ -2234,7 +2233,7 @@ int pic1dp_hip_xchg_create(pic1dp_ctx *c, unsigned char handle[PIC1DP_XCHG_HANDL
   if (c->lay.nranks > XCHG_MAX_RANKS) return fail(PIC1DP_ERR_ARG, "the exchange serves at most %d ranks", XCHG_MAX_RANKS);
   if (c->xc.local) return fail(PIC1DP_ERR_STATE, "exchange area already created");
   HIP_TRY(hipSetDevice(c->device));
-  const size_t bytes = kXchgFlagBytes + sizeof(double) * 2 * static_cast<size_t>(c->lay.nranks) * c->in.nx;
+  const size_t bytes = kXchgFlagBytes + sizeof(double) * 2 * static_cast<size_t>(c->lay.nranks) * XCHG_MAX_VEC * c->in.nx;
   // memory the peers' stores and this GPU's polls meet in: fine-grained (coherent
   // across agents inside a kernel); PIC1DP_XCHG_MEM = 2 uncached, 3 plain hipMalloc
   int want = 1;

@@ -1606,17 +1606,15 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
 // ---------------------------------------------------------------------------
 #define PIC1DP_SYS __HIP_MEMORY_SCOPE_SYSTEM
 
-__device__ __forceinline__ void exchange_charge(const FieldArgs &f, const XchgArgs &x, double *sC) {
-  const int nx = f.nx, nr = x.nranks, par = static_cast<int>(x.epoch & 1);
-  // this rank's charge2: from the species accumulators, or already formed in f.charge (k_pred_combine)
-  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sC[ix] = x.local_in_charge ? f.charge[ix] : charge_local_one(f, ix);
-  // own values only: no barrier needed before re-reading sC[ix] below
+// n values per rank (n <= x.vstride), this rank's in sV -- every thread has filled the elements
+// threadIdx.x + k * blockDim.x and only ever touches those -- summed over ranks in rank order, in place
+__device__ __forceinline__ void exchange_vectors(const XchgArgs &x, double *sV, int n) {
+  const int nr = x.nranks, par = static_cast<int>(x.epoch & 1);
   for (int k = 0; k < nr; ++k) {
     int q = x.rank + k;  // start with the own area, then the peers in ring order
     if (q >= nr) q -= nr;
-    double *dst = x.slots[q] + (static_cast<size_t>(par) * nr + x.rank) * nx;
-    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x)
-      __hip_atomic_store(dst + ix, sC[ix], __ATOMIC_RELAXED, PIC1DP_SYS);
+    double *dst = x.slots[q] + (static_cast<size_t>(par) * nr + x.rank) * x.vstride;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(dst + i, sV[i], __ATOMIC_RELAXED, PIC1DP_SYS);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this wave's stores have landed
   __syncthreads();
@@ -1637,19 +1635,26 @@ __device__ __forceinline__ void exchange_charge(const FieldArgs &f, const XchgAr
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   __syncthreads();
-  const double *mine = x.slots[x.rank] + static_cast<size_t>(par) * nr * nx;
-  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+  const double *mine = x.slots[x.rank] + static_cast<size_t>(par) * nr * x.vstride;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     double t[XCHG_MAX_RANKS];
 #pragma unroll
     for (int q = 0; q < XCHG_MAX_RANKS; ++q)
-      t[q] = q < nr ? __hip_atomic_load(mine + static_cast<size_t>(q) * nx + ix, __ATOMIC_RELAXED, PIC1DP_SYS) : 0.0;
+      t[q] = q < nr ? __hip_atomic_load(mine + static_cast<size_t>(q) * x.vstride + i, __ATOMIC_RELAXED, PIC1DP_SYS) : 0.0;
     double sum = t[0];
 #pragma unroll
     for (int q = 1; q < XCHG_MAX_RANKS; ++q)
       if (q < nr) sum = sum + t[q];
-    sC[ix] = sum;
-    f.charge[ix] = sum;
+    sV[i] = sum;
   }
+}
+
+__device__ __forceinline__ void exchange_charge(const FieldArgs &f, const XchgArgs &x, double *sC) {
+  const int nx = f.nx;
+  // this rank's charge2: from the species accumulators, or already formed in f.charge (k_pred_combine)
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sC[ix] = x.local_in_charge ? f.charge[ix] : charge_local_one(f, ix);
+  exchange_vectors(x, sC, nx);
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) f.charge[ix] = sC[ix];
 }
 
 // exchange only: charge1 into field charge (collect_charge call site, many-mode solve)
@@ -1684,23 +1689,39 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_xchg(const FieldA
 // one all-reduce)
 template <int SRC>
 __global__ void __launch_bounds__(FIELD_THREADS)
-k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const XchgArgs x2, const PairArgs pa) {
+k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const PairArgs pa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *sCD = reinterpret_cast<double *>(smem);
   double *sMode = sCD + f.nx;
   double *sScr = sMode + 2 * f.nmode;
   double *sTab = sScr + 16;
-  const int nx = f.nx, nm = f.nmode;
+  const int nx = f.nx, nm = f.nmode, np1 = 1 + 2 * nm;
+  // SRC 1: [charge2 | Z-weighted prediction slices] of this rank, then of all ranks, behind the solve's tiles
+  double *sV = sTab + (f.tab_lds ? 2 * static_cast<size_t>(nm) * nx : 0);
+  const double *pk = pa.pack;  // SRC 2: the same slices, all-reduced in memory
   if constexpr (SRC == 1) {
-    exchange_charge(f, x1, sCD);
     for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
-      const double cd = chargeden_from(f, sCD[ix]);
-      f.chargeden[ix] = cd;
-      sCD[ix] = cd;
+      sV[ix] = charge_local_one(f, ix);
+      for (int k = 0; k < np1; ++k) {
+        double c2 = 0.0;
+        for (int s = 0; s < f.nspecies; ++s) {
+          double *r = pa.pred + (static_cast<size_t>(s) * np1 + k) * nx + ix;
+          c2 = c2 + *r * f.Z[s];
+          *r = 0.0;
+        }
+        sV[static_cast<size_t>(1 + k) * nx + ix] = c2;
+      }
     }
-  } else if constexpr (SRC == 2) {
+    // element i of the packed vector belongs to thread i % blockDim; with nx a multiple of blockDim that is
+    // the thread that wrote it -- otherwise meet first
+    __syncthreads();
+    exchange_vectors(x1, sV, (1 + np1) * nx);
+    __syncthreads();
+    pk = sV;
+  }
+  if constexpr (SRC != 0) {
     for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
-      const double c = pa.pack[ix];
+      const double c = pk[ix];
       f.charge[ix] = c;
       const double cd = chargeden_from(f, c);
       f.chargeden[ix] = cd;
@@ -1712,11 +1733,10 @@ k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const XchgArgs x2, cons
   __syncthreads();
   solve_body(f, sCD, sMode, sScr, sTab);
   __syncthreads();  // E, mode_re/im (also in sMode) are final; sCD and sTab are free again
-  const int np1 = 1 + 2 * nm;
   for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
     double c2 = 0.0;
-    if constexpr (SRC == 2) {
-      const double *r = pa.pack + nx + ix;  // Z-weighted, summed over species and ranks
+    if constexpr (SRC != 0) {
+      const double *r = pk + nx + ix;  // Z-weighted, summed over species and ranks
       c2 = r[0];
       for (int m = 0; m < nm; ++m) {
         c2 = c2 + sMode[m] * r[static_cast<size_t>(1 + m) * nx];
@@ -1737,15 +1757,7 @@ k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const XchgArgs x2, cons
         c2 = c2 + c1 * f.Z[s];
       }
     }
-    if constexpr (SRC == 1) {
-      f.charge[ix] = c2;  // exchange_charge picks its own elements up again (local_in_charge)
-    } else {
-      sCD[ix] = c2;
-    }
-  }
-  if constexpr (SRC == 1) exchange_charge(f, x2, sCD);
-  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
-    const double cd = chargeden_from(f, sCD[ix]);
+    const double cd = chargeden_from(f, c2);
     pa.cd_h[ix] = cd;
     sCD[ix] = cd;
   }
@@ -1990,18 +2002,23 @@ hipError_t launch_field_solve_xchg(const FieldArgs &f, const XchgArgs &x, hipStr
   return hipGetLastError();
 }
 
-hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const XchgArgs *x1, const XchgArgs *x2,
-                                   hipStream_t st) {
+hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const XchgArgs *x1, hipStream_t st) {
   if (2 * f.nmode > FIELD_THREADS) return hipErrorInvalidValue;
-  const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
-                                       (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
+  size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
+                                 (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
   const XchgArgs none{};
-  if (x1 && x2) {
-    hipLaunchKernelGGL(k_field_solve_pair<1>, dim3(1), dim3(FIELD_THREADS), lds, st, f, *x1, *x2, pa);
+  if (x1) {
+    lds += sizeof(double) * (2 + 2 * static_cast<size_t>(f.nmode)) * f.nx;  // the packed vector
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_field_solve_pair<1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_field_solve_pair<1>, dim3(1), dim3(FIELD_THREADS), lds, st, f, *x1, pa);
   } else if (pa.pack) {
-    hipLaunchKernelGGL(k_field_solve_pair<2>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, none, pa);
+    hipLaunchKernelGGL(k_field_solve_pair<2>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, pa);
   } else {
-    hipLaunchKernelGGL(k_field_solve_pair<0>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, none, pa);
+    hipLaunchKernelGGL(k_field_solve_pair<0>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, pa);
   }
   return hipGetLastError();
 }

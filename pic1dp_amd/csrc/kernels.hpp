@@ -183,10 +183,13 @@ struct XchgArgs {
   long long timeout_ticks;                     // wall_clock64 ticks (100 MHz) a rank waits for its peers
   int rank, nranks;
   int local_in_charge;                         // 1: this rank's charge2 is already in FieldArgs::charge
+  int vstride;                                 // doubles per (parity, rank) slot: XCHG_MAX_VEC * nx
 };
+// vectors of nx doubles one exchange can carry: charge2 + the 1 + 2 * PRED_MAX_MODES prediction slices
+constexpr int XCHG_MAX_VEC = 6;
 // both fields of a one-pass step in one launch: the new state's field from its deposited charge, then the
-// NEXT step's half-step field from k_step_one's prediction (x1, x2: the two exchanges of a multi-rank
-// run, or both null for one rank)
+// NEXT step's half-step field from k_step_one's prediction (x1: the ONE exchange of a multi-rank step -- charge2
+// and the Z-weighted prediction slices travel together --, or null)
 struct PairArgs {
   double *pred;     // [nspecies][1 + 2 nmode][nx], consumed (re-zeroed)
   double *E_h;      // [nx] half-step field of the next step
@@ -196,8 +199,7 @@ struct PairArgs {
 };
 // this rank's charge2 and Z-weighted prediction slices packed for one all-reduce (accumulators re-zeroed)
 hipError_t launch_charge_pack(const FieldArgs &f, double *pred, int nm_pred, double *pack, hipStream_t st);
-hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const XchgArgs *x1, const XchgArgs *x2,
-                                   hipStream_t st);
+hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const XchgArgs *x1, hipStream_t st);
 // k_step_one's prediction accumulators [nspecies][1 + 2 nm][nx] + the field's kept modes -> this rank's
 // charge2 of the next first sub-step in f.charge; the accumulators are re-zeroed
 hipError_t launch_pred_combine(const FieldArgs &f, double *pred, int nm_pred, hipStream_t st);

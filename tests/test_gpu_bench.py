@@ -97,6 +97,14 @@ def test_bench_two_ranks_share_the_gpu(amd, config, particles, allreduce):
     nsteps = d["warmup_effective"] + steps
     e = virtual_rank_energy(amd, dict(nparticle_max=total, **phys), 2, nsteps)
     assert abs(d["field_energy_end"] / e - 1.0) < 1e-10
+    if allreduce == "host":
+        # the exchange measured beside another headline sum (on the driver's node: beside RCCL): both
+        # workloads, with the physics of the headline run continued
+        x = d["exchange"]
+        assert x["weak"]["value"] > 0 and x["strong_1e8_total"]["value"] > 0
+        assert "field_solve_ms_per_step" in x["weak"]["attribution"]
+    else:
+        assert "exchange" not in d
     if strong_cfg:
         assert "strong_1e8_total" not in d           # the headline is the strong run itself
     else:

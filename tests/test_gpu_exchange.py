@@ -40,10 +40,10 @@ def test_exchange_ranks_share_the_gpu(amd, tmp_path, nproc, mode):
         assert np.array_equal(r["hist"], ranks[0]["hist"])
         if mode == "calls":
             assert np.array_equal(r["fields"], ranks[0]["fields"])
-    # the initial deposit, two sums per step (the second sub-step's charge and the predicted
-    # first-sub-step charge of the next step), plus in step() the first step's own first sub-step;
-    # through the call sites the last prediction is never asked for
-    expect = 1 + 2 * steps + (1 if mode == "step" else 0)
+    # step(): the initial deposit, the first step's own first sub-step, then ONE exchange per step (the
+    # new state's charge and the prediction of the next first sub-step's travel together); through the
+    # call sites: the initial deposit and one exchange per collect_charge
+    expect = 2 + steps if mode == "step" else 1 + 2 * steps
     assert all(int(r["exchanges"]) == expect for r in ranks)
     # the exchange areas are fine-grained device memory (coherent across agents inside a kernel),
     # not one of the fall-backs
