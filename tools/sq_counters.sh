@@ -24,7 +24,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        for name in ("k_step_half", "k_step_full"):
+        for name in ("k_step_half", "k_step_full", "k_step_one"):
             if name in k:
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
