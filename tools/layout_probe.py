@@ -7,7 +7,6 @@ import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["PIC1DP_PLACEMENT_TRIES"] = "1"
 import pic1dp_amd  # noqa: E402
 from pic1dp_amd._lib import check  # noqa: E402
 

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """placement_probe.py -- what makes the whole-step kernels' time depend on where the
-marker arrays lie?  All engines live in ONE process (placement effects only compare
+marker arrays lie?  (Needs the UNTILED build, -DPIC1DP_TILE_LOG2=0: PIC1DP_SLAB_STAGGER sets the
+array-to-array distance there; layout 0 = four separate hipMallocs existed only in the commit that
+ran experiment C.  Logs: profiles/r02/experiments/placement_probe{1,2}.log.)  All engines live in ONE process (placement effects only compare
 inside one), each is loaded, warmed up and timed on the same physics.
 
   A. one slab, arrays k*stride apart with stride = 2 MiB multiple + stagger, for a
@@ -12,8 +14,6 @@ inside one), each is loaded, warmed up and timed on the same physics.
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["PIC1DP_PLACEMENT_TRIES"] = "1"
-os.environ["PIC1DP_PLACEMENT_VERBOSE"] = "1"
 import pic1dp_amd  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**8

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""placement_test.py -- does kernel time depend on where hipMalloc put the marker
+"""placement_spread.py -- does kernel time depend on where hipMalloc put the marker
 arrays?  Creates the engine several times in one process and times the whole-step
 kernels each time."""
 import os

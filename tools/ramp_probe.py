@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ramp_test.py -- time per step in consecutive batches right after the load:
+"""ramp_probe.py -- time per step in consecutive batches right after the load:
 does the GPU need a while to reach its streaming rate?"""
 import os
 import sys
