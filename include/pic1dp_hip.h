@@ -243,8 +243,10 @@ int pic1dp_hip_solve_field(pic1dp_ctx *ctx);
  * src/pic1dp.F90:80); irk = global_irk = 1 or 2.
  * In the reference's sequence push(1), collect_charge, solve_field, push(2),
  * collect_charge, solve_field the push is only noted and the collect_charge
- * that follows runs one whole-step kernel for both (88 instead of 184 bytes per
- * marker and step).  Whatever looks at the markers in between first gets the
+ * that follows runs one whole-step kernel for both; from the second step on the
+ * collect_charge after push(1) touches no marker at all -- the previous step's
+ * kernel has predicted its charge -- so a step is ONE pass over
+ * the markers (56-72 instead of 184 bytes per marker and step).  Whatever looks at the markers in between first gets the
  * ordinary kernels run, so every observable state is the eager one, bit for
  * bit.  PIC1DP_LAZY_CALLS=0 in the environment: one kernel per call, at once. */
 int pic1dp_hip_push(pic1dp_ctx *ctx, int32_t irk);
@@ -265,12 +267,17 @@ int pic1dp_hip_substep(pic1dp_ctx *ctx, int32_t irk);
  * (src/pic1dp.F90:79-93).  The field energy int E^2 dx after every step is
  * appended to a device-side history (see pic1dp_hip_energy_history). */
 int pic1dp_hip_step(pic1dp_ctx *ctx, int32_t nsteps);
-/* how pic1dp_hip_step advances a time step (results are bit-identical given
+/* how pic1dp_hip_step advances a time step (marker pushes are bit-identical given
  * identical fields; only the memory traffic differs):
  *   0 (default) whole-step kernels: the half-step state is recomputed in the
- *     second sub-step instead of being stored and re-read, state updated in place
- *     (88 B per marker per step); falls back to mode 1 when nx is too large
- *     for three grid tiles in LDS
+ *     second sub-step instead of being stored and re-read, state updated in place;
+ *     from the second step on ONE pass over the markers per step (the second
+ *     sub-step's kernel also deposits the next first sub-step's charge as
+ *     coefficients of the kept field modes: 56-72 B per marker per step; the
+ *     half-step charge then equals a marker-by-marker deposit up to rounding;
+ *     PIC1DP_PREDICT=0 in the environment keeps the two passes, 88 B); falls back
+ *     to two passes for more than two kept modes or nx beyond ~2400, and to mode 1
+ *     when nx is too large for three grid tiles in LDS
  *   1 two fused sub-steps through the RK ping-pong sets (136 B per marker) */
 int pic1dp_hip_set_step_mode(pic1dp_ctx *ctx, int32_t mode);
 /* on != 0: a time step after which the driver will call output_all (the cadence test of
