@@ -484,7 +484,16 @@ def main():
         # k_step_one hands -f0'/f0 of the new velocity to the next step through memory (8 B written,
         # 8 B read per marker) unless PIC1DP_CARRY=0
         carry_b = 16.0 if (deltaf and phys.get("iptcldist", 3) in (2, 3) and os.environ.get("PIC1DP_CARRY", "1") != "0") else 0.0
-        if one_n:
+        if one_n and eng.predict_kind() == 2:
+            kname = ("k_step_sums (one pass per step on a grid whose prediction tiles outgrow the LDS: recompute half-step "
+                     "state, push+gather, wrap, deposit, store in place, and the six sums that predict the next step's "
+                     "half-step field)")
+            kms, kn, kbytes = one_ms, one_n, rd + wr + carry_b
+            path = ("one pass over the markers per step (k_step_sums; the next half-step field follows from six sums "
+                    "over the markers taken by the previous step's kernel)")
+            if a.unfused:
+                path += ", reached through the three reference call sites per sub-step (lazy call sites)"
+        elif one_n:
             kname = ("k_step_one (one pass per step: recompute half-step state, push+gather, wrap, deposit, store in "
                      "place, and the deposits that predict the next step's first-sub-step charge)")
             kms, kn, kbytes = one_ms, one_n, rd + wr + carry_b
@@ -547,7 +556,8 @@ def main():
                                "sub-step" % world,
                 "path": path, "allreduce": headline_kind, "rccl_ranks": world if headline_kind == "rccl" else 0,
                 "marker_layout": "x, v, w, p interleaved in 32 KiB tiles in one slab per species",
-                "kernel_launches_in_timed_steps": {k: v[1] for k, v in ktab.items() if v[1]},
+                "kernel_launches_in_timed_steps": {("k_step_sums" if k == "k_step_one" and eng.predict_kind() == 2 else k): v[1]
+                                                   for k, v in ktab.items() if v[1]},
                 "sync": sync_kind, "load_seconds": job.load_s,
             },
             "roofline": {

@@ -275,11 +275,20 @@ int pic1dp_hip_step(pic1dp_ctx *ctx, int32_t nsteps);
  *     sub-step's kernel also deposits the next first sub-step's charge as
  *     coefficients of the kept field modes: 56-72 B per marker per step; the
  *     half-step charge then equals a marker-by-marker deposit up to rounding;
- *     PIC1DP_PREDICT=0 in the environment keeps the two passes, 88 B); falls back
- *     to two passes for more than two kept modes or nx beyond ~2400, and to mode 1
- *     when nx is too large for three grid tiles in LDS
+ *     PIC1DP_PREDICT=0 in the environment keeps the two passes, 88 B).  The
+ *     prediction is held as LDS tiles (up to two kept modes, nx up to ~2400) or,
+ *     for larger grids with one kept mode (nx up to ~5000), as six sums over the
+ *     markers -- then, through the call sites, field_chargeden between
+ *     collect_charge after push(1) and the collect_charge after push(2) holds the
+ *     kept mode's content of the half-step charge density only (all that
+ *     solve_field looks at; nothing in the reference driver reads it there).
+ *     Falls back to two passes otherwise, and to mode 1 when nx is too large for
+ *     three grid tiles in LDS
  *   1 two fused sub-steps through the RK ping-pong sets (136 B per marker) */
 int pic1dp_hip_set_step_mode(pic1dp_ctx *ctx, int32_t mode);
+/* how step mode 0 predicts the next first sub-step's charge for this input: 0 not at
+ * all (two passes per step), 1 prediction tiles (k_step_one), 2 six sums (k_step_sums) */
+int pic1dp_hip_predict_kind(pic1dp_ctx *ctx, int32_t *kind);
 /* on != 0: a time step after which the driver will call output_all (the cadence test of
  * src/pic1dp.F90:98-107 evaluated one step ahead from the library's time, see set_time; the
  * last step of a pic1dp_hip_step call, or the collect_charge that follows push(2)) takes the

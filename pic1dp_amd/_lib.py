@@ -104,6 +104,7 @@ SIGNATURES = {
     "pic1dp_hip_step": [_P, C.c_int32],
     "pic1dp_hip_set_step_mode": [_P, C.c_int32],
     "pic1dp_hip_set_output_fusion": [_P, C.c_int32],
+    "pic1dp_hip_predict_kind": [_P, C.POINTER(C.c_int32)],
     "pic1dp_hip_get_field_half": [_P, _P],
     "pic1dp_hip_set_field_solver": [_P, C.c_int32],
     "pic1dp_hip_sync": [_P],

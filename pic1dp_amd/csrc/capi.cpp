@@ -104,6 +104,10 @@ struct pic1dp_ctx {
   // one pass per step (kernels.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
   // prediction accumulators [nspecies][1 + 2 nm][nx], the combined half-step charge density
   double *d_tabA = nullptr, *d_tabB = nullptr, *d_pred = nullptr, *d_cd_h = nullptr, *d_mode_h = nullptr;
+  int pred_kind = 0;               // 0 no one-pass step here, 1 prediction tiles (k_step_one), 2 six sums (k_step_sums)
+  PredTab pred_tab{};              // kind 2: sums / Gram matrix of the kept mode's tables (host, libm)
+  int eh_modes = 0;                // kind 2: where the kept mode of the Eh about to be used lies: 0 nowhere, 1 fa.mode_*, 2 d_mode_h
+  bool charge_pending_pred = false;  // kind 2: charge_local handed out the six sums, not a charge vector
   double *d_Ehn = nullptr;         // half-step field predicted for the NEXT step (d_Eh stays the last step's)
   double *d_pack = nullptr;        // [2 + 2 nmode][nx] one all-reduce per one-pass step (RCCL path)
   int predict = 1;                 // PIC1DP_PREDICT=0: always two passes per step
@@ -607,7 +611,7 @@ static size_t step_lds_bytes(int nx, bool full, int rcopies);
 static bool output_follows(const pic1dp_ctx *c);
 static void field_written(pic1dp_ctx *c, bool by_solve);
 static bool pred_usable(const pic1dp_ctx *c);
-static int pred_to_charge(pic1dp_ctx *c);
+static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f);
 static int diag_buffers(pic1dp_ctx *c);
 static int diag_max_blocks(const pic1dp_ctx *c);
 static size_t dist_len(const pic1dp_input &in);
@@ -767,16 +771,34 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
         fim[static_cast<size_t>(m) * nx + ix] = -sin_fn(th);
       }
     }
-    if (nm <= PRED_MAX_MODES) {  // k_step_one's tables: E = 2*(cos re + (-sin) im) (src/pic1dp_field.F90:251-257)
+    // one pass per step: with prediction tiles where they fit the LDS (k_step_one), as six sums for larger
+    // grids with one kept mode (k_step_sums); PIC1DP_PRED_KIND=1|2 insists on one of them (tests)
+    if (nm <= PRED_MAX_MODES && step_one_lds_bytes(nx, c->grid.rcopies, nm) <= PARTICLE_LDS_CAP)
+      c->pred_kind = 1;
+    else if (nm == 1 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP)
+      c->pred_kind = 2;
+    if (const char *e = std::getenv("PIC1DP_PRED_KIND")) {
+      const int k = std::atoi(e);
+      if (k == 2 && nm == 1 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP) c->pred_kind = 2;
+      if (k == 1 && c->pred_kind != 1) c->pred_kind = 0;
+    }
+    if (c->pred_kind) {  // the tables: E = 2*(cos re + (-sin) im) (src/pic1dp_field.F90:251-257)
       std::vector<double> ta(fre.size()), tb(fim.size());
       for (size_t i = 0; i < fre.size(); ++i) ta[i] = 2.0 * fre[i], tb[i] = 2.0 * fim[i];
-      const size_t pred_doubles = static_cast<size_t>(ns) * (1 + 2 * nm) * nx;
+      if (c->pred_kind == 2) {
+        PredTab &pt = c->pred_tab;
+        for (int ix = 0; ix < nx; ++ix) {
+          pt.sum_fre += fre[ix], pt.sum_fim += fim[ix];
+          pt.g11 += fre[ix] * fre[ix], pt.g22 += fim[ix] * fim[ix], pt.g12 += fre[ix] * fim[ix];
+        }
+      }
+      const size_t pred_doubles = c->pred_kind == 2 ? 8 : static_cast<size_t>(ns) * (1 + 2 * nm) * nx;
       HIP_TRY_C(hipMalloc(&c->d_tabA, sizeof(double) * nm * nx));
       HIP_TRY_C(hipMalloc(&c->d_tabB, sizeof(double) * nm * nx));
       HIP_TRY_C(hipMalloc(&c->d_pred, sizeof(double) * pred_doubles));
       HIP_TRY_C(hipMalloc(&c->d_cd_h, sizeof(double) * nx));
       HIP_TRY_C(hipMalloc(&c->d_Ehn, sizeof(double) * nx));
-      HIP_TRY_C(hipMalloc(&c->d_pack, sizeof(double) * (2 + 2 * nm) * nx));
+      HIP_TRY_C(hipMalloc(&c->d_pack, sizeof(double) * pack_doubles(nx, nm, c->pred_kind)));
       HIP_TRY_C(hipMalloc(&c->d_mode_h, sizeof(double) * 2 * nm));
       HIP_TRY_C(hipMemcpy(c->d_tabA, ta.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
       HIP_TRY_C(hipMemcpy(c->d_tabB, tb.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
@@ -1115,6 +1137,8 @@ static int deposit_or_step(pic1dp_ctx *c) {
   if (c->lz == LZ_PUSH2) {
     c->state_version++;
     const bool diag = c->fuse_output && output_follows(c);
+    // Eh = d_E: the kept modes describe it when the mode-filter solve wrote it last
+    c->eh_modes = (c->field_solver == 0 && c->modes_field_version == c->field_version) ? 1 : 0;
     if (int rc = step_particles(c, true, c->d_E0, c->d_E, diag, !diag)) return rc;
     c->lz = LZ_CLEAN;
     return 0;
@@ -1134,8 +1158,7 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
     HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
     c->lz = LZ_HALF;
     Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
-    if (int rc = pred_to_charge(c)) return rc;
-    HIP_TRY(launch_chargeden(c->fa, false, c->st));
+    if (int rc = pred_to_chargeden(c, c->fa)) return rc;
     return tm.end();
   }
   const bool noted = c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2;
@@ -1412,15 +1435,18 @@ static bool output_follows(const pic1dp_ctx *c) {
 // One pass per step (kernels.hip k_step_one) needs: the mode-filter solver (the kept modes must
 // describe E), few kept modes, and LDS for E0, Eh, the mode tables and the four accumulators
 static bool predict_capable(const pic1dp_ctx *c) {
-  return c->predict && c->d_pred && c->field_solver == 0 && step_recompute_ok(c) && c->in.nmode <= PRED_MAX_MODES &&
-         step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode) <= PARTICLE_LDS_CAP;
+  return c->predict && c->pred_kind != 0 && c->d_pred && c->field_solver == 0 && step_recompute_ok(c);
+}
+static size_t pred_doubles(const pic1dp_ctx *c) {
+  return c->pred_kind == 2 ? 8 : static_cast<size_t>(c->in.nspecies) * (1 + 2 * c->in.nmode) * c->in.nx;
 }
 
 // full = true: the caller has bumped state_version for this step; the state the kernel READS is version - 1
 static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag, bool pred) {
   if (pred && (!full || diag || !predict_capable(c))) pred = false;
+  if (pred && c->pred_kind == 2 && c->eh_modes == 0) pred = false;  // k_step_sums forms Eh from its kept mode
   if (pred && c->pred_version != 0)  // a prediction nobody used: the accumulators start from zero
-    HIP_TRY(hipMemsetAsync(c->d_pred, 0, sizeof(double) * c->in.nspecies * (1 + 2 * c->in.nmode) * c->in.nx, c->st));
+    HIP_TRY(hipMemsetAsync(c->d_pred, 0, sizeof(double) * pred_doubles(c), c->st));
   // the diagnostics of output_all inside k_step_full: when asked for, the LDS holds them, and the
   // tuning build of the marker loop is the default one
   if (diag) {
@@ -1479,8 +1505,14 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     if (pred) {  // k_step_one: the full step + the prediction of the next first sub-step's charge
       a.tabA = c->d_tabA;
       a.tabB = c->d_tabB;
-      a.pred = c->d_pred + static_cast<size_t>(s) * (1 + 2 * c->in.nmode) * c->in.nx;
+      a.pred_kind = c->pred_kind;
+      a.pred = c->pred_kind == 2 ? c->d_pred  // six sums, all species together (Z folded in)
+                                 : c->d_pred + static_cast<size_t>(s) * (1 + 2 * c->in.nmode) * c->in.nx;
       a.pred_nm = c->in.nmode;
+      if (c->pred_kind == 2) {
+        a.eh_re = c->eh_modes == 2 ? c->d_mode_h : c->fa.mode_re;
+        a.eh_im = c->eh_modes == 2 ? c->d_mode_h + 1 : c->fa.mode_im;
+      }
       // -f0'/f0 at the new velocity is what the NEXT step's recomputation of the half-step state
       // needs: it goes there through memory (16 B per marker and step; k_step_one 1.45 -> 1.33 ms at
       // 1e8 markers, tools/ab_pred.sh).  PIC1DP_CARRY=0: evaluated again instead.
@@ -1492,9 +1524,21 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
         a.t2_mode = S.t2_version == read_version ? 2 : 1;
         S.t2_version = c->state_version;
       }
-      lc.lds = step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode);
-      const bool two = 2 * lc.lds <= PARTICLE_LDS_CAP;
-      lc.threads = c->threads_req > 0 ? c->threads_req : (two ? 768 : 1024);
+      lc.lds = c->pred_kind == 2 ? step_sums_lds_bytes(c->in.nx, c->grid.rcopies)
+                                 : step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode);
+      bool two = 2 * lc.lds <= PARTICLE_LDS_CAP;
+      int th2 = 768;
+      int th1 = 1024;
+      if (c->pred_kind == 2) {
+        // k_step_sums keeps its registers: four waves per SIMD with the exp-bearing distributions (one
+        // workgroup of 1024 per CU), eight with the others, which saturate the memory system with far fewer
+        // (tools/ab_sums_shapes.sh: 1e8 markers, Maxwellian, nx 4096: 512 x 1 0.925 ms, 1024 x 1 0.965 ms)
+        if (c->in.deltaf && (c->in.iptcldist == 2 || c->in.iptcldist == 3))
+          two = false;
+        else
+          th1 = 512;
+      }
+      lc.threads = c->threads_req > 0 ? c->threads_req : (two ? th2 : th1);
       const int bpc = c->bpc_req > 0 ? c->bpc_req : (two ? 2 : 1);
       const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
       lc.blocks = static_cast<int>(std::max<int64_t>(1, std::min(static_cast<int64_t>(c->num_cu) * bpc, need)));
@@ -1531,12 +1575,8 @@ static bool pred_usable(const pic1dp_ctx *c) {
          predict_capable(c);
 }
 
-// prediction -> charge1 of the next first sub-step in d_charge (combined locally, summed over ranks)
-static int pred_to_charge(pic1dp_ctx *c) {
-  HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
-  c->pred_version = 0;  // consumed: the accumulators are zero again
-  const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
-  if (!multi) return 0;
+// the local result of the prediction summed over ranks in d_charge
+static int pred_reduce(pic1dp_ctx *c) {
   if (xchg_active(c)) {
     Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
     XchgArgs x = next_xchg_args(c);
@@ -1547,13 +1587,35 @@ static int pred_to_charge(pic1dp_ctx *c) {
   return allreduce_charge(c);
 }
 
+// prediction -> chargeden of the next first sub-step (f.chargeden: field_chargeden, or a scratch vector).
+// Tiles: combined locally, summed over ranks, scaled.  Six sums: summed over ranks, then the kept mode's
+// content of that charge density -- all the solve looks at (k_pred_chargeden).
+static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f) {
+  c->pred_version = 0;  // consumed: the accumulators are zero again afterwards
+  const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
+  if (c->pred_kind == 2) {
+    if (!multi) {
+      HIP_TRY(launch_pred_chargeden(f, c->pred_tab, c->d_pred, c->d_pred, c->st));
+      return 0;
+    }
+    HIP_TRY(launch_pred_to_charge(c->fa, c->d_pred, c->st));
+    if (int rc = pred_reduce(c)) return rc;
+    HIP_TRY(launch_pred_chargeden(f, c->pred_tab, nullptr, c->d_charge, c->st));
+    return 0;
+  }
+  HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
+  if (multi)
+    if (int rc = pred_reduce(c)) return rc;
+  HIP_TRY(launch_chargeden(f, false, c->st));
+  return 0;
+}
+
 // step() path: Eh of the NEXT step from the prediction, right after the field of the new state is solved
 static int predict_half_field(pic1dp_ctx *c) {
-  if (int rc = pred_to_charge(c)) return rc;
-  Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
   f.chargeden = c->d_cd_h;
-  HIP_TRY(launch_chargeden(f, false, c->st));
+  if (int rc = pred_to_chargeden(c, f)) return rc;
+  Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   f.E = c->d_Ehn;
   f.mode_re = c->d_mode_h;
   f.mode_im = c->d_mode_h + c->in.nmode;
@@ -1574,9 +1636,9 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool 
   const bool will_pack = pred && c->pred_version == c->state_version && multi && !fused_xchg && c->comm != nullptr &&
                          !xchg_active(c) && c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (will_pack) {
-    HIP_TRY(launch_charge_pack(c->fa, c->d_pred, c->in.nmode, c->d_pack, c->st));
+    HIP_TRY(launch_charge_pack(c->fa, c->d_pred, c->in.nmode, c->pred_kind, c->d_pack, c->st));
     Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
-    ncclResult_t r = rccl().AllReduce(c->d_pack, c->d_pack, static_cast<size_t>(2 + 2 * c->in.nmode) * c->in.nx, ncclDouble,
+    ncclResult_t r = rccl().AllReduce(c->d_pack, c->d_pack, pack_doubles(c->in.nx, c->in.nmode, c->pred_kind), ncclDouble,
                                       ncclSum, c->comm, c->st);
     if (r != ncclSuccess) return fail(PIC1DP_ERR_COMM, "ncclAllReduce: %s", rccl().GetErrorString(r));
     if (int rc = sp.end()) return rc;
@@ -1592,8 +1654,8 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool 
   const bool pair = pred && c->pred_version == c->state_version && (!multi || fused_xchg || will_pack) &&
                     c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (pair) {
-    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr};
-    if (will_pack) {  // both charge sums of the step came in ONE all-reduce of (2 + 2 nmode) nx doubles
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab};
+    if (will_pack) {  // both charge sums of the step came in ONE all-reduce (pack_doubles)
       pa.pack = c->d_pack;
       HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));
     } else if (fused_xchg) {  // ONE exchange: charge2 and the prediction slices travel together
@@ -1632,8 +1694,11 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
       const bool have_eh = pc && c->eh_version == c->state_version && c->eh_field_version == c->field_version;
       if (have_eh) {
         std::swap(c->d_Eh, c->d_Ehn);  // d_Eh: the half-step field of the step being taken
+        c->eh_modes = 2;               // its kept modes: d_mode_h
       } else if (int rc = step_phase(c, false, c->d_Eh, false)) {
         return rc;
+      } else {
+        c->eh_modes = c->field_solver == 0 ? 1 : 0;  // that solve left them in fa.mode_re / mode_im
       }
       // the host can only call output_all after the last step of this call
       const bool diag = c->fuse_output && it == nsteps - 1 && output_follows(c);
@@ -1656,6 +1721,13 @@ int pic1dp_hip_set_step_mode(pic1dp_ctx *c, int32_t mode) {
   CHECK_CTX(c);
   if (mode != 0 && mode != 1) return fail(PIC1DP_ERR_ARG, "step mode must be 0 or 1");
   c->step_mode = mode;
+  return 0;
+}
+
+int pic1dp_hip_predict_kind(pic1dp_ctx *c, int32_t *kind) {
+  CHECK_CTX(c);
+  if (!kind) return fail(PIC1DP_ERR_ARG, "null argument");
+  *kind = predict_capable(c) ? c->pred_kind : 0;
   return 0;
 }
 
@@ -2161,7 +2233,12 @@ int pic1dp_hip_charge_local(pic1dp_ctx *c, double *charge2) {
   if (c->lz == LZ_PUSH1 && pred_usable(c)) {  // predicted by the previous step's kernel: no marker pass
     HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
     c->lz = LZ_HALF;
-    HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
+    if (c->pred_kind == 2) {  // the six sums in charge2[0..5], zeros behind: the host's sum over ranks sums them
+      HIP_TRY(launch_pred_to_charge(c->fa, c->d_pred, c->st));
+      c->charge_pending_pred = true;
+    } else {
+      HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
+    }
     c->pred_version = 0;
   } else {
     if (int rc = deposit_or_step(c)) return rc;
@@ -2180,6 +2257,11 @@ int pic1dp_hip_charge_reduced(pic1dp_ctx *c, const double *charge1) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpy(c->d_charge, charge1, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
   c->charge_pending = false;
+  if (c->charge_pending_pred) {  // what came back are the summed prediction sums
+    c->charge_pending_pred = false;
+    HIP_TRY(launch_pred_chargeden(c->fa, c->pred_tab, nullptr, c->d_charge, c->st));
+    return 0;
+  }
   HIP_TRY(launch_chargeden(c->fa, false, c->st));
   return 0;
 }

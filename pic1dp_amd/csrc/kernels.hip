@@ -389,15 +389,30 @@ __device__ __forceinline__ One push_core(double v, double w, double p, double xb
 
 // gather + push of one marker, src/pic1dp_interaction.F90:246-338:
 // derivatives at (x, v, w), base (xb, vb, wb), field tile sE, step dt
-template <int DIST, int MODE, int POW2, int T2MODE = 0>
+// where push_one takes the field at a grid point from: a staged tile, or -- for a mode-filter field of one kept
+// mode whose tile is not staged (k_step_sums) -- the mode's tables A = 2 fre, B = 2 fim and its amplitudes:
+// (fre re + fim im) * 2 as the solve writes it (src/pic1dp_field.F90:251-257) and A re + B im are the same
+// bits (the factor 2 commutes with every rounding; no contraction in this build)
+struct ModeField {
+  const double *A, *B;
+  double re, im;
+};
+__device__ __forceinline__ double field_at(const double *t, int i) { return t[i]; }
+__device__ __forceinline__ double field_at(const ModeField &m, int i) {
+  double e = m.A[i] * m.re;
+  e = e + m.B[i] * m.im;
+  return e;
+}
+
+template <int DIST, int MODE, int POW2, int T2MODE = 0, class FS = const double *>
 __device__ __forceinline__ One push_one(double x, double v, double w, double p, double xb,
-                                        double vb, double wb, const double *sE, double dt,
+                                        double vb, double wb, const FS &sE, double dt,
                                         const GridConst &g, const SpeciesConst &s, double *t2io = nullptr) {
   int ix;
   double wl;
   locate(x, g, ix, wl);
-  double e = sE[ix] * wl;                // :254
-  e = e + sE[ix + 1] * (1.0 - wl);       // :257 (sE[nx] holds E[0])
+  double e = field_at(sE, ix) * wl;                // :254
+  e = e + field_at(sE, ix + 1) * (1.0 - wl);       // :257 (cell nx holds E[0])
   if constexpr (POW2 == 0) {
     if (s.fastc) {
       DivFast dv;
@@ -707,8 +722,9 @@ struct StepArgsDev {
   double *dist_partial;  // [gridDim][3] kinetic sums per workgroup
   // k_step_one: prediction of the next step's first-sub-step charge
   const double *tabA, *tabB;  // [pred_nm][nx]
-  double *pred;               // [1 + 2*pred_nm][nx]
+  double *pred;               // [1 + 2*pred_nm][nx]; k_step_sums: [8]
   int pred_nm, t2_mode;
+  const double *eh_re, *eh_im;  // k_step_sums: the kept mode of Eh
 };
 
 // CARRY: a species whose divisor constants are general numbers spends most of either kernel
@@ -794,9 +810,9 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
 }
 
 // one marker through the second half of the time step
-template <int DIST, int MODE, int POW2, bool CARRY = false>
+template <int DIST, int MODE, int POW2, bool CARRY = false, class FH = const double *>
 __device__ __forceinline__ One step_full_one(double x, double v, double w, double p, const double *sE0,
-                                             const double *sEh, double *sR, const StepArgsDev &a, double t2 = 0.0,
+                                             const FH &sEh, double *sR, const StepArgsDev &a, double t2 = 0.0,
                                              int *ix_out = nullptr, double *wl_out = nullptr) {
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   // sub-step 1 again (identical arithmetic), with the wrap the deposit applied
@@ -1106,6 +1122,153 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   for (int k = 0; k < 1 + 2 * nm; ++k) flush_tile(sP + static_cast<size_t>(k) * nx, a.pred + static_cast<size_t>(k) * nx, nx);
 }
 
+// ---------------------------------------------------------------------------
+// k_step_sums: the one pass per step for grids whose prediction tiles outgrow the LDS (nx > ~2400: the
+// Landau scaling run's nx = 4096), one kept mode.  Two observations replace five of k_step_one's tiles:
+// * the solve that turns the predicted half-step charge into Eh only ever looks at its projections on the
+//   kept mode's tables (src/pic1dp_field.F90:231-240), and the projection of a linear (CIC) deposit of q at x'
+//   is q times the gather of the table at x':  sum_c fre[c] deposit[c] = q A(x') / 2.  Hence, with
+//   c = dt/2 (p - w)(-f0'/f0)(v) Z/m at the marker's NEW state,
+//       sum_c fre[c] rho_h[c] = 1/2 [ K0c + re K1c + im K2c ],   K0c = sum_i Z w_i A(x'_i),
+//       K1c = sum_i Z c_i A(x_i) A(x'_i),  K2c = sum_i Z c_i B(x_i) A(x'_i),  and K0s, K1s, K2s with B(x'_i):
+//   six scalars per rank instead of three tiles -- accumulated in registers, reduced per workgroup, one
+//   global atomic each; when the new state's field is solved (re, im known) Eh follows from them
+//   (k_field_solve_pair_sums);
+// * Eh is its kept mode times the tables the kernel holds anyway: gathered from A, B and (re_h, im_h)
+//   (ModeField: the same bits as a staged tile of Eh).
+// LDS: E0, A, B, rho = 4 tiles (128 KiB at nx = 4096).  The six accumulators and the extra gathers cost
+// registers (101-117 VGPRs for the exp-bearing distributions: four waves per SIMD), which is why k_step_one
+// stays the kernel wherever its tiles fit (profiles/r02/experiments/pred_six_sums_*.log).
+// The second sub-step's push is untouched; Eh differs from the solve of a marker-by-marker deposit by
+// rounding only, as with k_step_one.  Full-f: q = p, K1 = K2 = 0.
+// ---------------------------------------------------------------------------
+struct PredSums {
+  double k0c = 0.0, k1c = 0.0, k2c = 0.0, k0s = 0.0, k1s = 0.0, k2s = 0.0;
+};
+
+// the six sums' terms of one marker in its NEW state n (x wrapped); (ix, wl): cell and left weight of n.x,
+// where the next step gathers its field (:250-257).  Returns -f0'/f0(n.v) for the carry.
+template <int DIST, int MODE, int POW2>
+__device__ __forceinline__ double pred_one_sums(const One &n, double p, int ix, double wl, const double *sA,
+                                                const double *sB, PredSums &k, const StepArgsDev &a) {
+  double t2 = 0.0;
+  double cA = 0.0, cB = 0.0;
+  if constexpr (MODE != MODE_FULLF) {
+    // the long chain first (-f0'/f0: exp, division), with little else alive
+    const double c = a.s.Z * pred_coef<DIST, MODE, POW2>(n.v, n.w, p, a.dt_half, a.s, t2);
+    PAIR_FENCE();
+    double A = sA[ix] * wl;                       // tables at x: the field the half push will see
+    A = A + sA[ix + 1] * (1.0 - wl);
+    double B = sB[ix] * wl;
+    B = B + sB[ix + 1] * (1.0 - wl);
+    cA = c * A, cB = c * B;
+  }
+  double xh = n.x + a.dt_half * n.v;              // the next step's half push of x (:261)
+  xh = wrap(xh, a.g.lx);                          // and the wrap + cell of its deposit (:102-108)
+  int ih;
+  double wh;
+  locate(xh, a.g, ih, wh);
+  double Ah = sA[ih] * wh;                        // tables at x': the deposit's projection weights
+  Ah = Ah + sA[ih + 1] * (1.0 - wh);
+  double Bh = sB[ih] * wh;
+  Bh = Bh + sB[ih + 1] * (1.0 - wh);
+  const double q = a.s.Z * (MODE == MODE_FULLF ? p : n.w);
+  k.k0c += q * Ah;
+  k.k0s += q * Bh;
+  if constexpr (MODE != MODE_FULLF) {
+    k.k1c += cA * Ah;
+    k.k2c += cB * Ah;
+    k.k1s += cA * Bh;
+    k.k2s += cB * Bh;
+  }
+  return t2;
+}
+
+template <int DIST, int MODE, int POW2, bool NT, int T2>
+__global__ void __launch_bounds__(1024) k_step_sums(const StepArgsDev a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  exp_table_init();
+  const int nx = a.g.nx;
+  const int ne = (nx + 2) & ~1;
+  double *sE0 = reinterpret_cast<double *>(smem);
+  double *sA = sE0 + ne;
+  double *sB = sA + ne;
+  double *sR0 = sB + ne;
+  double *sScr = sR0 + ((nx * a.g.rcopies + 1) & ~1);  // [16] reduction scratch
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    sE0[i] = a.E0[i];
+    sA[i] = a.tabA[i];
+    sB[i] = a.tabB[i];
+  }
+  zero_rho(sR0, a.g);
+  if (threadIdx.x == 0) {
+    sE0[nx] = a.E0[0];
+    sA[nx] = a.tabA[0];
+    sB[nx] = a.tabB[0];
+  }
+  __syncthreads();
+  const ModeField sEh{sA, sB, *a.eh_re, *a.eh_im};
+  double *sR = my_rho_copy(sR0, a.g);
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
+  constexpr bool CARRY_IN = (T2 == 2) && HAS_W;
+  constexpr bool CARRY_OUT = (T2 != 0) && HAS_W;
+  PredSums ks;
+  const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double2 *x2 = reinterpret_cast<double2 *>(a.x);
+  double2 *v2 = reinterpret_cast<double2 *>(a.v);
+  double2 *w2 = reinterpret_cast<double2 *>(a.w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+  double2 *t2 = reinterpret_cast<double2 *>(a.t2);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+    const int64_t o = tidx2(j);
+    const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
+    double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
+    if constexpr (CARRY_IN) T = ld2t<NT>(t2 + j);
+    int i0, i1;
+    double l0, l1;
+    const One n0 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x, &i0, &l0);
+    PAIR_FENCE();
+    const double u0 = pred_one_sums<DIST, MODE, POW2>(n0, P.x, i0, l0, sA, sB, ks, a);
+    PAIR_FENCE();
+    const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y, &i1, &l1);
+    PAIR_FENCE();
+    const double u1 = pred_one_sums<DIST, MODE, POW2>(n1, P.y, i1, l1, sA, sB, ks, a);
+    st2t<NT>(x2 + o, n0.x, n1.x);
+    if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
+    if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
+    if constexpr (CARRY_OUT) st2t<NT>(t2 + j, u0, u1);
+  }
+  if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = tidx(a.np - 1);
+    const double w = HAS_W ? a.w[i] : 0.0, p = a.p[i];
+    int ic;
+    double lc;
+    const One n = step_full_one<DIST, MODE, POW2, CARRY_IN>(a.x[i], a.v[i], w, p, sE0, sEh, sR, a,
+                                                            CARRY_IN ? a.t2[a.np - 1] : 0.0, &ic, &lc);
+    a.x[i] = n.x;
+    if constexpr (PUSH_V) a.v[i] = n.v;
+    if constexpr (HAS_W) a.w[i] = n.w;
+    const double u = pred_one_sums<DIST, MODE, POW2>(n, p, ic, lc, sA, sB, ks, a);
+    if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
+  }
+  __syncthreads();
+  flush_rho(sR0, a.rho, a.g);
+  // the six sums: workgroup reduction, one global atomic each
+  const double r0 = block_sum(ks.k0c, sScr), r1 = block_sum(ks.k1c, sScr), r2 = block_sum(ks.k2c, sScr);
+  const double r3 = block_sum(ks.k0s, sScr), r4 = block_sum(ks.k1s, sScr), r5 = block_sum(ks.k2s, sScr);
+  if (threadIdx.x == 0) {
+    glb_add(a.pred + 0, r0);
+    glb_add(a.pred + 1, r1);
+    glb_add(a.pred + 2, r2);
+    glb_add(a.pred + 3, r3);
+    glb_add(a.pred + 4, r4);
+    glb_add(a.pred + 5, r5);
+  }
+}
+
 template <typename K>
 hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
   if (lc.lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (idempotent, cheap)
@@ -1120,6 +1283,17 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc,
 template <int DIST, int MODE, int POW2, bool CARRY = false>
 hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
 #if PIC1DP_STEP_PIPE == 0
+  if (full && d.pred && d.pred_nm < 0) {  // one pass per step, prediction as six sums (large grids)
+    const int t2m = d.t2 ? d.t2_mode : 0;
+    if (d.nt) {
+      if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 2>, d, lc, st);
+      if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1>, d, lc, st);
+      return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 0>, d, lc, st);
+    }
+    if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 2>, d, lc, st);
+    if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 1>, d, lc, st);
+    return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 0>, d, lc, st);
+  }
   if (full && d.pred) {  // one pass per step: also predicts the next step's first-sub-step charge
     const int t2m = d.t2 ? d.t2_mode : 0;
     if (d.nt) {
@@ -1273,8 +1447,10 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.tabA = a.tabA;
   d.tabB = a.tabB;
   d.pred = a.pred;
-  d.pred_nm = a.pred_nm;
+  d.pred_nm = a.pred_kind == 2 ? -1 : a.pred_nm;  // -1: k_step_sums
   d.t2_mode = a.t2_mode;
+  d.eh_re = a.eh_re;
+  d.eh_im = a.eh_im;
   switch (a.iptcldist) {
     case 1: return launch_step_d<1>(d, a.deltaf, a.linear, full, lc, st);
     case 2: return launch_step_d<2>(d, a.deltaf, a.linear, full, lc, st);
@@ -1385,6 +1561,58 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_charge_pack(const FieldArgs f
       }
       pack[static_cast<size_t>(1 + k) * nx + ix] = c2;
     }
+  }
+}
+
+// ---- prediction as six sums (k_step_sums) ----
+// The forward sums sum_c fre[c] cd_h[c], sum_c fim[c] cd_h[c] of the NEXT first sub-step's charge density
+// from the six sums K (summed over species with Z, and over ranks) and the kept mode (re, im) of the field the
+// markers were just advanced to (derivation at k_step_sums); PredTab: what the host knows of the tables
+__device__ __forceinline__ void pred_forward_sums(const FieldArgs &f, const PredTab &pt, const double *K, double re, double im,
+                                                  double &acc_c, double &acc_s) {
+  double off = 0.0;
+  if (!f.deltaf)
+    for (int s = 0; s < f.nspecies; ++s) off = off + f.Z[s] * f.n0[s];  // chargeden -= Z n0, :142-148
+  acc_c = 0.5 * (K[0] + re * K[1] + im * K[2]) * f.dnx / f.lx - off * pt.sum_fre;
+  acc_s = 0.5 * (K[3] + re * K[4] + im * K[5]) * f.dnx / f.lx - off * pt.sum_fim;
+}
+
+// Call-site path: collect_charge after a noted push(1).  The host will call solve_field next, which works
+// from field_chargeden -- so chargeden gets the kept mode's content of the half-step charge density,
+//     cd[c] = alpha fre[c] + beta fim[c]   with   sum fre cd = acc_c,  sum fim cd = acc_s,
+// from which the ordinary solve reproduces the predicted Eh (to rounding).  What the filter drops is absent
+// from this chargeden; nothing in the reference driver reads chargeden between the sub-steps.
+// K: the six sums (already summed over ranks); pred (or null) is re-zeroed.
+__global__ void __launch_bounds__(FIELD_THREADS) k_pred_chargeden(const FieldArgs f, const PredTab pt, double *pred,
+                                                                 const double *K) {
+  __shared__ double sab[2];
+  if (threadIdx.x == 0) {
+    double ac, as;
+    pred_forward_sums(f, pt, K, f.mode_re[0], f.mode_im[0], ac, as);
+    const double det = pt.g11 * pt.g22 - pt.g12 * pt.g12;
+    sab[0] = (ac * pt.g22 - as * pt.g12) / det;
+    sab[1] = (as * pt.g11 - ac * pt.g12) / det;
+    if (pred)
+      for (int k = 0; k < 8; ++k) pred[k] = 0.0;
+  }
+  __syncthreads();
+  const double alpha = sab[0], beta = sab[1];
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) f.chargeden[ix] = alpha * f.fre[ix] + beta * f.fim[ix];
+}
+
+// this rank's six sums into the head of f.charge (rest zero) for a reduction over ranks (call-site path)
+__global__ void __launch_bounds__(FIELD_THREADS) k_pred_to_charge(const FieldArgs f, double *pred) {
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) f.charge[ix] = ix < 6 ? pred[ix] : 0.0;
+  __syncthreads();
+  if (threadIdx.x < 8) pred[threadIdx.x] = 0.0;
+}
+
+// k_charge_pack for the six sums: pack[0..nx) = charge2 of the new state, pack[nx..nx+8) = the sums (+ pad)
+__global__ void __launch_bounds__(FIELD_THREADS) k_charge_pack_sums(const FieldArgs f, double *pred, double *pack) {
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) pack[ix] = charge_local_one(f, ix);
+  if (threadIdx.x < 8) {
+    pack[f.nx + threadIdx.x] = pred[threadIdx.x];
+    pred[threadIdx.x] = 0.0;
   }
 }
 
@@ -1797,6 +2025,77 @@ k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const PairArgs pa) {
   solve_body<true>(g, sCD, sMode, sScr, sTab);
 }
 
+// k_field_solve_pair for k_step_sums' prediction: the field of the new state from its deposited charge, then --
+// with the kept mode just found -- the half-step field of the NEXT step from the six sums: no second forward
+// transform, the sums ARE the projections (pred_forward_sums), only the inverse (:251-257).
+// SRC: 0 one rank (charge from the local accumulators, sums from pa.pred), 1 one-hop exchange (charge2 and the
+// six sums travel together, one exchange of nx + 8 doubles), 2 packed (pa.pack holds both, already all-reduced)
+template <int SRC>
+__global__ void __launch_bounds__(FIELD_THREADS)
+k_field_solve_pair_sums(const FieldArgs f, const XchgArgs x1, const PairArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sCD = reinterpret_cast<double *>(smem);
+  double *sMode = sCD + f.nx;
+  double *sScr = sMode + 2 * f.nmode;
+  double *sTab = sScr + 16;
+  const int nx = f.nx;
+  double *sV = sTab + (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * nx : 0);  // SRC 1: [charge2 | six sums | pad]
+  __shared__ double sK[8];
+  if constexpr (SRC == 1) {
+    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sV[ix] = charge_local_one(f, ix);
+    if (threadIdx.x < 8) {
+      sV[nx + threadIdx.x] = pa.pred[threadIdx.x];
+      pa.pred[threadIdx.x] = 0.0;
+    }
+    __syncthreads();  // element i of the packed vector belongs to thread i % blockDim in the exchange
+    exchange_vectors(x1, sV, nx + 8);
+    __syncthreads();
+    if (threadIdx.x < 8) sK[threadIdx.x] = sV[nx + threadIdx.x];
+    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+      const double c = sV[ix];
+      f.charge[ix] = c;
+      const double cd = chargeden_from(f, c);
+      f.chargeden[ix] = cd;
+      sCD[ix] = cd;
+    }
+  } else if constexpr (SRC == 2) {
+    if (threadIdx.x < 8) sK[threadIdx.x] = pa.pack[nx + threadIdx.x];
+    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+      const double c = pa.pack[ix];
+      f.charge[ix] = c;
+      const double cd = chargeden_from(f, c);
+      f.chargeden[ix] = cd;
+      sCD[ix] = cd;
+    }
+  } else {
+    if (threadIdx.x < 8) {
+      sK[threadIdx.x] = pa.pred[threadIdx.x];
+      pa.pred[threadIdx.x] = 0.0;
+    }
+    solve_fill_chargeden<true, false>(f, sCD);
+  }
+  __syncthreads();
+  solve_body(f, sCD, sMode, sScr, sTab);
+  __syncthreads();  // E, mode_re / mode_im (also in sMode: re, im) are final
+  if (threadIdx.x == 0) {
+    double ac, as;
+    pred_forward_sums(f, pa.pt, sK, sMode[0], sMode[1], ac, as);
+    const double im_h = ac * f.sc_im * f.grad_inv[0];   // :234, :243-247
+    const double re_h = as * f.sc_re * f.grad_inv[0];   // :239
+    sMode[0] = re_h;
+    sMode[1] = im_h;
+    pa.mode_h[0] = re_h;
+    pa.mode_h[1] = im_h;
+  }
+  __syncthreads();
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {  // inverse, :251-257
+    double sacc = 0.0;
+    sacc = sacc + f.fre[ix] * sMode[0];
+    sacc = sacc + f.fim[ix] * sMode[1];
+    pa.E_h[ix] = sacc * 2.0;
+  }
+}
+
 // Many kept modes (2*nmode > FIELD_THREADS, up to the full spectrum nmode = nx/2,
 // SURVEY N4): the same arithmetic in the same order, spread over workgroups.
 // The reference's operators are then O(nx^2) dense matrices exactly as here
@@ -2034,6 +2333,23 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
   size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
                                  (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
   const XchgArgs none{};
+  if (pa.kind == 2) {
+    if (f.nmode != 1) return hipErrorInvalidValue;
+    if (x1) {
+      lds += sizeof(double) * pack_doubles(f.nx, 1, 2);
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_field_solve_pair_sums<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(k_field_solve_pair_sums<1>, dim3(1), dim3(FIELD_THREADS), lds, st, f, *x1, pa);
+    } else if (pa.pack) {
+      hipLaunchKernelGGL(k_field_solve_pair_sums<2>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, pa);
+    } else {
+      hipLaunchKernelGGL(k_field_solve_pair_sums<0>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, pa);
+    }
+    return hipGetLastError();
+  }
   if (x1) {
     lds += sizeof(double) * (2 + 2 * static_cast<size_t>(f.nmode)) * f.nx;  // the packed vector
     if (lds > 64 * 1024) {
@@ -2050,8 +2366,22 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
   return hipGetLastError();
 }
 
-hipError_t launch_charge_pack(const FieldArgs &f, double *pred, int nm_pred, double *pack, hipStream_t st) {
-  hipLaunchKernelGGL(k_charge_pack, dim3(1), dim3(FIELD_THREADS), 0, st, f, pred, nm_pred, pack);
+hipError_t launch_charge_pack(const FieldArgs &f, double *pred, int nm_pred, int kind, double *pack, hipStream_t st) {
+  if (kind == 2)
+    hipLaunchKernelGGL(k_charge_pack_sums, dim3(1), dim3(FIELD_THREADS), 0, st, f, pred, pack);
+  else
+    hipLaunchKernelGGL(k_charge_pack, dim3(1), dim3(FIELD_THREADS), 0, st, f, pred, nm_pred, pack);
+  return hipGetLastError();
+}
+
+hipError_t launch_pred_chargeden(const FieldArgs &f, const PredTab &pt, double *pred, const double *K, hipStream_t st) {
+  if (f.nmode != 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_pred_chargeden, dim3(1), dim3(FIELD_THREADS), 0, st, f, pt, pred, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_pred_to_charge(const FieldArgs &f, double *pred, hipStream_t st) {
+  hipLaunchKernelGGL(k_pred_to_charge, dim3(1), dim3(FIELD_THREADS), 0, st, f, pred);
   return hipGetLastError();
 }
 

@@ -134,8 +134,18 @@ struct StepArgs {
   const double *tabA, *tabB;
   double *pred;
   int pred_nm, t2_mode;
+  // pred_kind 2 (kernels.hip k_step_sums, for grids whose prediction tiles outgrow the LDS; one kept mode): pred is
+  // [8] -- six global sums K0c K1c K2c K0s K1s K2s shared by all species (Z folded in) --, and Eh is not staged
+  // but formed from the tables and its kept mode *eh_re, *eh_im (Eh = re A + im B, bit for bit what the solve wrote)
+  int pred_kind;  // 1 tiles (k_step_one), 2 sums (k_step_sums)
+  const double *eh_re, *eh_im;
 };
 constexpr int PRED_MAX_MODES = 2;
+// dynamic LDS of k_step_sums: E0, A, B tiles (with guard cell), rho copies, reduction scratch
+inline size_t step_sums_lds_bytes(int nx, int rcopies) {
+  const size_t ne = static_cast<size_t>((nx + 2) & ~1);
+  return sizeof(double) * (3 * ne + ((static_cast<size_t>(nx) * rcopies + 1) & ~static_cast<size_t>(1)) + 16);
+}
 // dynamic LDS of k_step_one: E0, Eh, A_m, B_m tiles (with guard cell), rho copies, 1 + 2 nm prediction tiles
 inline size_t step_one_lds_bytes(int nx, int rcopies, int nm) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
@@ -190,16 +200,33 @@ constexpr int XCHG_MAX_VEC = 6;
 // both fields of a one-pass step in one launch: the new state's field from its deposited charge, then the
 // NEXT step's half-step field from k_step_one's prediction (x1: the ONE exchange of a multi-rank step -- charge2
 // and the Z-weighted prediction slices travel together --, or null)
-struct PairArgs {
-  double *pred;     // [nspecies][1 + 2 nmode][nx], consumed (re-zeroed)
-  double *E_h;      // [nx] half-step field of the next step
-  double *mode_h;   // [2 nmode] its kept modes (scratch)
-  double *cd_h;     // [nx] its charge density (scratch)
-  double *pack;     // null, or [2 + 2 nmode][nx]: charge2 and the Z-weighted prediction slices, already summed over ranks
+// what the host knows of the one kept mode's tables (pred_kind 2): their sums (full-f offset) and their Gram
+// matrix (kept-mode reconstruction of chargeden for the call-site path)
+struct PredTab {
+  double sum_fre, sum_fim, g11, g22, g12;
 };
-// this rank's charge2 and Z-weighted prediction slices packed for one all-reduce (accumulators re-zeroed)
-hipError_t launch_charge_pack(const FieldArgs &f, double *pred, int nm_pred, double *pack, hipStream_t st);
+struct PairArgs {
+  double *pred;     // kind 1: [nspecies][1 + 2 nmode][nx]; kind 2: [8] the six sums; consumed (re-zeroed)
+  double *E_h;      // [nx] half-step field of the next step
+  double *mode_h;   // [2 nmode] its kept modes (re..., im...)
+  double *cd_h;     // [nx] its charge density (scratch; kind 1)
+  double *pack;     // null, or what k_charge_pack made, already summed over ranks
+  int kind;         // 1 tiles, 2 sums
+  PredTab pt;       // kind 2
+};
+// doubles k_charge_pack writes / one exchange of a one-pass step carries per rank:
+// kind 1: charge2 + the 1 + 2 nmode Z-weighted prediction slices; kind 2: charge2 + the six sums (padded to 8)
+inline size_t pack_doubles(int nx, int nmode, int kind) {
+  return kind == 2 ? static_cast<size_t>(nx) + 8 : static_cast<size_t>(2 + 2 * nmode) * nx;
+}
+// this rank's charge2 and prediction packed for one all-reduce (accumulators re-zeroed)
+hipError_t launch_charge_pack(const FieldArgs &f, double *pred, int nm_pred, int kind, double *pack, hipStream_t st);
 hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const XchgArgs *x1, hipStream_t st);
+// kind 2, call-site path: the six sums K (summed over ranks) + the field's kept mode -> field_chargeden with the
+// kept-mode content of the next first sub-step's charge density; pred (or null) is re-zeroed
+hipError_t launch_pred_chargeden(const FieldArgs &f, const PredTab &pt, double *pred, const double *K, hipStream_t st);
+// kind 2, call-site path, several ranks: this rank's six sums into the head of f.charge (rest zero), pred re-zeroed
+hipError_t launch_pred_to_charge(const FieldArgs &f, double *pred, hipStream_t st);
 // k_step_one's prediction accumulators [nspecies][1 + 2 nm][nx] + the field's kept modes -> this rank's
 // charge2 of the next first sub-step in f.charge; the accumulators are re-zeroed
 hipError_t launch_pred_combine(const FieldArgs &f, double *pred, int nm_pred, hipStream_t st);

@@ -157,6 +157,13 @@ class Pic1dp:
         1: two fused sub-steps through the RK ping-pong sets"""
         check(self.L.pic1dp_hip_set_step_mode(self._ctx, mode))
 
+    def predict_kind(self):
+        """how step mode 0 predicts the next first sub-step's charge: 0 not (two passes per step),
+        1 prediction tiles (k_step_one), 2 six sums (k_step_sums, large grids)"""
+        k = C.c_int32(0)
+        check(self.L.pic1dp_hip_predict_kind(self._ctx, C.byref(k)))
+        return k.value
+
     def set_output_fusion(self, on=True):
         """diagnostics of output_all taken inside the step that precedes it (no extra pass)"""
         check(self.L.pic1dp_hip_set_output_fusion(self._ctx, int(on)))

@@ -391,6 +391,12 @@ interface
     integer(c_signed_char), intent(in) :: id(*)
     integer(c_int) :: ierr
   end function pic1dp_hip_comm_init
+  function pic1dp_hip_predict_kind(ctx, kind) bind(C, name="pic1dp_hip_predict_kind") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), intent(out) :: kind
+    integer(c_int) :: ierr
+  end function pic1dp_hip_predict_kind
   function pic1dp_hip_set_output_fusion(ctx, on) bind(C, name="pic1dp_hip_set_output_fusion") result(ierr)
     import
     type(c_ptr), value :: ctx

@@ -28,11 +28,16 @@ def run_ranks(tmp_path, nproc, kw, steps, mode, port, timeout_ms="60000"):
     return [np.load(out + ".rank%d.npz" % k) for k in range(nproc)]
 
 
-@pytest.mark.parametrize("nproc,mode", [(2, "step"), (3, "step"), (2, "calls")])
-def test_exchange_ranks_share_the_gpu(amd, tmp_path, nproc, mode):
+@pytest.mark.parametrize("nproc,mode,kind", [(2, "step", 1), (3, "step", 1), (2, "calls", 1), (3, "step", 2), (2, "calls", 2)],
+                         ids=["2-step", "3-step", "2-calls", "3-step-sums", "2-calls-sums"])
+def test_exchange_ranks_share_the_gpu(amd, tmp_path, monkeypatch, nproc, mode, kind):
+    """kind 2: the one-pass prediction travels as six sums behind charge2 (k_step_sums, the large-grid kernel,
+    insisted on at this small grid)"""
     kw = dict(nparticle_max=600_000, nx=128)
     steps = 12
-    ranks = run_ranks(tmp_path, nproc, kw, steps, mode, 29541 + nproc)
+    if kind == 2:
+        monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
+    ranks = run_ranks(tmp_path, nproc, kw, steps, mode, 29541 + nproc + 10 * kind)
     # every rank holds the same field, bit for bit
     for r in ranks[1:]:
         assert np.array_equal(r["E"], ranks[0]["E"])
