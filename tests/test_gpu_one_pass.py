@@ -155,11 +155,16 @@ def test_prediction_is_dropped_when_it_no_longer_applies(amd, monkeypatch, kind)
     (dict(nx=4096, deltaf=0), True),
     (dict(nx=4096, nspecies=2, iptcldist=0, species_charge=[-1.0, 1.0], species_mass=[1.0, 25.0], species_temperature=[1.0, 0.5],
           species_temperature2=[1.0, 1.0], species_density=[1.0, 1.0], species_v0=[0.0, 0.0], lx=4 * np.pi), True),
+    (dict(nx=33), True),                                        # odd grid: guard cell and tile padding
     (dict(nparticle_max=N + 1, species_nparticle_init=[N - 7]), True)],
-    ids=["two_modes", "three_modes_fall_back", "two_species", "nx4096_sums", "nx4096_two_modes_fall_back", "nx4096_full_f", "nx4096_two_species", "even_count_tail_slots"])
-def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted):
+    ids=["two_modes", "three_modes_fall_back", "two_species", "nx4096_sums", "nx4096_two_modes_fall_back", "nx4096_full_f", "nx4096_two_species", "odd_nx", "even_count_tail_slots"])
+@pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
+def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind):
     kw = dict(dict(nparticle_max=N, nx=96), **kw)
-    a = engine(amd, monkeypatch, True, **kw)
+    if kind == 2 and kw.get("nmode", 1) == 2 and kw["nx"] < 4096:
+        pytest.skip("two kept modes: the tiles' case")
+    a = engine(amd, monkeypatch, True, kind, **kw)
+    assert a.predict_kind() == (0 if not predicted else 2 if (kind == 2 or kw["nx"] == 4096) else 1)
     b = engine(amd, monkeypatch, False, **kw)
     a.kernel_stats_enable(True)
     a.step(8)

@@ -554,11 +554,17 @@ def test_split_phase_charge_time_loop(amd):
     assert b.kernel_stats(1)[1] == 0 and b.kernel_stats(4)[1] + b.kernel_stats(6)[1] == 3
 
 
-def test_rccl_allreduce_path_single_rank(oracle_mod, amd):
+@pytest.mark.parametrize("kind", [1, 2], ids=["tiles", "sums"])
+def test_rccl_allreduce_path_single_rank(oracle_mod, amd, monkeypatch, kind):
     """a 1-rank RCCL communicator: exercises the run-time RCCL binding, the
     unique-id hand-off and the split kernels (charge_local -> ncclAllReduce on
-    the engine's stream -> field solve) that N > 1 uses"""
+    the engine's stream -> field solve; in a one-pass step: pack -> ONE
+    ncclAllReduce -> the paired solve, with the prediction as tiles or as six
+    sums) that N > 1 uses"""
+    if kind == 2:
+        monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
     sim, eng = pair(oracle_mod, amd, nparticle_max=100000, nx=64)
+    assert eng.predict_kind() == kind
     uid = eng.comm_unique_id()
     assert len(uid) == 128 and any(uid)
     eng.comm_init(uid)
@@ -569,6 +575,14 @@ def test_rccl_allreduce_path_single_rank(oracle_mod, amd):
     eng.interaction_collect_charge()
     sim.collect_charge()
     assert relerr(eng.get_field()["chargeden"], sim.get_field()[1]) < CHARGE_RTOL
+    # and the reference's call sites over the same communicator
+    for _ in range(3):
+        for irk in (1, 2):
+            eng.interaction_push_particle(irk)
+            eng.interaction_collect_charge()
+            eng.field_solve_electric()
+        sim.step(1)
+    assert abs(eng.field_energy() / sim.field_energy() - 1.0) < ENERGY_RTOL
 
 
 def test_error_behaviour(amd):
