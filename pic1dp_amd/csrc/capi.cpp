@@ -104,6 +104,7 @@ struct pic1dp_ctx {
   // one pass per step (kernels.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
   // prediction accumulators [nspecies][1 + 2 nm][nx], the combined half-step charge density
   double *d_tabA = nullptr, *d_tabB = nullptr, *d_pred = nullptr, *d_cd_h = nullptr, *d_mode_h = nullptr;
+  int osub_req = 0;                // PIC1DP_OSUB: grid size of the marker kernels in units of the resident one (0: auto)
   int pred_kind = 0;               // 0 no one-pass step here, 1 prediction tiles (k_step_one), 2 six sums (k_step_sums)
   PredTab pred_tab{};              // kind 2: sums / Gram matrix of the kept mode's tables (host, libm)
   int eh_modes = 0;                // kind 2: where the kept mode of the Eh about to be used lies: 0 nowhere, 1 fa.mode_*, 2 d_mode_h
@@ -684,6 +685,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     if (k == 1 || k == 2 || k == 4 || k == 8) c->grid.rcopies = k;
   }
   c->grid.debug_noflush = std::getenv("PIC1DP_DEBUG_NOFLUSH") != nullptr;
+  if (const char *e = std::getenv("PIC1DP_OSUB")) c->osub_req = std::max(0, std::atoi(e));
   while (c->grid.rcopies > 1 && step_lds_bytes(nx, true, c->grid.rcopies) > 80 * 1024) c->grid.rcopies >>= 1;
   if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_MB"))
     c->nt_threshold_half = c->nt_threshold_full = std::atof(e) * 1048576.0;
@@ -1397,6 +1399,27 @@ static bool step_recompute_ok(const pic1dp_ctx *c) {
   return c->step_mode == 0 && step_lds_bytes(c->in.nx, true) <= PARTICLE_LDS_CAP;
 }
 
+// Grid of a marker kernel: `resident` workgroups fill the CUs; with a grid of exactly that size the kernel ends
+// when its slowest workgroup does, and the CUs do not all stream at the same rate.  A grid of several times that
+// size lets the CUs that finish early take more of the work (tools/ab_one_shapes.sh: k_step_one at 1e8 markers
+// 1.290 -> 1.238 ms with four times the resident workgroups) -- as long as a workgroup's share of the markers
+// dwarfs what it pays once (staging and flushing tiles of nx cells): about 48 markers per cell, at most x4.
+// Only where two workgroups share a CU (while one stages or flushes the other streams; alone on its CU a
+// workgroup's turn-over idles it: k_step_sums at nx 4096, 0.935 -> 1.004 ms with twice the grid), and not for
+// k_step_full, which measures 1-3 % slower that way (k_step_half 5 % faster; tools/ab_osub.sh).
+// PIC1DP_OSUB=n insists on a factor (1: the resident grid).
+static int64_t oversubscribed(const pic1dp_ctx *c, int64_t np, int64_t resident, bool allow = true) {
+  if (c->bpc_req > 0) return resident;  // a launch shape asked for by hand is taken literally
+  int64_t f = c->osub_req;
+  if (f <= 0 && !allow) return resident;
+  if (f <= 0) {
+    const int64_t per_wg = static_cast<int64_t>(48) * c->in.nx;
+    f = (np / per_wg + resident / 2) / std::max<int64_t>(resident, 1);
+  }
+  f = std::max<int64_t>(1, std::min<int64_t>(f, c->osub_req > 0 ? 64 : 4));
+  return resident * f;
+}
+
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
   LaunchCfg lc{};
   lc.lds = step_lds_bytes(c->in.nx, full, c->grid.rcopies);
@@ -1412,7 +1435,7 @@ static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
   if (bpc > by_lds) bpc = by_lds;
   if (c->bpc_req > 0) bpc = c->bpc_req < by_lds ? c->bpc_req : by_lds;
   if (bpc < 1) bpc = 1;
-  int64_t blocks = static_cast<int64_t>(c->num_cu) * bpc;
+  int64_t blocks = oversubscribed(c, np, static_cast<int64_t>(c->num_cu) * bpc, !full && bpc >= 2);
   const int64_t need = ((np >> 1) + threads - 1) / threads;
   if (blocks > need) blocks = need;
   if (blocks < 1) blocks = 1;
@@ -1541,7 +1564,8 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       lc.threads = c->threads_req > 0 ? c->threads_req : (two ? th2 : th1);
       const int bpc = c->bpc_req > 0 ? c->bpc_req : (two ? 2 : 1);
       const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
-      lc.blocks = static_cast<int>(std::max<int64_t>(1, std::min(static_cast<int64_t>(c->num_cu) * bpc, need)));
+      lc.blocks = static_cast<int>(
+          std::max<int64_t>(1, std::min(oversubscribed(c, S.np, static_cast<int64_t>(c->num_cu) * bpc, bpc >= 2), need)));
     }
     if (diag) {  // one workgroup of 1024 threads per CU: grid tiles + histograms in its LDS
       const size_t ntot = dist_len(c->in);
