@@ -119,6 +119,30 @@ def test_one_pass_through_the_call_sites(amd, monkeypatch, kind):
 
 
 @pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
+def test_one_pass_with_the_hosts_own_reduction(amd, monkeypatch, kind):
+    """a host that keeps its own MPI_Allreduce (charge_local / charge_reduced): after push(1) what it
+    reduces is the prediction -- a charge vector (tiles) or the six sums at the head of one (sums)"""
+    kw = dict(nparticle_max=N, nx=96)
+    a = engine(amd, monkeypatch, True, kind, **kw)
+    b = engine(amd, monkeypatch, False, **kw)
+    a.kernel_stats_enable(True)
+    for it in range(5):
+        for irk in (1, 2):
+            a.interaction_push_particle(irk)
+            c2 = a.charge_local()
+            if kind == 2 and irk == 1 and it > 0:
+                assert np.all(c2[6:] == 0.0) and np.any(c2[:6] != 0.0)
+            a.charge_reduced(c2)
+            a.field_solve_electric()
+        b.step(1)
+        assert abs(a.field_energy() / b.field_energy() - 1.0) < 1e-11, it
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
+    assert a.kernel_stats(3)[1] == 1 and a.kernel_stats(6)[1] == 5
+
+
+@pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
 def test_prediction_is_dropped_when_it_no_longer_applies(amd, monkeypatch, kind):
     """a field set from outside, re-uploaded markers, another solver: the first-sub-step pass runs again"""
     kw = dict(nparticle_max=N, nx=96)
