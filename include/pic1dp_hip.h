@@ -399,7 +399,11 @@ int pic1dp_hip_debug_layout_probe(pic1dp_ctx *ctx, int64_t n, int32_t log2_tile,
 /* ---- split-phase deposit for a host that owns the reduction (MPI) ------
  * charge_local: everything of collect_charge up to the all-reduce
  *   (src/pic1dp_interaction.F90:81-128) -> this rank's charge2[nx] on the host
- * charge_reduced: hand back the globally summed array; finishes :138-150 */
+ * charge_reduced: hand back the globally summed array; finishes :138-150
+ * The array is to be summed element by element over the ranks and handed back whole:
+ * after a noted push(1) whose charge the previous step has predicted as six sums
+ * (pic1dp_hip_predict_kind = 2) it carries those sums in its first six elements and
+ * zeros behind, not a charge vector. */
 int pic1dp_hip_charge_local(pic1dp_ctx *ctx, double *charge2);
 int pic1dp_hip_charge_reduced(pic1dp_ctx *ctx, const double *charge1);
 
