@@ -518,16 +518,20 @@ def main():
         # HBM bytes per launch of that kernel: rocprofv3 --pmc passes of this command, committed under
         # profiles/ (a profile constant of the same workload, NOT measured in this run)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        for tname in ("traffic_%s.json" % a.config, "traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if traffic is not None or not os.path.exists(tpath):
+                continue
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("particles_per_gpu") == per_gpu and tj.get("nx") == phys["nx"]:
                     key = "k_step_one" if one_n else ("k_step_full" if full_n else "k_push")
+                    if one_n and eng.predict_kind() == 2:
+                        key = "k_step_sums"
                     traffic = tj.get("hbm_bytes_per_launch_by_kernel", {}).get(key)
-                    traffic_src = "profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
-                                  "this command (committed profile of the same workload, not measured in this run)"
+                    traffic_src = "profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+                                  "this command (committed profile of the same workload, not measured in this run)" % tname
             except (OSError, ValueError):
                 pass
         # the box's own streaming rates (second denominator): plain copy and the

@@ -16,7 +16,7 @@ import json
 import re
 import sys
 
-PARTICLE_KERNELS = ("k_push", "k_step_half", "k_step_full", "k_step_one", "k_deposit")
+PARTICLE_KERNELS = ("k_push", "k_step_half", "k_step_full", "k_step_one", "k_step_sums", "k_deposit")
 
 
 def short_name(full):
@@ -62,7 +62,9 @@ def main():
     if fused:
         by_kernel["k_push"] = sum(r["hbm_bytes"] * r["launches"] for r in fused) / sum(r["launches"] for r in fused)
     res = dict(particles_per_gpu=n, nx=nx, hbm_bytes_per_launch_by_kernel=by_kernel,
-               compulsory_bytes_per_marker=dict(k_step_half=32.0, k_step_full=56.0, k_step_one=72.0),
+               compulsory_bytes_per_marker=dict(k_step_half=32.0, k_step_full=56.0, k_step_one=72.0, k_step_sums=56.0),
+               compulsory_note="k_step_one / k_step_sums: 56 B + 16 B carry of -f0'/f0 for the exp-bearing distributions "
+                               "(bump-on-tail, two-stream2); 56 B otherwise (Maxwellian: BASELINE configs[4])",
                reference_priced_bytes_per_update=80.0,
                correction="FETCH_SIZE x2 (gfx950 wide coalesced reads), WRITE_SIZE exact; KiB units",
                kernels=rows)
