@@ -539,6 +539,11 @@ def main():
         probe_n = int(min(np_local, 10**8))
         copy_gbs = max(eng.stream_probe(1, 1, probe_n, 10) for _ in range(3))
         shape_gbs = max(eng.stream_probe(4, 3, probe_n, 10) for _ in range(3))
+        # the same traffic in the layout the markers are stored in (x | v | w | p tiles, three written back in
+        # place): what a kernel that did nothing but stream them would reach -- the denominator that does not
+        # depend on where the allocator puts seven separate arrays
+        tiled_ms = min(eng.layout_probe(probe_n, 12, 10)[1] for _ in range(2))
+        tiled_gbs = 56.0 * (probe_n // 4096 * 4096) / (tiled_ms * 1e-3) / 1e9
         # bytes the timed steps had to move: every launch of the three whole-step kernels at its own price
         step_bytes = None
         if full_n or one_n:
@@ -587,6 +592,8 @@ def main():
                                          "not an HBM fraction" % (step_bytes / np_local if step_bytes else rd + wr),
                 "measured_copy_GBs": copy_gbs, "measured_4read_3write_GBs": shape_gbs,
                 "frac_of_measured_4read_3write": achieved / shape_gbs if shape_gbs else None,
+                "measured_tiled_4read_3write_GBs": tiled_gbs,
+                "frac_of_measured_tiled_stream": achieved / tiled_gbs if tiled_gbs else None,
                 "traffic_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and kn) else None,
             },
             "attribution": attr,

@@ -157,6 +157,14 @@ class Pic1dp:
         1: two fused sub-steps through the RK ping-pong sets"""
         check(self.L.pic1dp_hip_set_step_mode(self._ctx, mode))
 
+    def layout_probe(self, n, log2_tile=12, reps=10):
+        """pure streams of the whole-step kernels' traffic shape over a fresh slab (tuning / bench denominator):
+        ms per launch of [arrays apart r/w, tiled r/w, arrays apart read-only, tiled read-only, tiled r/w one
+        workgroup per tile, the same read-only]; r/w = 4 arrays of n doubles read, 3 written back in place"""
+        ms = (C.c_double * 6)()
+        check(self.L.pic1dp_hip_debug_layout_probe(self._ctx, int(n), log2_tile, 0, reps, 0, ms))
+        return list(ms)
+
     def predict_kind(self):
         """how step mode 0 predicts the next first sub-step's charge: 0 not (two passes per step),
         1 prediction tiles (k_step_one), 2 six sums (k_step_sums, large grids)"""
