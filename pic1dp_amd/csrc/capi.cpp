@@ -104,6 +104,7 @@ struct pic1dp_ctx {
   // one pass per step (kernels.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
   // prediction accumulators [nspecies][1 + 2 nm][nx], the combined half-step charge density
   double *d_tabA = nullptr, *d_tabB = nullptr, *d_pred = nullptr, *d_cd_h = nullptr, *d_mode_h = nullptr;
+  int pair_plain = 0;              // PIC1DP_PAIR_PLAIN
   int osub_req = 0;                // PIC1DP_OSUB: grid size of the marker kernels in units of the resident one (0: auto)
   int pred_kind = 0;               // 0 no one-pass step here, 1 prediction tiles (k_step_one), 2 six sums (k_step_sums)
   PredTab pred_tab{};              // kind 2: sums / Gram matrix of the kept mode's tables (host, libm)
@@ -686,6 +687,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   }
   c->grid.debug_noflush = std::getenv("PIC1DP_DEBUG_NOFLUSH") != nullptr;
   if (const char *e = std::getenv("PIC1DP_OSUB")) c->osub_req = std::max(0, std::atoi(e));
+  if (const char *e = std::getenv("PIC1DP_PAIR_PLAIN")) c->pair_plain = std::atoi(e) != 0;
   while (c->grid.rcopies > 1 && step_lds_bytes(nx, true, c->grid.rcopies) > 80 * 1024) c->grid.rcopies >>= 1;
   if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_MB"))
     c->nt_threshold_half = c->nt_threshold_full = std::atof(e) * 1048576.0;
@@ -1678,7 +1680,7 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool 
   const bool pair = pred && c->pred_version == c->state_version && (!multi || fused_xchg || will_pack) &&
                     c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (pair) {
-    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab};
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, c->pair_plain};
     if (will_pack) {  // both charge sums of the step came in ONE all-reduce (pack_doubles)
       pa.pack = c->d_pack;
       HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));

@@ -28,6 +28,7 @@
 #include "kernels.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace pic1dp {
@@ -1673,6 +1674,47 @@ __device__ __forceinline__ void solve_fill_chargeden(const FieldArgs &f, double 
 // TREE: the forward sums as workgroup reductions instead of the reference's serial ascending-ix chains.
 // Only for a field that has no reference order to keep: the half-step field predicted by k_step_one, whose
 // charge already differs from a marker-by-marker deposit by rounding (0.6 us instead of 5.8 us at nx = 1024).
+// sum of prod[0..nx) in ascending order, one lane, bit-identical to the sequential loop.
+// One wave issues this whole chain, so every instruction counts (a wave64
+// VALU or LDS instruction occupies its SIMD for 4 cycles whatever the exec
+// mask): two register batches in ping-pong, no copies between them, and
+// 16-byte LDS loads when the row is aligned.  16 dependent adds per batch
+// cover the LDS round trip of the next one.
+__device__ __forceinline__ double chain_sum_lds(const double *prod, int nx) {
+  double acc = 0.0;
+  int ix = 0;
+  constexpr int W = CHAIN_W;
+  if ((reinterpret_cast<uintptr_t>(prod) & 15) == 0) {
+    double A[W], B[W];
+    const int nb = nx / W;
+    auto load = [](double (&r)[W], const double *q) {
+#pragma unroll
+      for (int k = 0; k < W; k += 2) {
+        const double2 t = *reinterpret_cast<const double2 *>(q + k);
+        r[k] = t.x;
+        r[k + 1] = t.y;
+      }
+    };
+    if (nb > 0) load(A, prod);
+    int b = 0;
+    for (; b + 2 <= nb; b += 2) {
+      load(B, prod + (b + 1) * W);
+#pragma unroll
+      for (int k = 0; k < W; ++k) acc = acc + A[k];
+      if (b + 2 < nb) load(A, prod + (b + 2) * W);
+#pragma unroll
+      for (int k = 0; k < W; ++k) acc = acc + B[k];
+    }
+    if (b < nb) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) acc = acc + A[k];
+    }
+    ix = nb * W;
+  }
+  for (; ix < nx; ++ix) acc = acc + prod[ix];
+  return acc;
+}
+
 template <bool TREE = false>
 __device__ __forceinline__ void solve_body(const FieldArgs &f, double *sCD, double *sMode, double *sScr,
                                            double *sTab) {
@@ -1721,40 +1763,7 @@ __device__ __forceinline__ void solve_body(const FieldArgs &f, double *sCD, doub
     int ix = 0;
     if (f.tab_lds) {
       const double *prod = sTab + (use_cos ? 0 : nm * nx) + m * nx;
-      // One wave issues this whole chain, so every instruction counts (a wave64
-      // VALU or LDS instruction occupies its SIMD for 4 cycles whatever the exec
-      // mask): two register batches in ping-pong, no copies between them, and
-      // 16-byte LDS loads when the row is aligned.  16 dependent adds per batch
-      // cover the LDS round trip of the next one.
-      constexpr int W = CHAIN_W;
-      if ((reinterpret_cast<uintptr_t>(prod) & 15) == 0) {
-        double A[W], B[W];
-        const int nb = nx / W;
-        auto load = [](double (&r)[W], const double *q) {
-#pragma unroll
-          for (int k = 0; k < W; k += 2) {
-            const double2 t = *reinterpret_cast<const double2 *>(q + k);
-            r[k] = t.x;
-            r[k + 1] = t.y;
-          }
-        };
-        if (nb > 0) load(A, prod);
-        int b = 0;
-        for (; b + 2 <= nb; b += 2) {
-          load(B, prod + (b + 1) * W);
-#pragma unroll
-          for (int k = 0; k < W; ++k) acc = acc + A[k];
-          if (b + 2 < nb) load(A, prod + (b + 2) * W);
-#pragma unroll
-          for (int k = 0; k < W; ++k) acc = acc + B[k];
-        }
-        if (b < nb) {
-#pragma unroll
-          for (int k = 0; k < W; ++k) acc = acc + A[k];
-        }
-        ix = nb * W;
-      }
-      for (; ix < nx; ++ix) acc = acc + prod[ix];
+      acc = chain_sum_lds(prod, nx);
     } else {
       const double *tab = (use_cos ? f.fre : f.fim) + static_cast<size_t>(m) * nx;
       for (; ix + 8 <= nx; ix += 8) {
@@ -2023,6 +2032,187 @@ k_field_solve_pair(const FieldArgs f, const XchgArgs x1, const PairArgs pa) {
   g.mode_im = pa.mode_h + nm;
   g.history = nullptr;
   solve_body<true>(g, sCD, sMode, sScr, sTab);
+}
+
+// k_field_solve_pair for the usual case -- ONE kept mode, tables that fit the LDS -- with everything that does
+// not wait for the serial sums moved in front of them.  The launch is latency-bound (one workgroup; at 1e7
+// markers per GPU it is 7-10 % of the time step), and k_field_solve_pair spends it in a row of dependent
+// round trips: charge, tables, [chain], prediction tiles, two workgroup reductions, inverse.  Here every
+// thread issues all its loads at once (charge, the three prediction slices, both tables), forms the chain's
+// products AND the prediction's forward sums before the chain runs -- the predicted charge density is
+// cd_h = g0 + re ga + im gb with g0 = chargeden(R0), ga = RA nx/lx, gb = RB nx/lx, so its projections are
+// S0 + re Sa + im Sb with six sums that need no mode: wave reductions, no barrier -- and after the chain one
+// thread combines them; both inverse transforms then run in one loop.  The field of the new state: the same
+// products in the same order as k_field_solve (bit for bit).  Eh: regrouped sums, as before (TREE).
+template <int SRC>
+__global__ void __launch_bounds__(FIELD_THREADS)
+k_field_solve_pair1(const FieldArgs f, const XchgArgs x1, const PairArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nx = f.nx;
+  const int ne = (nx + 1) & ~1;
+  double *sPc = reinterpret_cast<double *>(smem);  // [ne] fre * chargeden   (16-byte aligned rows for the chain)
+  double *sPs = sPc + ne;                           // [ne] fim * chargeden
+  double *sW = sPs + ne;                            // [FIELD_THREADS / 64][6] wave partials of the six sums
+  double *sMode = sW + (FIELD_THREADS / 64) * 6;    // re, im, then the six sums of the workgroup
+  double *sScr = sMode + 8;                         // [16]
+  double *sV = sScr + 16;                           // SRC 1: [charge2 | R0 | RA | RB] of this rank, then of all
+  const double *pk = pa.pack;                       // SRC 2: the same, all-reduced in memory
+  const size_t np1 = 3;
+  if constexpr (SRC == 1) {
+    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+      sV[ix] = charge_local_one(f, ix);
+      for (size_t k = 0; k < np1; ++k) {
+        double c2 = 0.0;
+        for (int sp = 0; sp < f.nspecies; ++sp) {
+          double *r = pa.pred + (static_cast<size_t>(sp) * np1 + k) * nx + ix;
+          c2 = c2 + *r * f.Z[sp];
+          *r = 0.0;
+        }
+        sV[(1 + k) * nx + ix] = c2;
+      }
+    }
+    __syncthreads();
+    exchange_vectors(x1, sV, 4 * nx);
+    __syncthreads();
+    pk = sV;
+  }
+  double off = 0.0;
+  if (!f.deltaf)
+    for (int sp = 0; sp < f.nspecies; ++sp) off = off + f.Z[sp] * f.n0[sp];
+  double s0c = 0.0, sac = 0.0, sbc = 0.0, s0s = 0.0, sas = 0.0, sbs = 0.0;
+  constexpr int U = 4;
+  const double ginv = f.grad_inv[0];  // off the critical path behind the chain
+  double tr[U], ti[U];                // the tables of the last trip stay in registers for the inverse
+  for (int base = threadIdx.x; base < nx; base += U * FIELD_THREADS) {
+    double c[U], r0[U], ra[U], rb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // all loads of the trip in flight together
+      const int ix = base + u * FIELD_THREADS;
+      c[u] = r0[u] = ra[u] = rb[u] = tr[u] = ti[u] = 0.0;
+      if (ix < nx) {
+        tr[u] = f.fre[ix];
+        ti[u] = f.fim[ix];
+        if constexpr (SRC != 0) {
+          c[u] = pk[ix];
+          r0[u] = pk[nx + ix];
+          ra[u] = pk[2 * static_cast<size_t>(nx) + ix];
+          rb[u] = pk[3 * static_cast<size_t>(nx) + ix];
+        } else {
+          for (int sp = 0; sp < f.nspecies; ++sp) {  // src/pic1dp_interaction.F90:126-127
+            double *r = f.rho_sp + static_cast<size_t>(sp) * nx + ix;
+            double c1 = *r;
+            for (int g = 1; g < f.rho_copies; ++g) c1 = c1 + r[static_cast<size_t>(g) * f.rho_stride];
+            c[u] = c[u] + c1 * f.Z[sp];
+            const double *q = pa.pred + static_cast<size_t>(sp) * np1 * nx + ix;
+            r0[u] = r0[u] + q[0] * f.Z[sp];
+            ra[u] = ra[u] + q[nx] * f.Z[sp];
+            rb[u] = rb[u] + q[2 * static_cast<size_t>(nx)] * f.Z[sp];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ix = base + u * FIELD_THREADS;
+      if (ix < nx) {
+        if constexpr (SRC == 0) {  // accumulators consumed: zero for the next kernels
+          for (int sp = 0; sp < f.nspecies; ++sp) {
+            double *r = f.rho_sp + static_cast<size_t>(sp) * nx + ix;
+            for (int g = 0; g < f.rho_copies; ++g) r[static_cast<size_t>(g) * f.rho_stride] = 0.0;
+            double *q = pa.pred + static_cast<size_t>(sp) * np1 * nx + ix;
+            q[0] = 0.0;
+            q[nx] = 0.0;
+            q[2 * static_cast<size_t>(nx)] = 0.0;
+          }
+        }
+        f.charge[ix] = c[u];
+        const double cd = chargeden_from(f, c[u]);  // :138-148
+        f.chargeden[ix] = cd;
+        sPc[ix] = tr[u] * cd;
+        sPs[ix] = ti[u] * cd;
+        const double g0 = r0[u] * f.dnx / f.lx - off, ga = ra[u] * f.dnx / f.lx, gb = rb[u] * f.dnx / f.lx;
+        s0c += tr[u] * g0;
+        sac += tr[u] * ga;
+        sbc += tr[u] * gb;
+        s0s += ti[u] * g0;
+        sas += ti[u] * ga;
+        sbs += ti[u] * gb;
+      }
+    }
+  }
+  {
+    double v[6] = {s0c, sac, sbc, s0s, sas, sbs};
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
+    if ((threadIdx.x & 63) == 0)
+      for (int k = 0; k < 6; ++k) sW[(threadIdx.x >> 6) * 6 + k] = v[k];
+  }
+  __syncthreads();
+  // the serial sums, ascending ix (:231-240): lane 0 the cos table -> im, lane 1 the -sin table -> re;
+  // beside them the second wave adds up the wave partials of the six sums
+  if (threadIdx.x < 2) {
+    const bool use_cos = threadIdx.x == 0;
+    const double acc = chain_sum_lds(use_cos ? sPc : sPs, nx);
+    if (use_cos) {
+      const double im = acc * f.sc_im * ginv;
+      sMode[1] = im;
+      f.mode_im[0] = im;
+    } else {
+      const double re = acc * f.sc_re * ginv;
+      sMode[0] = re;
+      f.mode_re[0] = re;
+    }
+  } else if (threadIdx.x >= 64 && threadIdx.x < 70) {
+    const int k = threadIdx.x - 64;
+    double t = 0.0;
+    for (int w = 0; w < FIELD_THREADS / 64; ++w) t += sW[w * 6 + k];
+    sMode[2 + k] = t;
+  }
+  __syncthreads();
+  // the kept mode of the next step's half-step field (every thread for itself), both inverse transforms (:251-257)
+  double e2 = 0.0;
+  const double re = sMode[0], im = sMode[1];
+  const double ac = sMode[2] + re * sMode[3] + im * sMode[4], as = sMode[5] + re * sMode[6] + im * sMode[7];
+  const double im_h = ac * f.sc_im * ginv, re_h = as * f.sc_re * ginv;
+  if (threadIdx.x == 0) {
+    pa.mode_h[0] = re_h;
+    pa.mode_h[1] = im_h;
+  }
+  const bool one_trip = nx <= U * FIELD_THREADS;
+  for (int base = threadIdx.x; base < nx; base += U * FIELD_THREADS) {
+    if (!one_trip) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ix = base + u * FIELD_THREADS;
+        tr[u] = ix < nx ? f.fre[ix] : 0.0;
+        ti[u] = ix < nx ? f.fim[ix] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ix = base + u * FIELD_THREADS;
+      if (ix < nx) {
+        double a = 0.0;
+        a = a + tr[u] * re;
+        a = a + ti[u] * im;
+        const double e = a * 2.0;
+        f.E[ix] = e;
+        e2 += e * e;
+        double b = 0.0;
+        b = b + tr[u] * re_h;
+        b = b + ti[u] * im_h;
+        pa.E_h[ix] = b * 2.0;
+      }
+    }
+  }
+  if (f.history) {  // int E^2 dx, src/pic1dp_output.F90:120-124
+    const double tot = block_sum(e2, sScr);
+    if (threadIdx.x == 0) {
+      const double nrm = sqrt(tot);
+      *f.history = nrm * nrm * f.lx / f.dnx;
+    }
+  }
 }
 
 // k_field_solve_pair for k_step_sums' prediction: the field of the new state from its deposited charge, then --
@@ -2333,6 +2523,24 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
   size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
                                  (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
   const XchgArgs none{};
+  if (pa.kind != 2 && f.nmode == 1 && f.tab_lds && !pa.plain) {  // the lean kernel of the usual case
+    const size_t ne = (static_cast<size_t>(f.nx) + 1) & ~static_cast<size_t>(1);
+    size_t l1 = sizeof(double) * (2 * ne + (FIELD_THREADS / 64) * 6 + 8 + 16);
+    if (x1) {
+      l1 += sizeof(double) * 4 * static_cast<size_t>(f.nx);
+      if (l1 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_field_solve_pair1<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(k_field_solve_pair1<1>, dim3(1), dim3(FIELD_THREADS), l1, st, f, *x1, pa);
+    } else if (pa.pack) {
+      hipLaunchKernelGGL(k_field_solve_pair1<2>, dim3(1), dim3(FIELD_THREADS), l1, st, f, none, pa);
+    } else {
+      hipLaunchKernelGGL(k_field_solve_pair1<0>, dim3(1), dim3(FIELD_THREADS), l1, st, f, none, pa);
+    }
+    return hipGetLastError();
+  }
   if (pa.kind == 2) {
     if (f.nmode != 1) return hipErrorInvalidValue;
     if (x1) {

@@ -213,6 +213,7 @@ struct PairArgs {
   double *pack;     // null, or what k_charge_pack made, already summed over ranks
   int kind;         // 1 tiles, 2 sums
   PredTab pt;       // kind 2
+  int plain;        // 1: k_field_solve_pair also where the lean k_field_solve_pair1 applies (PIC1DP_PAIR_PLAIN; tests)
 };
 // doubles k_charge_pack writes / one exchange of a one-pass step carries per rank:
 // kind 1: charge2 + the 1 + 2 nmode Z-weighted prediction slices; kind 2: charge2 + the six sums (padded to 8)

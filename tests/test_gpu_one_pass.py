@@ -118,6 +118,33 @@ def test_one_pass_through_the_call_sites(amd, monkeypatch, kind):
     assert a.kernel_stats(3)[1] == 1 and a.kernel_stats(6)[1] == 4
 
 
+@pytest.mark.parametrize("kw", [dict(nx=96), dict(nx=1000), dict(nx=2050, deltaf=0),
+                                dict(nx=64, nspecies=2, iptcldist=0, species_charge=[-1.0, 1.0], species_mass=[1.0, 25.0],
+                                     species_temperature=[1.0, 0.5], species_temperature2=[1.0, 1.0],
+                                     species_density=[1.0, 1.0], species_v0=[0.0, 0.0], lx=4 * np.pi)],
+                         ids=["nx96", "nx1000", "nx2050_full_f", "two_species"])
+def test_lean_pair_solve_equals_the_plain_one(oracle_mod, amd, monkeypatch, kw):
+    """k_field_solve_pair1 (one kept mode: everything that does not wait for the serial sums in front of them)
+    against k_field_solve_pair: the predicted half-step field and the run to rounding; and the field of the
+    new state from ITS charge density against the oracle's solve bit for bit, both kernels"""
+    kw = dict(kw, nparticle_max=N)
+    monkeypatch.setenv("PIC1DP_PAIR_PLAIN", "1")
+    a = engine(amd, monkeypatch, True, **kw)
+    monkeypatch.delenv("PIC1DP_PAIR_PLAIN")
+    b = engine(amd, monkeypatch, True, **kw)
+    field = oracle_mod.Field(oracle_mod.make_input(**kw))
+    for it in range(4):
+        a.step(1)
+        b.step(1)
+        fa, fb = a.get_field(), b.get_field()
+        assert relerr(fa["electric"], fb["electric"]) < 1e-11, it
+        assert relerr(a.get_field_half(), b.get_field_half()) < 1e-11, it
+        for f in (fa, fb):
+            E, re, im = field.solve(f["chargeden"])
+            assert np.array_equal(f["electric"], E) and np.array_equal(f["mode_re"], re) and np.array_equal(f["mode_im"], im)
+    assert np.max(np.abs(a.energy_history() / b.energy_history() - 1.0)) < 1e-11
+
+
 @pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
 def test_one_pass_with_the_hosts_own_reduction(amd, monkeypatch, kind):
     """a host that keeps its own MPI_Allreduce (charge_local / charge_reduced): after push(1) what it
