@@ -233,7 +233,10 @@ int pic1dp_hip_particles_download_bak(pic1dp_ctx *ctx, int32_t ispecies,
 /* interaction_collect_charge, iptclshape 4 (src/pic1dp_interaction.F90:79-151,
  * call sites src/pic1dp.F90:71,88): periodic wrap of x (stored back), linear
  * deposit, species charge scaling, all-reduce over ranks (RCCL), normalisation
- * into field_chargeden */
+ * into field_chargeden.  The last step (on one rank: the species sum too) runs in
+ * the launch of the solve_field that follows, or as soon as anything else asks for
+ * field_chargeden or touches the accumulators (one launch less per sub-step: at the
+ * reference's default size a launch is 5 % of a step); PIC1DP_LAZY_CALLS=0: at once */
 int pic1dp_hip_collect_charge(pic1dp_ctx *ctx);
 /* field_solve_electric (src/pic1dp_field.F90:218-270, call sites
  * src/pic1dp.F90:72,89): mode-filtered partial DFT solve of field_chargeden

@@ -122,6 +122,11 @@ struct pic1dp_ctx {
   // below): a push is only noted; the collect_charge that follows runs the
   // whole-step kernel instead of push + deposit.
   int lazy_calls = 1;            // PIC1DP_LAZY_CALLS=0: every call launches its own kernel at once
+  // collect_charge leaves its last step to the solve_field that follows (one launch less per sub-step):
+  // 0 field_chargeden is current; 1 d_charge holds the summed charge1, its scaling is pending; 2 (one rank) the
+  // species accumulators hold the deposits, species sum and scaling pending.  materialize_cd() before anything
+  // else looks at charge, chargeden or the accumulators.
+  int cd_lazy = 0;
   int lz = 0;                    // LZ_CLEAN / LZ_PUSH1 / LZ_HALF / LZ_PUSH2
   double *d_E0 = nullptr;        // field the noted push(1) saw
   double *d_rho_dummy = nullptr; // accumulator of a wrap-only deposit
@@ -613,7 +618,7 @@ static size_t step_lds_bytes(int nx, bool full, int rcopies);
 static bool output_follows(const pic1dp_ctx *c);
 static void field_written(pic1dp_ctx *c, bool by_solve);
 static bool pred_usable(const pic1dp_ctx *c);
-static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f);
+static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer);
 static int diag_buffers(pic1dp_ctx *c);
 static int diag_max_blocks(const pic1dp_ctx *c);
 static size_t dist_len(const pic1dp_input &in);
@@ -919,10 +924,12 @@ int pic1dp_hip_local_sizes(pic1dp_ctx *c, int32_t isp, int64_t *nalloc, int64_t 
 }
 
 static int materialize(pic1dp_ctx *c);  // lazy call sites, see below
+static int materialize_cd(pic1dp_ctx *c);
 
 int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
+  if (int rc = materialize_cd(c)) return rc;  // deposits of the old markers are consumed, not mixed with the new ones
   HIP_TRY(hipStreamSynchronize(c->st));  // kernels of an earlier run may still be writing the arrays
   c->lz = LZ_CLEAN;  // a noted push of markers that are about to be replaced is void
   c->state_version++;
@@ -994,6 +1001,7 @@ int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, con
   HIP_TRY(hipSetDevice(c->device));
   if (c->loaded)
     if (int rc = materialize(c)) return rc;
+  if (int rc = materialize_cd(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   c->state_version++;
   // an upload (re)starts from set 0 for every species: slots beyond np live there
@@ -1068,12 +1076,21 @@ int pic1dp_hip_particles_download_bak(pic1dp_ctx *c, int32_t isp, double *xb, do
 // hot path
 // ---------------------------------------------------------------------------
 // checks only: for the call sites that take part in the lazy scheme themselves
+// field_chargeden (and d_charge, and zeroed accumulators) as collect_charge would have left them at once
+static int materialize_cd(pic1dp_ctx *c) {
+  const int pending = c->cd_lazy;
+  c->cd_lazy = 0;
+  if (pending == 0) return 0;
+  HIP_TRY(launch_chargeden(c->fa, pending == 2, c->st));
+  return 0;
+}
+
 static int require_loaded_keep_lazy(pic1dp_ctx *c) {
   if (!c->loaded) return fail(PIC1DP_ERR_STATE, "no particles: call particle_load or particles_upload first");
   if (c->charge_pending) return fail(PIC1DP_ERR_STATE, "charge_local is waiting for charge_reduced");
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail(PIC1DP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
-  return 0;
+  return materialize_cd(c);
 }
 
 // every other entry point that reads or writes markers or charge accumulators:
@@ -1162,7 +1179,7 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
     HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
     c->lz = LZ_HALF;
     Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
-    if (int rc = pred_to_chargeden(c, c->fa)) return rc;
+    if (int rc = pred_to_chargeden(c, c->fa, c->lazy_calls != 0)) return rc;
     return tm.end();
   }
   const bool noted = c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2;
@@ -1174,7 +1191,10 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (multi)
     if (int rc = reduce_charge(c)) return rc;
-  HIP_TRY(launch_chargeden(c->fa, !multi, c->st));
+  if (c->lazy_calls)  // the species sum (one rank) and the scaling: in the launch of the solve_field that follows
+    c->cd_lazy = multi ? 1 : 2;
+  else
+    HIP_TRY(launch_chargeden(c->fa, !multi, c->st));
   return tm.end();
 }
 
@@ -1212,7 +1232,9 @@ int pic1dp_hip_solve_field(pic1dp_ctx *c) {
     if (int rc = materialize(c)) return rc;
   Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
-  if (int rc = enqueue_field_solve(c, f, false, true)) return rc;
+  const int pending = c->cd_lazy;  // what collect_charge left to this launch
+  c->cd_lazy = 0;
+  if (int rc = enqueue_field_solve(c, f, pending == 2, pending == 0)) return rc;
   field_written(c, true);
   return tm.end();
 }
@@ -1616,7 +1638,8 @@ static int pred_reduce(pic1dp_ctx *c) {
 // prediction -> chargeden of the next first sub-step (f.chargeden: field_chargeden, or a scratch vector).
 // Tiles: combined locally, summed over ranks, scaled.  Six sums: summed over ranks, then the kept mode's
 // content of that charge density -- all the solve looks at (k_pred_chargeden).
-static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f) {
+// defer (call sites, f = c->fa): leave the scaling of the summed charge to the solve_field that follows (cd_lazy)
+static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer = false) {
   c->pred_version = 0;  // consumed: the accumulators are zero again afterwards
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (c->pred_kind == 2) {
@@ -1632,7 +1655,10 @@ static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f) {
   HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
   if (multi)
     if (int rc = pred_reduce(c)) return rc;
-  HIP_TRY(launch_chargeden(f, false, c->st));
+  if (defer)
+    c->cd_lazy = 1;
+  else
+    HIP_TRY(launch_chargeden(f, false, c->st));
   return 0;
 }
 
@@ -1815,6 +1841,7 @@ int pic1dp_hip_output_due(pic1dp_ctx *c, int32_t itermination, int32_t *flag) {
 int pic1dp_hip_get_field(pic1dp_ctx *c, double *E, double *cd, double *re, double *im) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
+  if (int rc = materialize_cd(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   const size_t nx = c->in.nx, nm = c->in.nmode;
   if (int rc = xchg_check(c)) return rc;
@@ -1841,6 +1868,7 @@ int pic1dp_hip_set_chargeden(pic1dp_ctx *c, const double *cd) {
   CHECK_CTX(c);
   if (!cd) return fail(PIC1DP_ERR_ARG, "null array");
   HIP_TRY(hipSetDevice(c->device));
+  if (int rc = materialize_cd(c)) return rc;  // pending deposits are consumed, then overwritten
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(c->d_chargeden, cd, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
   return 0;
@@ -2288,7 +2316,10 @@ int pic1dp_hip_charge_reduced(pic1dp_ctx *c, const double *charge1) {
     HIP_TRY(launch_pred_chargeden(c->fa, c->pred_tab, nullptr, c->d_charge, c->st));
     return 0;
   }
-  HIP_TRY(launch_chargeden(c->fa, false, c->st));
+  if (c->lazy_calls)
+    c->cd_lazy = 1;
+  else
+    HIP_TRY(launch_chargeden(c->fa, false, c->st));
   return 0;
 }
 
