@@ -124,8 +124,9 @@ struct pic1dp_ctx {
   int lazy_calls = 1;            // PIC1DP_LAZY_CALLS=0: every call launches its own kernel at once
   // collect_charge leaves its last step to the solve_field that follows (one launch less per sub-step):
   // 0 field_chargeden is current; 1 d_charge holds the summed charge1, its scaling is pending; 2 (one rank) the
-  // species accumulators hold the deposits, species sum and scaling pending.  materialize_cd() before anything
-  // else looks at charge, chargeden or the accumulators.
+  // species accumulators hold the deposits, species sum and scaling pending; 3 (one rank, mode-filter solve, few
+  // modes) k_step_one's prediction accumulators hold the charge, combination with the kept modes, species sum and
+  // scaling pending.  materialize_cd() before anything else looks at charge, chargeden or the accumulators.
   int cd_lazy = 0;
   int lz = 0;                    // LZ_CLEAN / LZ_PUSH1 / LZ_HALF / LZ_PUSH2
   double *d_E0 = nullptr;        // field the noted push(1) saw
@@ -1081,6 +1082,7 @@ static int materialize_cd(pic1dp_ctx *c) {
   const int pending = c->cd_lazy;
   c->cd_lazy = 0;
   if (pending == 0) return 0;
+  if (pending == 3) HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
   HIP_TRY(launch_chargeden(c->fa, pending == 2, c->st));
   return 0;
 }
@@ -1234,7 +1236,12 @@ int pic1dp_hip_solve_field(pic1dp_ctx *c) {
   FieldArgs f = c->fa;
   const int pending = c->cd_lazy;  // what collect_charge left to this launch
   c->cd_lazy = 0;
-  if (int rc = enqueue_field_solve(c, f, pending == 2, pending == 0)) return rc;
+  if (pending == 3 && c->field_solver == 0) {
+    HIP_TRY(launch_field_solve_pred(f, c->d_pred, c->in.nmode, c->st));
+  } else {
+    if (pending == 3) HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
+    if (int rc = enqueue_field_solve(c, f, pending == 2, pending == 0)) return rc;
+  }
   field_written(c, true);
   return tm.end();
 }
@@ -1650,6 +1657,10 @@ static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer = fal
     HIP_TRY(launch_pred_to_charge(c->fa, c->d_pred, c->st));
     if (int rc = pred_reduce(c)) return rc;
     HIP_TRY(launch_pred_chargeden(f, c->pred_tab, nullptr, c->d_charge, c->st));
+    return 0;
+  }
+  if (defer && !multi && c->field_solver == 0 && 2 * c->in.nmode <= 256) {
+    c->cd_lazy = 3;  // all of it in the launch of the solve_field that follows
     return 0;
   }
   HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));

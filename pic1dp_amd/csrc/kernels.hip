@@ -1847,6 +1847,40 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve(const FieldArgs f
   solve_body(f, sCD, sMode, sScr, sTab);
 }
 
+// Call sites, one rank: collect_charge after a noted push(1) whose charge k_step_one has predicted, and the
+// solve_field that follows, in one launch -- k_pred_combine (with the kept modes of the field as it is), the
+// scaling, the solve.  The prediction accumulators are consumed.
+__global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_pred(const FieldArgs f, double *pred, int nm_pred) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sCD = reinterpret_cast<double *>(smem);
+  double *sMode = sCD + f.nx;
+  double *sScr = sMode + 2 * f.nmode;
+  double *sTab = sScr + 16;
+  const int nx = f.nx, np1 = 1 + 2 * nm_pred;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+    double c2 = 0.0;
+    for (int s = 0; s < f.nspecies; ++s) {
+      double *r = pred + static_cast<size_t>(s) * np1 * nx + ix;
+      double c1 = r[0];
+      r[0] = 0.0;
+      for (int m = 0; m < nm_pred; ++m) {
+        double *ra = r + static_cast<size_t>(1 + m) * nx, *rb = r + static_cast<size_t>(1 + nm_pred + m) * nx;
+        c1 = c1 + f.mode_re[m] * *ra;
+        c1 = c1 + f.mode_im[m] * *rb;
+        *ra = 0.0;
+        *rb = 0.0;
+      }
+      c2 = c2 + c1 * f.Z[s];
+    }
+    f.charge[ix] = c2;
+    const double cd = chargeden_from(f, c2);
+    f.chargeden[ix] = cd;
+    sCD[ix] = cd;
+  }
+  __syncthreads();  // every thread has read mode_re / mode_im before solve_body overwrites them
+  solve_body(f, sCD, sMode, sScr, sTab);
+}
+
 // ---------------------------------------------------------------------------
 // One-hop charge exchange (replaces MPI_Allreduce, src/pic1dp_interaction.F90:130-135,
 // for N processes = N GPUs of one node).  Every rank owns an exchange
@@ -2571,6 +2605,14 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
   } else {
     hipLaunchKernelGGL(k_field_solve_pair<0>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, pa);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_field_solve_pred(const FieldArgs &f, double *pred, int nm_pred, hipStream_t st) {
+  if (2 * f.nmode > FIELD_THREADS) return hipErrorInvalidValue;
+  const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
+                                       (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
+  hipLaunchKernelGGL(k_field_solve_pred, dim3(1), dim3(FIELD_THREADS), lds, st, f, pred, nm_pred);
   return hipGetLastError();
 }
 

@@ -231,6 +231,8 @@ hipError_t launch_pred_to_charge(const FieldArgs &f, double *pred, hipStream_t s
 // k_step_one's prediction accumulators [nspecies][1 + 2 nm][nx] + the field's kept modes -> this rank's
 // charge2 of the next first sub-step in f.charge; the accumulators are re-zeroed
 hipError_t launch_pred_combine(const FieldArgs &f, double *pred, int nm_pred, hipStream_t st);
+// launch_pred_combine, the scaling into f.chargeden and the mode-filter solve in one launch (call sites, one rank)
+hipError_t launch_field_solve_pred(const FieldArgs &f, double *pred, int nm_pred, hipStream_t st);
 // local charge + exchange: the summed charge1 into f.charge
 hipError_t launch_charge_exchange(const FieldArgs &f, const XchgArgs &x, hipStream_t st);
 // local charge + exchange + chargeden + field solve in one launch
