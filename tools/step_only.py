@@ -10,7 +10,9 @@ import pic1dp_amd  # noqa: E402
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**7
 nx = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=n, nx=nx))
+import json  # noqa: E402
+extra = json.loads(os.environ.get("PIC1DP_INPUT", "{}"))
+eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=n, nx=nx, **extra))
 eng.particle_load()
 eng.interaction_collect_charge()
 eng.field_solve_electric()
