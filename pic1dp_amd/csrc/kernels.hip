@@ -2320,6 +2320,143 @@ k_field_solve_pair_sums(const FieldArgs f, const XchgArgs x1, const PairArgs pa)
   }
 }
 
+// k_field_solve_pair_sums trimmed like k_field_solve_pair1, and launched with as many threads as the grid has
+// cells (up to 1024: at nx = 4096 every thread owns four cells and has all its loads in flight at once -- with 256
+// threads each of the kernel's loops is four dependent round trips): charge -> products, [chain | the six sums
+// fetched beside it], both inverse transforms in one loop.  41 -> 33 us at nx 4096, of which the chain is 23.
+template <int SRC>
+__global__ void __launch_bounds__(1024)
+k_field_solve_pair_sums1(const FieldArgs f, const XchgArgs x1, const PairArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nx = f.nx;
+  const int ne = (nx + 1) & ~1;
+  double *sPc = reinterpret_cast<double *>(smem);  // [ne] fre * chargeden
+  double *sPs = sPc + ne;                           // [ne] fim * chargeden
+  double *sMode = sPs + ne;                         // re, im, then the six sums
+  double *sScr = sMode + 8;                         // [16]
+  double *sV = sScr + 16;                           // SRC 1: [charge2 | six sums | pad]
+  const double *pk = pa.pack;
+  if constexpr (SRC == 1) {
+    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sV[ix] = charge_local_one(f, ix);
+    if (threadIdx.x < 8) {
+      sV[nx + threadIdx.x] = pa.pred[threadIdx.x];
+      pa.pred[threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+    exchange_vectors(x1, sV, nx + 8);
+    __syncthreads();
+    pk = sV;
+  }
+  const double ginv = f.grad_inv[0];
+  constexpr int U = 4;
+  const int T = blockDim.x;
+  double tr[U], ti[U];
+  for (int base = threadIdx.x; base < nx; base += U * T) {
+    double c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ix = base + u * T;
+      c[u] = tr[u] = ti[u] = 0.0;
+      if (ix < nx) {
+        tr[u] = f.fre[ix];
+        ti[u] = f.fim[ix];
+        if constexpr (SRC != 0) {
+          c[u] = pk[ix];
+        } else {
+          for (int sp = 0; sp < f.nspecies; ++sp) {  // src/pic1dp_interaction.F90:126-127
+            const double *r = f.rho_sp + static_cast<size_t>(sp) * nx + ix;
+            double c1 = *r;
+            for (int g = 1; g < f.rho_copies; ++g) c1 = c1 + r[static_cast<size_t>(g) * f.rho_stride];
+            c[u] = c[u] + c1 * f.Z[sp];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ix = base + u * T;
+      if (ix < nx) {
+        if constexpr (SRC == 0)
+          for (int sp = 0; sp < f.nspecies; ++sp) {
+            double *r = f.rho_sp + static_cast<size_t>(sp) * nx + ix;
+            for (int g = 0; g < f.rho_copies; ++g) r[static_cast<size_t>(g) * f.rho_stride] = 0.0;
+          }
+        f.charge[ix] = c[u];
+        const double cd = chargeden_from(f, c[u]);  // :138-148
+        f.chargeden[ix] = cd;
+        sPc[ix] = tr[u] * cd;
+        sPs[ix] = ti[u] * cd;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {  // the serial sums, ascending ix (:231-240)
+    const bool use_cos = threadIdx.x == 0;
+    const double acc = chain_sum_lds(use_cos ? sPc : sPs, nx);
+    if (use_cos) {
+      const double im = acc * f.sc_im * ginv;
+      sMode[1] = im;
+      f.mode_im[0] = im;
+    } else {
+      const double re = acc * f.sc_re * ginv;
+      sMode[0] = re;
+      f.mode_re[0] = re;
+    }
+  } else if (threadIdx.x >= 64 && threadIdx.x < 72) {  // beside them: the six sums (+ pad) of this step
+    const int k = threadIdx.x - 64;
+    if constexpr (SRC == 0) {
+      if (k < 6) sMode[2 + k] = pa.pred[k];
+      pa.pred[k] = 0.0;
+    } else {
+      if (k < 6) sMode[2 + k] = pk[nx + k];
+    }
+  }
+  __syncthreads();
+  const double re = sMode[0], im = sMode[1];
+  double ac, as;
+  pred_forward_sums(f, pa.pt, sMode + 2, re, im, ac, as);
+  const double im_h = ac * f.sc_im * ginv, re_h = as * f.sc_re * ginv;  // :234, :239, :243-247
+  if (threadIdx.x == 0) {
+    pa.mode_h[0] = re_h;
+    pa.mode_h[1] = im_h;
+  }
+  double e2 = 0.0;
+  const bool one_trip = nx <= U * T;
+  for (int base = threadIdx.x; base < nx; base += U * T) {
+    if (!one_trip) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ix = base + u * T;
+        tr[u] = ix < nx ? f.fre[ix] : 0.0;
+        ti[u] = ix < nx ? f.fim[ix] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ix = base + u * T;
+      if (ix < nx) {  // both inverse transforms, :251-257
+        double a = 0.0;
+        a = a + tr[u] * re;
+        a = a + ti[u] * im;
+        const double e = a * 2.0;
+        f.E[ix] = e;
+        e2 += e * e;
+        double b = 0.0;
+        b = b + tr[u] * re_h;
+        b = b + ti[u] * im_h;
+        pa.E_h[ix] = b * 2.0;
+      }
+    }
+  }
+  if (f.history) {  // int E^2 dx, src/pic1dp_output.F90:120-124
+    const double tot = block_sum(e2, sScr);
+    if (threadIdx.x == 0) {
+      const double nrm = sqrt(tot);
+      *f.history = nrm * nrm * f.lx / f.dnx;
+    }
+  }
+}
+
 // Many kept modes (2*nmode > FIELD_THREADS, up to the full spectrum nmode = nx/2,
 // SURVEY N4): the same arithmetic in the same order, spread over workgroups.
 // The reference's operators are then O(nx^2) dense matrices exactly as here
@@ -2572,6 +2709,33 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
       hipLaunchKernelGGL(k_field_solve_pair1<2>, dim3(1), dim3(FIELD_THREADS), l1, st, f, none, pa);
     } else {
       hipLaunchKernelGGL(k_field_solve_pair1<0>, dim3(1), dim3(FIELD_THREADS), l1, st, f, none, pa);
+    }
+    return hipGetLastError();
+  }
+  if (pa.kind == 2 && f.nmode == 1 && !pa.plain) {  // the lean kernel
+    const size_t ne = (static_cast<size_t>(f.nx) + 1) & ~static_cast<size_t>(1);
+    size_t l1 = sizeof(double) * (2 * ne + 8 + 16);
+    const int threads = f.nx > 2048 ? 1024 : (f.nx > 1024 ? 512 : FIELD_THREADS);
+    if (x1) {
+      l1 += sizeof(double) * pack_doubles(f.nx, 1, 2);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_field_solve_pair_sums1<1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_field_solve_pair_sums1<1>, dim3(1), dim3(threads), l1, st, f, *x1, pa);
+    } else if (pa.pack) {
+      if (l1 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_field_solve_pair_sums1<2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(k_field_solve_pair_sums1<2>, dim3(1), dim3(threads), l1, st, f, none, pa);
+    } else {
+      if (l1 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_field_solve_pair_sums1<0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(k_field_solve_pair_sums1<0>, dim3(1), dim3(threads), l1, st, f, none, pa);
     }
     return hipGetLastError();
   }

@@ -123,15 +123,19 @@ def test_one_pass_through_the_call_sites(amd, monkeypatch, kind):
                                      species_temperature=[1.0, 0.5], species_temperature2=[1.0, 1.0],
                                      species_density=[1.0, 1.0], species_v0=[0.0, 0.0], lx=4 * np.pi)],
                          ids=["nx96", "nx1000", "nx2050_full_f", "two_species"])
-def test_lean_pair_solve_equals_the_plain_one(oracle_mod, amd, monkeypatch, kw):
-    """k_field_solve_pair1 (one kept mode: everything that does not wait for the serial sums in front of them)
-    against k_field_solve_pair: the predicted half-step field and the run to rounding; and the field of the
+@pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
+def test_lean_pair_solve_equals_the_plain_one(oracle_mod, amd, monkeypatch, kw, kind):
+    """k_field_solve_pair1 / k_field_solve_pair_sums1 (one kept mode: everything that does not wait for the
+    serial sums in front of them) against k_field_solve_pair / k_field_solve_pair_sums: the predicted half-step field and the run to rounding; and the field of the
     new state from ITS charge density against the oracle's solve bit for bit, both kernels"""
     kw = dict(kw, nparticle_max=N)
+    if kind == 2 and kw["nx"] == 1000:
+        kw["nx"] = 4096               # the grid the sums are for: 1024 threads, four cells each
     monkeypatch.setenv("PIC1DP_PAIR_PLAIN", "1")
-    a = engine(amd, monkeypatch, True, **kw)
+    a = engine(amd, monkeypatch, True, kind, **kw)
     monkeypatch.delenv("PIC1DP_PAIR_PLAIN")
-    b = engine(amd, monkeypatch, True, **kw)
+    b = engine(amd, monkeypatch, True, kind, **kw)
+    assert a.predict_kind() == kind and b.predict_kind() == kind
     field = oracle_mod.Field(oracle_mod.make_input(**kw))
     for it in range(4):
         a.step(1)
