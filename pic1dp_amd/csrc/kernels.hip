@@ -57,6 +57,11 @@ __device__ __forceinline__ void glb_add(double *p, double v) {
 // held to 512 / 6 VGPRs (4 spilled registers; measured best, tools/ab_waves.sh).  k_step_half / k_step_full
 // are left alone: held to the same budget k_step_full spills 15-19 registers and runs 1.12-1.39 ms instead
 // of 0.96-0.98 ms (it then keeps 96 VGPRs and fewer waves).
+// 0: every x / lx through the hardware division sequence (tuning / cross-check builds).  A compile-time choice:
+// as a run-time flag the second code path cost the marker kernels registers (four more spilled in k_step_one)
+#ifndef PIC1DP_FAST_DIV
+#define PIC1DP_FAST_DIV 1
+#endif
 #ifndef PIC1DP_WAVES_PER_EU
 #define PIC1DP_WAVES_PER_EU 6
 #endif
@@ -177,7 +182,7 @@ __device__ __forceinline__ double divh(double a, double c, double rc, D &d) {
 // the hardware division.  tests: test_exact_division_by_lx (GPU and host).
 __device__ __forceinline__ double div_lx(double x, const GridConst &g) {
   const double ax = fabs(x);
-  if (g.fast_div && ax > 0x1p-500 && ax < 0x1p+500) {
+  if (PIC1DP_FAST_DIV && ax > 0x1p-500 && ax < 0x1p+500) {
     const double y = g.rlx;
     const double q0 = x * y;
     const double r0 = fma(-g.lx, q0, x);
@@ -198,7 +203,9 @@ __device__ __forceinline__ double div_lx(double x, const GridConst &g) {
 // as the IEEE quotient does; NaN stays NaN and folds to cell 0 below like NaN / lx; |x| > 2^500 would
 // index outside the grid in the reference and folds to cell 0 here either way.
 __device__ __forceinline__ double div_lx_unchecked(double x, const GridConst &g) {
-  if (!g.fast_div) return x / g.lx;
+#if !PIC1DP_FAST_DIV
+  return x / g.lx;
+#endif
   const double y = g.rlx;
   const double q0 = x * y;
   const double r0 = fma(-g.lx, q0, x);
