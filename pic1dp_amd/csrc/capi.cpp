@@ -682,7 +682,6 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   c->grid.dt_full = in->dt;
   c->grid.nx = nx;
   c->grid.rlx = 1.0 / in->lx;
-  c->grid.fast_div = 1;
   // copies of the per-workgroup rho tile: as many (up to 8) as leave two workgroups per CU
   // their LDS (E0, Eh and the copies within 80 KiB); PIC1DP_RHO_COPIES overrides
   c->grid.rcopies = 1;

@@ -2962,7 +2962,6 @@ __host__ __device__ inline double div_check_value(uint64_t seed, int64_t i, doub
 
 __global__ void k_div_check(GridConst g, uint64_t seed, int64_t n, unsigned long long *bad) {
   GridConst gf = g;
-  gf.fast_div = 1;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const double x = div_check_value(seed, i, g.lx, g.nx);

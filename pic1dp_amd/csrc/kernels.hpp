@@ -28,7 +28,6 @@ struct GridConst {
   double lx, dnx, dt_full;
   double rlx;    // RN(1/lx), for the exact division by the constant lx
   int nx;
-  int fast_div;  // unused (x/lx by reciprocal + two FMA corrections is a compile-time choice: kernels.hip PIC1DP_FAST_DIV)
   int rcopies;   // copies of the workgroup's LDS rho tile (1, 2, 4, 8; lane l deposits into copy l % rcopies)
   int gcopies, gstride;  // copies of the species accumulators in memory (power of two) and doubles between them:
                          // workgroup b flushes into copy b % gcopies (fewer atomics per address), the field
