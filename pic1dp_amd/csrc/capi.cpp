@@ -239,7 +239,7 @@ LaunchCfg particle_launch(const pic1dp_ctx *c, int64_t np, bool with_E, bool wit
   const int nx = c->in.nx;
   LaunchCfg lc{};
   lc.lds = sizeof(double) * ((with_E ? static_cast<size_t>((nx + 2) & ~1) : 0) +
-                             (with_rho ? static_cast<size_t>(nx) * c->grid.rcopies : 0));
+                             (with_rho ? static_cast<size_t>(nx) * c->grid.rcopies + 1 : 0));  // + guard cell
   const size_t lds_cap = PARTICLE_LDS_CAP;
   int by_lds = lc.lds ? static_cast<int>(lds_cap / lc.lds) : 8;
   if (by_lds < 1) by_lds = 1;
@@ -1421,7 +1421,7 @@ int pic1dp_hip_substep(pic1dp_ctx *c, int32_t irk) {
 // LDS bytes of the whole-step kernels: E0 tile, Eh tile (full only), rho tile
 static size_t step_lds_bytes(int nx, bool full, int rcopies = 1) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
-  return sizeof(double) * ((full ? 2 : 1) * ne + static_cast<size_t>(nx) * rcopies);
+  return sizeof(double) * ((full ? 2 : 1) * ne + ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)));
 }
 
 static bool step_recompute_ok(const pic1dp_ctx *c) {

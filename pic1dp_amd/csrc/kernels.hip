@@ -477,10 +477,10 @@ __device__ __forceinline__ double deposit_one(double x, double q, double *sR, co
   if (ix > g.nx - 1) ix = 0;
   lds_add_matched(sR, ix, (1.0 - wl) * q);
 #else
-  lds_add(&sR[ix], wl * q);              // :110
-  ix = ix + 1;
-  if (ix > g.nx - 1) ix = 0;
-  lds_add(&sR[ix], (1.0 - wl) * q);      // :113
+  // :110, :113.  The right-hand neighbour of the last cell is cell 0: of the next copy of the tile, or the
+  // guard cell behind the last copy (flush_rho adds them all) -- no wrap-around of the index, one address
+  lds_add(&sR[ix], wl * q);
+  lds_add(&sR[ix + 1], (1.0 - wl) * q);
 #endif
   return px;
 }
@@ -493,7 +493,7 @@ __device__ __forceinline__ double *my_rho_copy(double *sR, const GridConst &g) {
   return sR + (threadIdx.x & (g.rcopies - 1)) * g.nx;
 }
 __device__ __forceinline__ void zero_rho(double *sR, const GridConst &g) {
-  for (int i = threadIdx.x; i < g.nx * g.rcopies; i += blockDim.x) sR[i] = 0.0;
+  for (int i = threadIdx.x; i < g.nx * g.rcopies + 1; i += blockDim.x) sR[i] = 0.0;  // + the guard cell
 }
 __device__ __forceinline__ void flush_rho(const double *sR, double *rho, const GridConst &g) {
   // one global atomic per cell per workgroup; start cell rotated by workgroup
@@ -506,6 +506,7 @@ __device__ __forceinline__ void flush_rho(const double *sR, double *rho, const G
     if (j >= nx) j -= nx;
     double val = sR[j];
     for (int c = 1; c < g.rcopies; ++c) val += sR[c * nx + j];
+    if (j == 0) val += sR[g.rcopies * nx];  // the guard cell behind the last copy is cell 0
     if (val != 0.0) glb_add(&rho[j], val);  // rho: this workgroup's copy of the accumulator
   }
 }
@@ -733,6 +734,7 @@ struct StepArgsDev {
   double *pred;               // [1 + 2*pred_nm][nx]; k_step_sums: [8]
   int pred_nm, t2_mode;
   const double *eh_re, *eh_im;  // k_step_sums: the kept mode of Eh
+  double snx, pred_k;           // k_step_one's prediction: nx / lx, and dt/2 Z/m
 };
 
 // CARRY: a species whose divisor constants are general numbers spends most of either kernel
@@ -857,7 +859,7 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
   // DIAG: histograms behind the rho copies (16-byte aligned), then the block_sum scratch
-  double *sH = sR0 + ((nx * a.g.rcopies + 1) & ~1);
+  double *sH = sR0 + ((nx * a.g.rcopies + 2) & ~1);
   const int ntot = DIAG ? 3 * a.dg.nxo * a.dg.nvo + 3 * a.dg.nvo : 0;
   const DistBins bins{sH, a.dg.nxo * a.dg.nvo, a.dg.nvo};
   DistSums sums;
@@ -976,15 +978,6 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
 // the order of magnitude the atomics' order contributes anyway).  Full-f: rho_h = R0 (p at x').
 // Falls back to k_step_half + k_step_full when nmode > PRED_MAX_MODES or the tiles outgrow the LDS.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void flush_tile(const double *sT, double *dst, int nx) {
-  const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);
-  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-    int j = i + rot;
-    if (j >= nx) j -= nx;
-    const double val = sT[j];
-    if (val != 0.0) glb_add(&dst[j], val);
-  }
-}
 
 // c = dt/2 * (p - w) * (-f0'/f0)(v) * Z / m  (linear: p), and -f0'/f0(v) itself for the carry
 template <int DIST, int MODE, int POW2, class D>
@@ -1009,38 +1002,72 @@ __device__ __forceinline__ double pred_coef(double v, double w, double p, double
 
 // the prediction deposits of one marker in its NEW state n (x wrapped); returns -f0'/f0(n.v)
 // (ix, wl): cell and left weight of n.x, where the next step gathers its field (:250-257) -- the deposit
-// of the new state has just computed them
+// of the new state has just computed them.
+// The kernel runs at the package power limit with its FP64 pipes ~77 % busy at the clock that leaves
+// (DESIGN.md 7), so instructions are what this part is written for:
+// * the tables lie cell by cell, sAB[cell][A_0 B_0 (A_1 B_1)] with a guard cell, and the accumulators likewise,
+//   sP[cell][R0 RA_0 RB_0 (...)] with TWO guard cells (folded into cells 0 and 1 at the flush): one address
+//   per cell instead of one per tile and cell, no wrap-around of the right-hand cell, no clamp;
+// * the cell of x' needs no exact division and no wrap of the position: the prediction equals a marker-by-
+//   marker deposit to rounding anyway, and a deposit is continuous across a cell boundary (a position within
+//   an ulp of one puts ~0 into the far cell either way) -- s = x' * (nx / lx), one multiplication, and the
+//   CELL is wrapped (x' in (-lx, 2 lx) unless a marker crosses a box length in half a step: cells 0 ... nx,
+//   right-hand neighbour up to nx + 1; cvt(NaN) = 0);
+// * the constants of c are folded (pred_k = dt/2 Z/m).
 template <int DIST, int MODE, int POW2>
-__device__ __forceinline__ double pred_one(const One &n, double p, int ix, double wl, const double *sA, const double *sB,
-                                           int ne, double *sP, const StepArgsDev &a) {
-  const int nx = a.g.nx, nm = a.pred_nm;
-  double xh = n.x + a.dt_half * n.v;              // the next step's half push of x (:261)
-  xh = wrap(xh, a.g.lx);                          // and the wrap + cell of its deposit (:102-108)
-  int ih;
-  double wh;
-  locate(xh, a.g, ih, wh);
-  int ih1 = ih + 1;
-  if (ih1 > nx - 1) ih1 = 0;
+__device__ __forceinline__ double pred_one(const One &n, double p, int ix, double wl, const double *sAB, double *sP,
+                                           const StepArgsDev &a) {
+  const int nm = a.pred_nm, np1 = 1 + 2 * nm;
+  const double xh = n.x + a.dt_half * n.v;        // the next step's half push of x (:261)
+  const double sh = xh * a.snx;                   // its cell, wrapped as an integer (:102-108 to rounding)
+  const double fh = floor(sh);
+  int ih = static_cast<int>(fh);
+  const double wr = sh - fh, wh = 1.0 - wr;
+  ih = ih < 0 ? ih + a.g.nx : ih;
+  ih = ih > a.g.nx ? ih - a.g.nx : ih;            // (cell nx is a guard cell)
+  if (static_cast<unsigned>(ih) > static_cast<unsigned>(a.g.nx)) {  // more than a box length in half a step, NaN
+    ih = ih % a.g.nx;
+    if (ih < 0) ih += a.g.nx;
+  }
+  double *cl = sP + __mul24(ih, np1), *cr = cl + np1;
   double t2 = 0.0;
   if constexpr (MODE == MODE_FULLF) {
-    lds_add(&sP[ih], wh * p);
-    lds_add(&sP[ih1], (1.0 - wh) * p);
+    lds_add(cl, wh * p);
+    lds_add(cr, wr * p);
   } else {
-    lds_add(&sP[ih], wh * n.w);
-    lds_add(&sP[ih1], (1.0 - wh) * n.w);
-    const double c = pred_coef<DIST, MODE, POW2>(n.v, n.w, p, a.dt_half, a.s, t2);
+    lds_add(cl, wh * n.w);
+    lds_add(cr, wr * n.w);
+    const double tmp1 = (MODE == MODE_DF_LIN) ? p : (p - n.w);
+    if constexpr (POW2 == 0) {
+      if (a.s.fastc) {
+        DivFast dv;
+        t2 = dlnf0<DIST, POW2>(n.v, a.s, dv);
+        if (!dv.ok()) {
+          DivTrue dt;
+          t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+        }
+      } else {
+        DivTrue dt;
+        t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+      }
+    } else {
+      DivTrue dt;
+      t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+    }
+    const double c = tmp1 * t2 * a.pred_k;
+    const double *gl = sAB + __mul24(ix, 2 * nm), *gr = gl + 2 * nm;
+    const double wlr = 1.0 - wl;
     for (int m = 0; m < nm; ++m) {
-      const double *tA = sA + m * ne, *tB = sB + m * ne;
-      double A = tA[ix] * wl;
-      A = A + tA[ix + 1] * (1.0 - wl);
-      double B = tB[ix] * wl;
-      B = B + tB[ix + 1] * (1.0 - wl);
+      const double2 tl = *reinterpret_cast<const double2 *>(gl + 2 * m), tr = *reinterpret_cast<const double2 *>(gr + 2 * m);
+      double A = tl.x * wl;
+      A = A + tr.x * wlr;
+      double B = tl.y * wl;
+      B = B + tr.y * wlr;
       const double cA = c * A, cB = c * B;
-      double *RA = sP + static_cast<size_t>(1 + m) * nx, *RB = sP + static_cast<size_t>(1 + nm + m) * nx;
-      lds_add(&RA[ih], wh * cA);
-      lds_add(&RA[ih1], (1.0 - wh) * cA);
-      lds_add(&RB[ih], wh * cB);
-      lds_add(&RB[ih1], (1.0 - wh) * cB);
+      lds_add(cl + 1 + m, wh * cA);
+      lds_add(cr + 1 + m, wr * cA);
+      lds_add(cl + 1 + nm + m, wh * cB);
+      lds_add(cr + 1 + nm + m, wr * cB);
     }
   }
   return t2;
@@ -1052,32 +1079,27 @@ template <int DIST, int MODE, int POW2, bool NT, int T2>
 __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   exp_table_init();
-  const int nx = a.g.nx, nm = a.pred_nm;
+  const int nx = a.g.nx, nm = a.pred_nm, np1 = 1 + 2 * nm;
   const int ne = (nx + 2) & ~1;
   double *sE0 = reinterpret_cast<double *>(smem);
   double *sEh = sE0 + ne;
-  double *sA = sEh + ne;
-  double *sB = sA + static_cast<size_t>(nm) * ne;
-  double *sR0 = sB + static_cast<size_t>(nm) * ne;
-  double *sP = sR0 + ((nx * a.g.rcopies + 1) & ~1);
+  double *sAB = sEh + ne;                                        // [nx + 1][2 nm]: A_0 B_0 (A_1 B_1) per cell
+  double *sR0 = sAB + static_cast<size_t>(nx + 1) * 2 * nm;
+  double *sP = sR0 + ((nx * a.g.rcopies + 2) & ~1);              // [nx + 2][1 + 2 nm]: R0 RA_m RB_m per cell
   for (int i = threadIdx.x; i < nx; i += blockDim.x) {
     sE0[i] = a.E0[i];
     sEh[i] = a.Eh[i];
   }
-  for (int i = threadIdx.x; i < nm * nx; i += blockDim.x) {
-    const int m = i / nx, c = i - m * nx;
-    sA[m * ne + c] = a.tabA[i];
-    sB[m * ne + c] = a.tabB[i];
+  for (int i = threadIdx.x; i < nm * (nx + 1); i += blockDim.x) {
+    const int m = i / (nx + 1), c = i - m * (nx + 1), cs = c < nx ? c : 0;  // cell nx: the guard, = cell 0
+    sAB[c * 2 * nm + 2 * m] = a.tabA[m * nx + cs];
+    sAB[c * 2 * nm + 2 * m + 1] = a.tabB[m * nx + cs];
   }
   zero_rho(sR0, a.g);
-  for (int i = threadIdx.x; i < (1 + 2 * nm) * nx; i += blockDim.x) sP[i] = 0.0;
+  for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
   if (threadIdx.x == 0) {
     sE0[nx] = a.E0[0];
     sEh[nx] = a.Eh[0];
-  }
-  if (threadIdx.x < nm) {
-    sA[threadIdx.x * ne + nx] = a.tabA[threadIdx.x * nx];
-    sB[threadIdx.x * ne + nx] = a.tabB[threadIdx.x * nx];
   }
   __syncthreads();
   double *sR = my_rho_copy(sR0, a.g);
@@ -1103,10 +1125,10 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     // the two markers of a pair one after the other (PAIR_FENCE): interleaving their four exp chains
     // costs more registers than six waves per SIMD leave
     const One n0 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x, &i0, &l0);
-    const double u0 = pred_one<DIST, MODE, POW2>(n0, P.x, i0, l0, sA, sB, ne, sP, a);
+    const double u0 = pred_one<DIST, MODE, POW2>(n0, P.x, i0, l0, sAB, sP, a);
     PAIR_FENCE();
     const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y, &i1, &l1);
-    const double u1 = pred_one<DIST, MODE, POW2>(n1, P.y, i1, l1, sA, sB, ne, sP, a);
+    const double u1 = pred_one<DIST, MODE, POW2>(n1, P.y, i1, l1, sAB, sP, a);
     st2t<NT>(x2 + o, n0.x, n1.x);
     if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
     if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
@@ -1122,12 +1144,28 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     a.x[i] = n.x;
     if constexpr (PUSH_V) a.v[i] = n.v;
     if constexpr (HAS_W) a.w[i] = n.w;
-    const double u = pred_one<DIST, MODE, POW2>(n, p, ic, lc, sA, sB, ne, sP, a);
+    const double u = pred_one<DIST, MODE, POW2>(n, p, ic, lc, sAB, sP, a);
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
   }
   __syncthreads();
   flush_rho(sR0, a.rho, a.g);
-  for (int k = 0; k < 1 + 2 * nm; ++k) flush_tile(sP + static_cast<size_t>(k) * nx, a.pred + static_cast<size_t>(k) * nx, nx);
+  // the guard cells nx, nx + 1 are cells 0, 1 (mod nx); then one global atomic per cell and slice
+  if (threadIdx.x < 2 * np1) {
+    const int g = threadIdx.x / np1, k = threadIdx.x - g * np1;
+    const int to = (nx + g) % nx;
+    if (g == 0 || to != 0 || nx > 1) lds_add(&sP[to * np1 + k], sP[(nx + g) * np1 + k]);
+  }
+  __syncthreads();
+  {
+    const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);
+    for (int i = threadIdx.x; i < np1 * nx; i += blockDim.x) {
+      const int k = i / nx;
+      int c = i - k * nx + rot;
+      if (c >= nx) c -= nx;
+      const double val = sP[c * np1 + k];
+      if (val != 0.0) glb_add(&a.pred[static_cast<size_t>(k) * nx + c], val);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1202,7 +1240,7 @@ __global__ void __launch_bounds__(1024) k_step_sums(const StepArgsDev a) {
   double *sA = sE0 + ne;
   double *sB = sA + ne;
   double *sR0 = sB + ne;
-  double *sScr = sR0 + ((nx * a.g.rcopies + 1) & ~1);  // [16] reduction scratch
+  double *sScr = sR0 + ((nx * a.g.rcopies + 2) & ~1);  // [16] reduction scratch
   for (int i = threadIdx.x; i < nx; i += blockDim.x) {
     sE0[i] = a.E0[i];
     sA[i] = a.tabA[i];
@@ -1459,6 +1497,8 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.t2_mode = a.t2_mode;
   d.eh_re = a.eh_re;
   d.eh_im = a.eh_im;
+  d.snx = a.g.dnx / a.g.lx;
+  d.pred_k = a.dt_half * a.s.Z / a.s.m;
   switch (a.iptcldist) {
     case 1: return launch_step_d<1>(d, a.deltaf, a.linear, full, lc, st);
     case 2: return launch_step_d<2>(d, a.deltaf, a.linear, full, lc, st);

@@ -28,7 +28,8 @@ struct GridConst {
   double lx, dnx, dt_full;
   double rlx;    // RN(1/lx), for the exact division by the constant lx
   int nx;
-  int rcopies;   // copies of the workgroup's LDS rho tile (1, 2, 4, 8; lane l deposits into copy l % rcopies)
+  int rcopies;   // copies of the workgroup's LDS rho tile (1, 2, 4, 8; lane l deposits into copy l % rcopies);
+                 // the tile region is nx * rcopies + 1 doubles: a guard cell (= cell 0) behind the last copy
   int gcopies, gstride;  // copies of the species accumulators in memory (power of two) and doubles between them:
                          // workgroup b flushes into copy b % gcopies (fewer atomics per address), the field
                          // kernels add the copies up
@@ -143,18 +144,20 @@ constexpr int PRED_MAX_MODES = 2;
 // dynamic LDS of k_step_sums: E0, A, B tiles (with guard cell), rho copies, reduction scratch
 inline size_t step_sums_lds_bytes(int nx, int rcopies) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
-  return sizeof(double) * (3 * ne + ((static_cast<size_t>(nx) * rcopies + 1) & ~static_cast<size_t>(1)) + 16);
+  return sizeof(double) * (3 * ne + ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) + 16);
 }
-// dynamic LDS of k_step_one: E0, Eh, A_m, B_m tiles (with guard cell), rho copies, 1 + 2 nm prediction tiles
+// dynamic LDS of k_step_one: E0, Eh tiles (with guard cell), the tables cell by cell (nx + 1 cells of 2 nm), rho
+// copies, the prediction accumulators cell by cell (nx + 2 cells of 1 + 2 nm)
 inline size_t step_one_lds_bytes(int nx, int rcopies, int nm) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
-  return sizeof(double) * ((2 + 2 * static_cast<size_t>(nm)) * ne + ((static_cast<size_t>(nx) * rcopies + 1) & ~static_cast<size_t>(1)) +
-                           (1 + 2 * static_cast<size_t>(nm)) * nx);
+  return sizeof(double) * (2 * ne + (static_cast<size_t>(nx) + 1) * 2 * nm +
+                           ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) +
+                           (static_cast<size_t>(nx) + 2) * (1 + 2 * nm));
 }
 // dynamic LDS of the DIAG variant beyond the grid tiles: histograms + reduction scratch
 inline size_t step_diag_lds_bytes(int nx, int rcopies, int nxo, int nvo) {
-  const size_t pad = ((static_cast<size_t>(nx) * rcopies + 1) & ~static_cast<size_t>(1)) - static_cast<size_t>(nx) * rcopies;
-  return sizeof(double) * (pad + 3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo) + 16);
+  (void)nx, (void)rcopies;  // the rho region of step_lds_bytes ends 16-byte aligned
+  return sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo) + 16);
 }
 // full = false: first sub-step (deposit of the half-step state, nothing stored)
 // full = true : second sub-step (recompute half-step state, push, deposit, store)
