@@ -231,3 +231,25 @@ def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind)
         assert a.kernel_stats(3)[1] == ns and a.kernel_stats(6)[1] == 8 * ns and a.kernel_stats(4)[1] == 0
     else:
         assert a.kernel_stats(3)[1] == 8 * ns and a.kernel_stats(4)[1] == 8 * ns and a.kernel_stats(6)[1] == 0
+
+
+@pytest.mark.parametrize("kw,kind", [
+    (dict(nx=2542), 1), (dict(nx=2543), 2),                                   # the last grid the tiles hold, the first for the sums
+    (dict(nx=1694, nmode=2, modes=[1, 3]), 1), (dict(nx=1695, nmode=2, modes=[1, 3]), 0),
+    (dict(nx=5083), 2), (dict(nx=5084), 0)],                                  # the last grid for the sums, then two passes
+    ids=["tiles_last", "sums_first", "two_modes_last", "two_modes_beyond", "sums_last", "beyond"])
+def test_one_pass_at_the_lds_limits(amd, monkeypatch, kw, kind):
+    """the grids at which the one-pass kernels' LDS tiles just fit and just do not (kernels.hpp step_one_lds_bytes,
+    step_sums_lds_bytes against PARTICLE_LDS_CAP): the choice, and the run against the two-pass engine"""
+    kw = dict(kw, nparticle_max=N)
+    a = engine(amd, monkeypatch, True, **kw)
+    assert a.predict_kind() == kind
+    b = engine(amd, monkeypatch, False, **kw)
+    a.step(5)
+    b.step(5)
+    assert np.max(np.abs(a.energy_history() / b.energy_history() - 1.0)) < 1e-11
+    assert relerr(a.get_field()["electric"], b.get_field()["electric"]) < 1e-11
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
+
