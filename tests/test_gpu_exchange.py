@@ -28,16 +28,18 @@ def run_ranks(tmp_path, nproc, kw, steps, mode, port, timeout_ms="60000"):
     return [np.load(out + ".rank%d.npz" % k) for k in range(nproc)]
 
 
-@pytest.mark.parametrize("nproc,mode,kind", [(2, "step", 1), (3, "step", 1), (2, "calls", 1), (3, "step", 2), (2, "calls", 2)],
-                         ids=["2-step", "3-step", "2-calls", "3-step-sums", "2-calls-sums"])
-def test_exchange_ranks_share_the_gpu(amd, tmp_path, monkeypatch, nproc, mode, kind):
+@pytest.mark.parametrize("nproc,mode,kind,nx", [(2, "step", 1, 128), (3, "step", 1, 128), (2, "calls", 1, 128),
+                                                (3, "step", 2, 128), (2, "calls", 2, 128),
+                                                (2, "step", 1, 2048), (2, "step", 2, 4096)],
+                         ids=["2-step", "3-step", "2-calls", "3-step-sums", "2-calls-sums", "2-step-nx2048", "2-step-sums-nx4096"])
+def test_exchange_ranks_share_the_gpu(amd, tmp_path, monkeypatch, nproc, mode, kind, nx):
     """kind 2: the one-pass prediction travels as six sums behind charge2 (k_step_sums, the large-grid kernel,
-    insisted on at this small grid)"""
-    kw = dict(nparticle_max=600_000, nx=128)
+    insisted on at the small grid); the large grids: the paired solve's exchange vector beyond 64 KiB of LDS"""
+    kw = dict(nparticle_max=600_000, nx=nx)
     steps = 12
     if kind == 2:
         monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
-    ranks = run_ranks(tmp_path, nproc, kw, steps, mode, 29541 + nproc + 10 * kind)
+    ranks = run_ranks(tmp_path, nproc, kw, steps, mode, 29541 + nproc + 10 * kind + (nx > 128) * 20)
     # every rank holds the same field, bit for bit
     for r in ranks[1:]:
         assert np.array_equal(r["E"], ranks[0]["E"])
