@@ -554,8 +554,8 @@ def test_split_phase_charge_time_loop(amd):
     assert b.kernel_stats(1)[1] == 0 and b.kernel_stats(4)[1] + b.kernel_stats(6)[1] == 3
 
 
-@pytest.mark.parametrize("kind", [1, 2], ids=["tiles", "sums"])
-def test_rccl_allreduce_path_single_rank(oracle_mod, amd, monkeypatch, kind):
+@pytest.mark.parametrize("kind,nx", [(1, 64), (2, 64), (1, 2048), (2, 4096)], ids=["tiles", "sums", "tiles-nx2048", "sums-nx4096"])
+def test_rccl_allreduce_path_single_rank(oracle_mod, amd, monkeypatch, kind, nx):
     """a 1-rank RCCL communicator: exercises the run-time RCCL binding, the
     unique-id hand-off and the split kernels (charge_local -> ncclAllReduce on
     the engine's stream -> field solve; in a one-pass step: pack -> ONE
@@ -563,7 +563,7 @@ def test_rccl_allreduce_path_single_rank(oracle_mod, amd, monkeypatch, kind):
     sums) that N > 1 uses"""
     if kind == 2:
         monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
-    sim, eng = pair(oracle_mod, amd, nparticle_max=100000, nx=64)
+    sim, eng = pair(oracle_mod, amd, nparticle_max=100000, nx=nx)
     assert eng.predict_kind() == kind
     uid = eng.comm_unique_id()
     assert len(uid) == 128 and any(uid)
