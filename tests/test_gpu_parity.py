@@ -173,6 +173,30 @@ def test_collect_charge(oracle_mod, amd, nx):
     assert relerr(eng.get_field()["chargeden"], sim.get_field()[1]) < CHARGE_RTOL
 
 
+@pytest.mark.parametrize("copies", [2, 4, 8])
+def test_collect_charge_with_copies_of_the_rho_tile(oracle_mod, amd, monkeypatch, copies):
+    """PIC1DP_RHO_COPIES: lane l deposits into copy l % copies of the workgroup's rho tile; the right-hand
+    neighbour of the last cell is cell 0 of the NEXT copy (or the guard cell behind the last one).  Charge
+    density against the oracle through every kernel that deposits: the stand-alone deposit, the fused
+    sub-step, the whole-step kernels"""
+    monkeypatch.setenv("PIC1DP_RHO_COPIES", str(copies))
+    sim, eng = pair(oracle_mod, amd, nparticle_max=200001, nx=48)
+    eng.interaction_collect_charge()
+    sim.collect_charge()
+    assert relerr(eng.get_field()["chargeden"], sim.get_field()[1]) < CHARGE_RTOL
+    eng.field_solve_electric()
+    sim.solve_field()
+    for mode in (1, 0):
+        eng.set_step_mode(mode)
+        eng.step(3)
+        for _ in range(3):
+            sim.step(1)
+        eng.interaction_collect_charge()
+        sim.collect_charge()
+        assert relerr(eng.get_field()["chargeden"], sim.get_field()[1]) < 1e-10, mode
+        assert abs(eng.field_energy() / sim.field_energy() - 1.0) < ENERGY_RTOL, mode
+
+
 def test_collect_charge_edge_positions(oracle_mod, amd):
     """positions on and beyond the period boundaries, signed zeros, the
     x + lx -> lx rounding case and far-out values (general fmod)"""
