@@ -253,3 +253,26 @@ def test_one_pass_at_the_lds_limits(amd, monkeypatch, kw, kind):
     for k in "xvw":
         assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
 
+
+@pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
+def test_prediction_of_markers_that_cross_several_boxes(amd, monkeypatch, kind):
+    """markers fast enough to cross more than a box length in half a step: the prediction wraps the CELL of
+    x + dt/2 v as an integer (its general path), the push wraps the position"""
+    kw = dict(nparticle_max=N, nx=96, iptcldist=0, species_density=[1.0], species_v0=[0.0], lx=4 * np.pi)
+    a = engine(amd, monkeypatch, True, kind, **kw)
+    b = engine(amd, monkeypatch, False, **kw)
+    g = b.particles_download()
+    rng = np.random.default_rng(5)
+    fast = rng.random(g["v"].size) < 0.05
+    g["v"][fast] = rng.choice([-1.0, 1.0], fast.sum()) * rng.uniform(600.0, 3000.0, fast.sum())
+    for e in (a, b):
+        e.particles_upload(g["x"], g["v"], g["p"], g["w"])
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+    a.kernel_stats_enable(True)
+    a.step(5)
+    b.step(5)
+    assert np.max(np.abs(a.energy_history() / b.energy_history() - 1.0)) < 1e-11
+    assert relerr(a.get_field_half(), b.get_field_half()) < 1e-11
+    assert a.kernel_stats(6)[1] == 5
+
