@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--step-mode", type=int, default=0, choices=[0, 1],
                     help="0: whole-step kernels (half-step state recomputed); 1: two fused sub-steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic-pass", action="store_true",
+                    help="roofline.traffic from the committed profile constant instead of two rocprofv3 --pmc "
+                         "passes of this command run as child processes (N = 1 only)")
     ap.add_argument("--cpu-particles", type=int, default=10**7, help="markers of the CPU sample (BASELINE.md 3: C2)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of the all-core CPU sample")
     return ap.parse_args()
@@ -259,6 +262,56 @@ class Job:
             self.eng.step(nsteps)
         else:
             self.call_sites(nsteps)
+
+
+def measure_traffic(a, key):
+    """HBM bytes per launch of the dominant kernel, measured for THIS command: two child processes run it again
+    for five steps under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, --kernel-trace
+    only) while this process idles; bytes = 2 * FETCH_SIZE KiB (gfx950 wide-read correction) + WRITE_SIZE KiB,
+    mean over the kernel's launches (profiles/summarize_pmc.py).  (None, why) when that is not possible."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    try:
+        import summarize_pmc
+    except ImportError as e:
+        return None, "profiles/summarize_pmc.py: %s" % e
+    base = tempfile.mkdtemp(prefix="pic1dp_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(base, counter.lower())
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--config", a.config, "--steps", "5", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-strong", "--no-traffic-pass"]
+            if a.particles:
+                cmd += ["--particles", str(a.particles)]
+            if a.nx:
+                cmd += ["--nx", str(a.nx)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                                   timeout=300)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, "rocprofv3 --pmc %s pass: %s" % (counter, e)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s pass failed (exit %d)" % (counter, r.returncode)
+            csvs = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not csvs:
+                return None, "rocprofv3 --pmc %s pass wrote no counter file" % counter
+            mean, _ = summarize_pmc.mean_by_kernel(",".join(csvs), counter)
+            if key not in mean:
+                return None, "%s is not in the %s pass" % (key, counter)
+            vals[counter] = mean[key]
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return vals["FETCH_SIZE"] * 1024 * 2.0 + vals["WRITE_SIZE"] * 1024, None
 
 
 def main():
@@ -517,7 +570,17 @@ def main():
         achieved = kbytes * np_local / (avg_ms * 1e-3) / 1e9 if kn else 0.0
         # HBM bytes per launch of that kernel: rocprofv3 --pmc passes of this command, committed under
         # profiles/ (a profile constant of the same workload, NOT measured in this run)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_why = None, None, None
+        tkey = "k_step_one" if one_n else ("k_step_full" if full_n else "k_push")
+        if one_n and eng.predict_kind() == 2:
+            tkey = "k_step_sums"
+        if world == 1 and not a.no_traffic_pass and not a.unfused and a.step_mode == 0:
+            traffic, traffic_why = measure_traffic(a, tkey)
+            if traffic is not None:
+                traffic_src = ("measured for this command in this run: two child processes, rocprofv3 --pmc FETCH_SIZE "
+                               "and --pmc WRITE_SIZE (separate passes, --kernel-trace only) over 5 steps; "
+                               "2 x FETCH_SIZE KiB (gfx950 wide-read correction) + WRITE_SIZE KiB, mean over the "
+                               "launches of %s" % tkey)
         for tname in ("traffic_%s.json" % a.config, "traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is not None or not os.path.exists(tpath):
@@ -531,7 +594,8 @@ def main():
                         key = "k_step_sums"
                     traffic = tj.get("hbm_bytes_per_launch_by_kernel", {}).get(key)
                     traffic_src = "profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
-                                  "this command (committed profile of the same workload, not measured in this run)" % tname
+                                  "this command (committed profile of the same workload, not measured in this run%s)" \
+                                  % (tname, ": " + traffic_why if traffic_why else "")
             except (OSError, ValueError):
                 pass
         # the box's own streaming rates (second denominator): plain copy and the

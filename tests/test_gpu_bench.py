@@ -58,6 +58,10 @@ def test_bench_contract_line_small():
     assert abs(r["reference_priced_GBs"] / r["achieved"] - 160.0 / 72.0) < 1e-9
     assert r["whole_step_bytes"] == 72.0 * n          # every timed step was one k_step_one launch
     assert r["whole_step_GBs"] <= r["peak"]
+    # HBM traffic per launch measured for this very command (two child rocprofv3 --pmc passes): the bytes the
+    # kernel has to move plus the tiles' staging and flush (small at any realistic marker count)
+    assert r["traffic"] is not None and "measured for this command in this run" in r["traffic_source"], r["traffic_source"]
+    assert 0.95 < r["traffic"] / (72.0 * n) < 1.5
     assert d["strong_1e8_total"]["same_run_as_headline"] is True
     assert d["drop_in_call_sites"]["value"] > 0
     assert d["attribution"]["particle_kernels_ms_per_step"] > 0 and d["attribution"]["field_solve_ms_per_step"] > 0

@@ -20,7 +20,7 @@ cat "$OUT/bench_${CFG}_wholestep.json"
 
 echo "[2/4] kernel trace + stats" && date
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \
-  python3 "$R/bench.py" --config $CFG --steps 50 --warmup 40 --no-cpu-baseline \
+  python3 "$R/bench.py" --config $CFG --steps 50 --warmup 40 --no-cpu-baseline --no-traffic-pass \
   > "$OUT/bench_${CFG}_wholestep_under_rocprof.json" 2> "$OUT/stats.err"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -n 1)" "$OUT/bench_${CFG}_wholestep_kernel_stats.csv"
 
@@ -28,7 +28,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   lc=$(echo $C | tr 'A-Z' 'a-z')
   echo "[pmc] $C" && date
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$lc" -- \
-    python3 "$R/bench.py" --config $CFG --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/bench_pmc_$lc.json" 2> "$OUT/pmc_$lc.err"
+    python3 "$R/bench.py" --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-traffic-pass > "$OUT/bench_pmc_$lc.json" 2> "$OUT/pmc_$lc.err"
   # keep the particle and field kernels only (torch's own fill kernels are noise)
   f=$(find "$OUT/pmc_$lc" -name '*counter_collection.csv' | head -n 1)
   (head -n 1 "$f"; grep -E 'k_step|k_push|k_deposit|k_field|k_charge|k_pred' "$f" || true) > "$OUT/bench_${CFG}_wholestep_pmc_$lc.csv"
