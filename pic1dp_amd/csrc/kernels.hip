@@ -1018,7 +1018,7 @@ template <int DIST, int MODE, int POW2>
 __device__ __forceinline__ double pred_one(const One &n, double p, int ix, double wl, const double *sAB, double *sP,
                                            const StepArgsDev &a) {
   const int nm = a.pred_nm, np1 = 1 + 2 * nm;
-  const double xh = n.x + a.dt_half * n.v;        // the next step's half push of x (:261)
+  const double xh = fma(a.dt_half, n.v, n.x);     // the next step's half push of x (:261), to rounding
   const double sh = xh * a.snx;                   // its cell, wrapped as an integer (:102-108 to rounding)
   const double fh = floor(sh);
   int ih = static_cast<int>(fh);
@@ -1059,10 +1059,7 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
     const double wlr = 1.0 - wl;
     for (int m = 0; m < nm; ++m) {
       const double2 tl = *reinterpret_cast<const double2 *>(gl + 2 * m), tr = *reinterpret_cast<const double2 *>(gr + 2 * m);
-      double A = tl.x * wl;
-      A = A + tr.x * wlr;
-      double B = tl.y * wl;
-      B = B + tr.y * wlr;
+      const double A = fma(tr.x, wlr, tl.x * wl), B = fma(tr.y, wlr, tl.y * wl);  // (contraction is fine here)
       const double cA = c * A, cB = c * B;
       lds_add(cl + 1 + m, wh * cA);
       lds_add(cr + 1 + m, wr * cA);
