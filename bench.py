@@ -47,7 +47,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import pic1dp_amd  # noqa: E402  (loads libpic1dp_hip.so first: one HIP runtime per process)
+pic1dp_amd = None   # imported by main() in a rank process only (it loads libpic1dp_hip.so): the launching parent of
+                    # `python bench.py --gpus N` never maps the HIP library and never touches a GPU
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 PRICED_BYTES_PER_UPDATE = 80.0  # what a store-and-reload push+gather sub-step would move
@@ -195,6 +196,11 @@ class Job:
                 else:
                     # every rank gets the same answer (pic1dp_amd/parallel.py); a communicator that
                     # comes up on some ranks only ends the job at the process group's timeout
+                    if rank == 0:
+                        sys.stderr.write("bench.py: %d ranks entering ncclCommInitRank; should it come up on some ranks "
+                                         "only, the others wait for the process group's 300 s timeout and the job ends "
+                                         "without a line\n" % world)
+                        sys.stderr.flush()
                     self.rccl_why = parallel.bootstrap_comm(self.eng, dist)
                 self.have_rccl = self.rccl_why is None
             if a.allreduce in ("auto", "p2p", "host"):   # "host": connected too, to be measured beside it
@@ -283,25 +289,36 @@ def measure_traffic(a, key):
         import summarize_pmc
     except ImportError as e:
         return None, "profiles/summarize_pmc.py: %s" % e
+    # the program after `--` must be the interpreter binary itself: a shim or a script would be an exec hop
+    # under the profiler's GPU-initialising preload
+    python = os.path.realpath(sys.executable)
+    try:
+        with open(python, "rb") as f:
+            if f.read(4) != b"\x7fELF":
+                return None, "%s is not an ELF binary (an exec hop under the profiler is not allowed)" % python
+    except OSError as e:
+        return None, "cannot read %s: %s" % (python, e)
     base = tempfile.mkdtemp(prefix="pic1dp_pmc_", dir="/tmp")
     vals = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(base, counter.lower())
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
-                   sys.executable, os.path.join(ROOT, "bench.py"), "--config", a.config, "--steps", "5", "--warmup", "1",
+                   python, os.path.join(ROOT, "bench.py"), "--config", a.config, "--steps", "5", "--warmup", "1",
                    "--no-cpu-baseline", "--no-strong", "--no-traffic-pass"]
-            if a.particles:
-                cmd += ["--particles", str(a.particles)]
-            if a.nx:
-                cmd += ["--nx", str(a.nx)]
+            # everything that shapes the launch (grid size -> flush atomics and staging bytes) goes to the child
+            for flag, val in (("--particles", a.particles), ("--nx", a.nx), ("--threads", a.threads),
+                              ("--blocks-per-cu", a.blocks_per_cu)):
+                if val:
+                    cmd += [flag, str(val)]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
                                    timeout=300)
             except (OSError, subprocess.TimeoutExpired) as e:
                 return None, "rocprofv3 --pmc %s pass: %s" % (counter, e)
             if r.returncode != 0:
-                return None, "rocprofv3 --pmc %s pass failed (exit %d)" % (counter, r.returncode)
+                tail = " | ".join((r.stderr or "").strip().splitlines()[-4:])
+                return None, "rocprofv3 --pmc %s pass failed (exit %d): %s" % (counter, r.returncode, tail[-600:])
             csvs = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if not csvs:
                 return None, "rocprofv3 --pmc %s pass wrote no counter file" % counter
@@ -314,18 +331,79 @@ def measure_traffic(a, key):
     return vals["FETCH_SIZE"] * 1024 * 2.0 + vals["WRITE_SIZE"] * 1024, None
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` started as ONE process (the form the driver uses for N = 1; the reference's one
+    launch line is `mpiexec -n $(NPE_RUN) ./pic1dp`, run/Makefile:41): start N fresh rank processes of this very
+    command -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run
+    would hand them -- wait, pass their output through (rank 0 prints the one JSON line) and return the worst exit
+    code.  This parent never loads the HIP library, never initialises a GPU and never replaces itself with another
+    program; a rank that fails is not started again, and when one fails the others get 20 s to follow before they
+    are terminated (exact PIDs)."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the one-hop exchange and RCCL need it
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), PIC1DP_BENCH_LAUNCHER="self")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0"),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout is the job's stdout (the other ranks print nothing there)
+    lines = 0
+    for ln in procs[0].stdout:
+        out = sys.stdout if ln.startswith("{") else sys.stderr     # anything a library printed there: not the line
+        out.write(ln)
+        out.flush()
+        lines += ln.startswith("{")
+    worst, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        codes = [p.poll() for p in procs]
+        if deadline is None and any(c not in (None, 0) for c in codes):
+            deadline = time.monotonic() + 20.0
+        if deadline is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.monotonic() + 10.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        time.sleep(0.05)
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c:
+            sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, c))
+            worst = max(worst, abs(c) if c > 0 else 128 - c)
+    if not worst and lines != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d JSON lines instead of one\n" % lines)
+        worst = 5
+    return min(worst, 255)
+
+
 def main():
     if os.environ.get("PIC1DP_BENCH_TRACE"):     # debugging aid: dump all stacks after N seconds and exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["PIC1DP_BENCH_TRACE"]), exit=True)
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))            # before anything of this process has touched the GPU
+    global pic1dp_amd
+    import pic1dp_amd       # loads libpic1dp_hip.so first: one HIP runtime per process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "(one process per GPU); WORLD_SIZE is 1" % a.gpus)
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size holds\n" % (a.gpus, world))
         a.gpus = world
 
     cfg = CONFIGS[a.config]
@@ -346,8 +424,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         # control plane only (barrier, max over ranks, id / handle exchange); the data path is
         # inside libpic1dp_hip.so, on the engine's stream
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=300))
+        # gloo's C++ side prints its "connected to N peer ranks" note on stdout: stdout is for the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=300))
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     # one GPU per rank; more ranks than visible GPUs (a rehearsal of the multi-rank
     # control flow on a one-GPU box: exchange or host-staged sum only) share the devices

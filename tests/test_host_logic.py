@@ -255,3 +255,34 @@ def test_product_never_touches_the_oracle(amd):
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.count("import oracle") == 1 and src.index("import oracle") > src.index("def cpu_baseline")
     assert src.index("import oracle") < src.index("def main")
+
+
+def test_bench_self_launch_starts_rank_processes(amd):
+    """`python bench.py --gpus 2` as ONE process (the driver's command form; the reference's launch line is
+    `mpiexec -n 4 ./pic1dp`, run/Makefile:41) starts its own rank processes and relays the worst exit code.
+    Without a GPU every rank fails loudly with NODEVICE (no CPU path) -- the launching parent itself must not
+    have loaded the HIP library: it only forks, waits and reports."""
+    import subprocess
+    import sys
+    if amd.device_count() > 0:
+        pytest.skip("a GPU is visible: the GPU suite runs the self-launched two-rank bench for real")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--particles", "1000", "--nx", "16", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "rank 0 exited with code" in r.stderr and "rank 1 exited with code" in r.stderr
+    assert "NODEVICE" in r.stderr
+
+
+def test_bench_launcher_parent_never_loads_the_hip_library():
+    """the module imports without pic1dp_amd (bench.py binds it inside main(), in a rank process only)"""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_import_only", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    before = set(sys.modules)
+    spec.loader.exec_module(mod)
+    assert mod.pic1dp_amd is None
+    assert not [m for m in set(sys.modules) - before if m.startswith(("pic1dp_amd", "torch"))]
