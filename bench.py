@@ -188,6 +188,7 @@ class Job:
         self.kind = "none (1 GPU)"
         self.rccl_why = self.p2p_why = None
         self.have_rccl = self.have_p2p = False
+        self.xchg_memkind = 0
         if world > 1:
             from pic1dp_amd import parallel
             if a.allreduce in ("auto", "rccl"):
@@ -205,6 +206,13 @@ class Job:
                 self.have_rccl = self.rccl_why is None
             if a.allreduce in ("auto", "p2p", "host"):   # "host": connected too, to be measured beside it
                 self.p2p_why = parallel.bootstrap_exchange(self.eng, dist)
+                if self.p2p_why is None:
+                    # plain (coarse-grained) device memory is not coherent across GPUs inside a kernel: a stale
+                    # slot would be summed silently.  The library only hands it out when PIC1DP_XCHG_MEM=3 asks for
+                    # it; a measurement does not take it on any rank
+                    self.xchg_memkind = self.eng.xchg_info()[0]
+                    if not parallel.agree(dist, self.xchg_memkind in (1, 2)):
+                        self.p2p_why = "the exchange area of some rank is plain device memory (memkind 3)"
                 self.have_p2p = self.p2p_why is None
             want = a.allreduce
             if want == "auto":
@@ -614,46 +622,47 @@ def main():
 
     if rank == 0:
         value = total * 2.0 * a.steps / elapsed
-        deltaf, linear = 1, 0                      # all configs of BASELINE.json are nonlinear delta-f
-        rd = 8.0 * (3 + deltaf)                    # x, v, p (+ w) read by either whole-step kernel
-        wr = 8.0 * (1 + (0 if linear else 1) + deltaf)  # x (+ v) (+ w) written by the second one
+        # what each marker kernel moves per marker and launch comes from the LIBRARY (pic1dp_hip_kernel_bytes: the
+        # instantiation it launched -- mode, carry on or off), not from constants here
+        names = {0: "k_push_fused", 1: "k_push", 2: "k_deposit", 3: "k_step_half", 4: "k_step_full", 6: "k_step_one"}
+        kb = {nm: eng.kernel_bytes(k) for k, nm in names.items()}
         half_ms, half_n = ktab["k_step_half"]
         full_ms, full_n = ktab["k_step_full"]
         one_ms, one_n = ktab["k_step_one"]
-        # k_step_one hands -f0'/f0 of the new velocity to the next step through memory (8 B written,
-        # 8 B read per marker) unless PIC1DP_CARRY=0
-        carry_b = 16.0 if (deltaf and phys.get("iptcldist", 3) in (2, 3) and os.environ.get("PIC1DP_CARRY", "1") != "0") else 0.0
-        if one_n and eng.predict_kind() == 2:
+        sums = bool(one_n) and eng.predict_kind() == 2
+        lazy = ", reached through the three reference call sites per sub-step (lazy call sites)" if a.unfused else ""
+        if sums:
+            dom = "k_step_one"
             kname = ("k_step_sums (one pass per step on a grid whose prediction tiles outgrow the LDS: recompute half-step "
                      "state, push+gather, wrap, deposit, store in place, and the six sums that predict the next step's "
                      "half-step field)")
-            kms, kn, kbytes = one_ms, one_n, rd + wr + carry_b
             path = ("one pass over the markers per step (k_step_sums; the next half-step field follows from six sums "
-                    "over the markers taken by the previous step's kernel)")
-            if a.unfused:
-                path += ", reached through the three reference call sites per sub-step (lazy call sites)"
+                    "over the markers taken by the previous step's kernel)" + lazy)
         elif one_n:
+            dom = "k_step_one"
             kname = ("k_step_one (one pass per step: recompute half-step state, push+gather, wrap, deposit, store in "
                      "place, and the deposits that predict the next step's first-sub-step charge)")
-            kms, kn, kbytes = one_ms, one_n, rd + wr + carry_b
             path = ("one pass over the markers per step (k_step_one; the first sub-step's charge is predicted by the "
-                    "previous step's kernel as coefficients of the kept field modes)")
-            if a.unfused:
-                path += ", reached through the three reference call sites per sub-step (lazy call sites)"
+                    "previous step's kernel as coefficients of the kept field modes)" + lazy)
         elif full_n:
+            dom = "k_step_full"
             kname = "k_step_full (2nd sub-step: recompute half-step state, push+gather, wrap, deposit, store in place)"
-            kms, kn, kbytes = full_ms, full_n, rd + wr
-            path = "whole-step kernels k_step_half + k_step_full (half-step state recomputed, not stored)"
-            if a.unfused:
-                path += ", reached through the three reference call sites per sub-step (lazy call sites)"
+            path = "whole-step kernels k_step_half + k_step_full (half-step state recomputed, not stored)" + lazy
         elif ktab["k_push"][1]:
-            kname, (kms, kn), kbytes = "k_push (separate gather+push)", ktab["k_push"], 68.0
+            dom = "k_push"
+            kname = "k_push (separate gather+push; the launch of the second sub-step is priced)"
             path = "separate push / deposit kernels (RK ping-pong sets)"
         else:
-            kname, (kms, kn), kbytes = "k_push<fused push+gather+deposit>", ktab["k_push_fused"], 68.0
+            dom = "k_push_fused"
+            kname = "k_push<fused push+gather+deposit> (the launch of the second sub-step is priced)"
             path = "two fused push+gather+deposit sub-steps (RK ping-pong sets: 56 / 80 B per marker)"
+        kms, kn = ktab[dom]
+        rd, wr, carry_b = kb[dom]["read"], kb[dom]["written"], kb[dom]["carry"]
+        kbytes, kcomp = rd + wr + carry_b, rd + wr
+        one_launch_is_a_step = dom == "k_step_one"
         avg_ms = kms / max(kn, 1)
         achieved = kbytes * np_local / (avg_ms * 1e-3) / 1e9 if kn else 0.0
+        achieved_compulsory = kcomp * np_local / (avg_ms * 1e-3) / 1e9 if kn else 0.0
         # HBM bytes per launch of that kernel: rocprofv3 --pmc passes of this command, committed under
         # profiles/ (a profile constant of the same workload, NOT measured in this run)
         traffic, traffic_src, traffic_why = None, None, None
@@ -686,18 +695,20 @@ def main():
                 pass
         # the box's own streaming rates (second denominator): plain copy and the
         # dominant kernel's traffic shape (4 arrays read, 3 written)
+        from pic1dp_amd import probe       # libpic1dp_probe.so: measurement code, not part of the product library
         probe_n = int(min(np_local, 10**8))
-        copy_gbs = max(eng.stream_probe(1, 1, probe_n, 10) for _ in range(3))
-        shape_gbs = max(eng.stream_probe(4, 3, probe_n, 10) for _ in range(3))
+        copy_gbs = max(probe.stream(1, 1, probe_n, 10, device=device) for _ in range(3))
+        shape_gbs = max(probe.stream(4, 3, probe_n, 10, device=device) for _ in range(3))
         # the same traffic in the layout the markers are stored in (x | v | w | p tiles, three written back in
         # place): what a kernel that did nothing but stream them would reach -- the denominator that does not
         # depend on where the allocator puts seven separate arrays
-        tiled_ms = min(eng.layout_probe(probe_n, 12, 10)[1] for _ in range(2))
+        tiled_ms = min(probe.layout(probe_n, 12, 10, device=device)[1] for _ in range(2))
         tiled_gbs = 56.0 * (probe_n // 4096 * 4096) / (tiled_ms * 1e-3) / 1e9
         # bytes the timed steps had to move: every launch of the three whole-step kernels at its own price
         step_bytes = None
         if full_n or one_n:
-            step_bytes = (half_n * rd + full_n * (rd + wr) + one_n * (rd + wr + carry_b)) * np_local / a.steps
+            step_bytes = sum(ktab[nm][1] * (kb[nm]["read"] + kb[nm]["written"] + kb[nm]["carry"])
+                             for nm in ("k_step_half", "k_step_full", "k_step_one")) * np_local / a.steps
         out = {
             "metric": "particle-updates/sec", "value": value, "unit": "updates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "warmup_effective": a.warmup + settle,
@@ -714,6 +725,7 @@ def main():
                 "parallelism": "particle shard x%d, replicated grid, charge vector summed over GPUs once per "
                                "sub-step" % world,
                 "path": path, "allreduce": headline_kind, "rccl_ranks": world if headline_kind == "rccl" else 0,
+                "exchange_memkind": {0: None, 1: "fine-grained", 2: "uncached", 3: "plain"}[job.xchg_memkind],
                 "marker_layout": "x, v, w, p interleaved in 32 KiB tiles in one slab per species",
                 "kernel_launches_in_timed_steps": {("k_step_sums" if k == "k_step_one" and eng.predict_kind() == 2 else k): v[1]
                                                    for k, v in ktab.items() if v[1]},
@@ -723,18 +735,27 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kname, "avg_launch_ms": avg_ms, "launches": kn,
-                "bytes_per_marker": kbytes, "bytes_per_marker_note":
-                    "traffic THIS kernel has to move: %g B read (x, v, w, p) + %g B written (x, v, w)%s"
-                    % (rd, wr, (" + %g B carry of -f0'/f0 (8 read, 8 written); one launch = one whole time step "
-                                "(two particle-updates) per marker" % carry_b) if one_n else
-                       "; one launch = one particle-update per marker"),
-                "updates_per_launch": np_local * (2 if one_n else 1),
+                "bytes_per_marker": kbytes, "bytes_per_marker_source":
+                    "pic1dp_hip_kernel_bytes: the library reports what the instantiation it launched moves (%s)"
+                    % kb[dom]["name"],
+                "bytes_per_marker_note":
+                    "traffic THIS kernel moves: %g B read (x, v, p%s) + %g B written + %g B carry of -f0'/f0 (traffic the "
+                    "kernel chooses to spend instead of evaluating it again)%s"
+                    % (rd, ", w" if rd > 24.0 else "", wr, carry_b,
+                       "; one launch = one whole time step (two particle-updates) per marker" if one_launch_is_a_step
+                       else "; one launch = one particle-update per marker"),
+                # the same launch priced on the strictly compulsory bytes only (no carry): 0.73 on 72 B flatters a kernel
+                # that spends 16 of them by choice
+                "bytes_compulsory": kcomp, "achieved_compulsory": achieved_compulsory,
+                "frac_compulsory": achieved_compulsory / HBM_PEAK_GBS,
+                "updates_per_launch": np_local * (2 if one_launch_is_a_step else 1),
                 "step_half_kernel_avg_ms": half_ms / half_n if half_n else None,
-                "step_half_kernel_GBs": (rd * np_local / (half_ms / half_n * 1e-3) / 1e9) if half_n else None,
+                "step_half_kernel_GBs": ((kb["k_step_half"]["read"] + kb["k_step_half"]["carry"]) * np_local
+                                         / (half_ms / half_n * 1e-3) / 1e9) if half_n else None,
                 "whole_step_bytes": step_bytes,
                 "whole_step_GBs": (step_bytes / (elapsed / a.steps) / 1e9) if step_bytes else None,
                 "whole_step_frac": (step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS) if step_bytes else None,
-                "reference_priced_GBs": PRICED_BYTES_PER_UPDATE * np_local * (2 if one_n else 1) / (avg_ms * 1e-3) / 1e9
+                "reference_priced_GBs": PRICED_BYTES_PER_UPDATE * np_local * (2 if one_launch_is_a_step else 1) / (avg_ms * 1e-3) / 1e9
                                         if kn else None,
                 "reference_priced_note": "SURVEY 8(d) prices a push+gather sub-step that stores and reloads the RK "
                                          "state at 80 B per update (160 B per marker and step); this design moves %g B per "
@@ -744,6 +765,7 @@ def main():
                 "frac_of_measured_4read_3write": achieved / shape_gbs if shape_gbs else None,
                 "measured_tiled_4read_3write_GBs": tiled_gbs,
                 "frac_of_measured_tiled_stream": achieved / tiled_gbs if tiled_gbs else None,
+                "measured_tiled_note": "a pure stream of 56 B per marker (4 tiles read, 3 written back in place)",
                 "traffic_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and kn) else None,
             },
             "attribution": attr,

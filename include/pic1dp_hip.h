@@ -177,20 +177,6 @@ int pic1dp_hip_host_multirand_int64(int32_t al_int, int32_t seed_type, int32_t m
                                     int32_t warmup, int32_t selftest, int64_t *out,
                                     int64_t n);
 
-/* self-check of the kernels' division by the constant lx (reciprocal + two FMA
- * corrections, see kernels.hip div_lx) against the IEEE quotient on n generated
- * positions (uniform, cell boundaries +- a few ulp, wide exponent range):
- * *mismatches counts results differing in any bit.  host_: same algorithm with
- * the host's fma(); debug_: on the device, against the hardware division. */
-int pic1dp_hip_host_div_check(double lx, int32_t nx, int64_t n, uint64_t seed,
-                              int64_t *mismatches);
-/* the same for the division by a species constant (m, T, T/m, T2/m, 2T/m, 2T2/m,
- * sqrt(T/m), sqrt(T2/m); kernels.hip div_const), used when the constants are not
- * all powers of two: n generated dividends (random significands, edge patterns,
- * exponents in [-300, 300]) against the IEEE quotient. */
-int pic1dp_hip_host_divc_check(double divisor, int64_t n, uint64_t seed,
-                               int64_t *mismatches);
-
 /* ---- life cycle -------------------------------------------------------
  * create  <-> input_init + particle_init + field_init
  *             (src/pic1dp.F90:57-59; src/pic1dp_particle.F90:66-139;
@@ -369,36 +355,6 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *ctx, int32_t ispecies, int32_t finish,
                         double *markr_xv, double *total_xv, double *pertb_xv,
                         double *markr_v, double *total_v, double *pertb_v);
 
-int pic1dp_hip_debug_div_check(pic1dp_ctx *ctx, int64_t n, uint64_t seed,
-                               int64_t *mismatches);
-/* device-side check of div_const on all eight divisor constants of a species,
- * n dividends each */
-int pic1dp_hip_debug_divc_check(pic1dp_ctx *ctx, int32_t ispecies, int64_t n,
-                                uint64_t seed, int64_t *mismatches);
-/* measured streaming bandwidth of this GPU with the particle kernels' access
- * pattern (16 B per lane, grid-stride, the context's launch shape): nread
- * (1, 4 or 7) arrays of n doubles read and nwrite (0, 1 or 3) written per pass,
- * reps passes timed with HIP events; result in GB/s.  (4,0), (4,3) and (7,3)
- * are the traffic shapes of k_step_half, k_step_full and the fused sub-step 2;
- * (1,1) is a plain copy.  Gives the "achievable" denominator beside the 8 TB/s
- * nominal peak. */
-int pic1dp_hip_stream_probe(pic1dp_ctx *ctx, int32_t nread, int32_t nwrite, int64_t n,
-                            int32_t reps, double *gbytes_per_s);
-
-/* y[i] = exp(x[i]), i < n, evaluated on the device by the function the push
- * kernels call for the weight equation (src/pic1dp_interaction.F90:278-321): lets a
- * test bound it against the host's libm (host arrays in and out) */
-int pic1dp_hip_debug_exp(pic1dp_ctx *ctx, const double *x, double *y, int64_t n);
-/* tuning only (tools/layout_probe.py): the traffic shapes of the two whole-step kernels
- * (4 arrays of n doubles read; 3 of them written back in place, or nothing written) timed
- * over a fresh slab: ms[0] arrays apart, read+write; ms[1] interleaved in tiles of
- * 2^log2_tile markers, read+write; ms[2], ms[3] the same two read-only; ms[4], ms[5] tiled
- * with one workgroup walking whole tiles, read+write and read-only.  keep != 0 leaves the
- * slab allocated until destroy (the next call then lands in other physical memory) */
-int pic1dp_hip_debug_layout_probe(pic1dp_ctx *ctx, int64_t n, int32_t log2_tile,
-                                  int64_t stagger_bytes, int32_t reps, int32_t keep,
-                                  double ms[6]);
-
 /* ---- split-phase deposit for a host that owns the reduction (MPI) ------
  * charge_local: everything of collect_charge up to the all-reduce
  *   (src/pic1dp_interaction.F90:81-128) -> this rank's charge2[nx] on the host
@@ -472,6 +428,16 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);
+/* what the marker kernel launched last under `which` (numbering of kernel_stats; not 5)
+ * moves per marker and launch, in bytes: read_bytes (x, v, p (+ w); the RK base as well
+ * for the second sub-step's k_push) and written_bytes (x (+ v) (+ w)) are compulsory for
+ * its data flow; carry_bytes is the traffic the kernel CHOOSES to spend on handing
+ * -f0'/f0 to the next launch instead of evaluating it again (k_step_one: 8 read + 8
+ * written; 0 when it recomputes).  name: the kernel (k_step_one / k_step_sums / ...) and
+ * the form of -f0'/f0 it was instantiated with.  bench.py prices its roofline on these. */
+int pic1dp_hip_kernel_bytes(pic1dp_ctx *ctx, int32_t which, double *read_bytes,
+                            double *written_bytes, double *carry_bytes, char *name,
+                            int32_t name_len);
 
 #ifdef __cplusplus
 }

@@ -158,6 +158,7 @@ def lib():
         "orc_field_new": (P, [IN]),
         "orc_field_free": (None, [P]),
         "orc_field_solve": (None, [IN, P, _dp, _dp, _dp, _dp]),
+        "orc_field_solve_ranks": (None, [IN, P, C.c_int, _dp, _dp, _dp, _dp]),
         "orc_field_energy": (C.c_double, [IN, _dp]),
         "orc_field_solve_fd": (None, [IN, _dp, _dp]),
         "orc_energy_sums": (None, [C.c_int64, _dp, _dp, _dp, C.c_int, _dp]),
@@ -292,12 +293,13 @@ class Field:
             lib().orc_field_free(self.f)
             self.f = None
 
-    def solve(self, rho):
+    def solve(self, rho, npe=1):
+        """field_solve_electric in the summation order of an npe-rank reference run (1: SeqAIJ)"""
         nx, nm = self.inp.nx, self.inp.nmode
         E = np.empty(nx)
         re = np.empty(nm)
         im = np.empty(nm)
-        lib().orc_field_solve(C.byref(self.inp), self.f, np.ascontiguousarray(rho, dtype=np.float64), E, re, im)
+        lib().orc_field_solve_ranks(C.byref(self.inp), self.f, npe, np.ascontiguousarray(rho, dtype=np.float64), E, re, im)
         return E, re, im
 
 

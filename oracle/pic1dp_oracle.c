@@ -625,22 +625,60 @@ void orc_field_free(orc_field *f) {
   free(f);
 }
 
-/* field_solve_electric, :231-257, one-rank PETSc SeqAIJ summation order:
- * MatMultTranspose accumulates y[col] += a(row,col)*x[row] over ascending
- * rows; MatMult / MatMultAdd sum a row's entries in ascending column order;
- * VecScale multiplies by the scalar (here a pre-formed reciprocal). */
-void orc_field_solve(const orc_input *in, const orc_field *f,
-                     const double *rho, double *E, double *mode_re,
-                     double *mode_im) {
+/* field_solve_electric, :231-257, in PETSc's summation order.
+ * One rank (SeqAIJ): MatMultTranspose accumulates y[col] += a(row,col)*x[row] over
+ * ascending rows; MatMult / MatMultAdd sum a row's entries in ascending column
+ * order; VecScale multiplies by the scalar (here a pre-formed reciprocal).
+ * npe ranks (MPI-AIJ; the operators are created with PETSC_DECIDE row blocks,
+ * src/pic1dp_global.F90:96-133, and the reference is run as mpiexec -n 4,
+ * run/Makefile:41): MatMultTranspose_MPIAIJ forms every rank's contribution from
+ * its own rows -- ascending, from zero, exactly the loop above restricted to the
+ * rank's block of n/npe + (rank < n%npe) rows -- and a reverse VecScatter with
+ * ADD_VALUES adds the contributions into the owner's entry, which already holds
+ * the owner's own.  The owner of mode entry m follows from the PETSC_DECIDE split
+ * of the nmode entries (src/pic1dp_field.F90:86-88); the order in which the
+ * received contributions are added is the scatter's (message completion): stated
+ * here as the canonical one -- the owner's own block first, then the other ranks
+ * in rank order, which for mode entry 0 (the one kept mode of the default input,
+ * owned by rank 0) is plain rank order.  The inverse (MatMult, MatMultAdd: <= 2 nmode
+ * terms per row) keeps the one-rank order; under MPI-AIJ a row adds its rank's own
+ * columns first, which is the same sum for nmode = 1. */
+void orc_field_solve_ranks(const orc_input *in, const orc_field *f, int npe,
+                           const double *rho, double *E, double *mode_re,
+                           double *mode_im) {
   const int nx = f->nx, nm = f->nmode;
   const double dnx = (double)in->nx;
   const double sc_im = -1.0 / dnx, sc_re = 1.0 / dnx;
-  for (int im = 0; im < nm; im++) mode_im[im] = mode_re[im] = 0.0;
-  for (int ix = 0; ix < nx; ix++)
-    for (int im = 0; im < nm; im++) {
-      mode_im[im] += f->fourier_re[(size_t)ix * nm + im] * rho[ix]; /* :231 */
-      mode_re[im] += f->fourier_im[(size_t)ix * nm + im] * rho[ix]; /* :236 */
+  if (npe < 1) npe = 1;
+  for (int im = 0; im < nm; im++) {
+    int owner = 0; /* PETSC_DECIDE split of the nmode entries (src/pic1dp_field.F90:86-88): whose block holds im */
+    for (int64_t first = 0; owner < npe - 1; owner++) {
+      first += orc_local_size(nm, owner, npe);
+      if (im < first) break;
     }
+    double tot_im = 0.0, tot_re = 0.0;
+    for (int k = 0; k < npe; k++) {
+      /* the owner's own rows first, then ranks 0, 1, ... (skipping the owner) */
+      const int r = k == 0 ? owner : (k <= owner ? k - 1 : k);
+      int64_t lo = 0;
+      for (int q = 0; q < r; q++) lo += orc_local_size(nx, q, npe);
+      const int64_t hi = lo + orc_local_size(nx, r, npe);
+      double p_im = 0.0, p_re = 0.0;
+      for (int64_t ix = lo; ix < hi; ix++) {
+        p_im += f->fourier_re[(size_t)ix * nm + im] * rho[ix]; /* :231 */
+        p_re += f->fourier_im[(size_t)ix * nm + im] * rho[ix]; /* :236 */
+      }
+      if (k == 0) {
+        tot_im = p_im;
+        tot_re = p_re;
+      } else {
+        tot_im += p_im;
+        tot_re += p_re;
+      }
+    }
+    mode_im[im] = tot_im;
+    mode_re[im] = tot_re;
+  }
   for (int im = 0; im < nm; im++) {
     mode_im[im] = mode_im[im] * sc_im;          /* :234 */
     mode_re[im] = mode_re[im] * sc_re;          /* :239 */
@@ -655,6 +693,13 @@ void orc_field_solve(const orc_input *in, const orc_field *f,
       s += f->fourier_im[(size_t)ix * nm + im] * mode_im[im];
     E[ix] = s * 2.0; /* :256 */
   }
+}
+
+/* the one-rank run (SeqAIJ): one block, ascending rows */
+void orc_field_solve(const orc_input *in, const orc_field *f,
+                     const double *rho, double *E, double *mode_re,
+                     double *mode_im) {
+  orc_field_solve_ranks(in, f, 1, rho, E, mode_re, mode_im);
 }
 
 /* CPU statement of the engine's OPT-IN finite-difference solver (NOT part of
@@ -1109,7 +1154,7 @@ void orc_sim_collect_charge(orc_sim *s) {
 }
 
 void orc_sim_solve_field(orc_sim *s) {
-  orc_field_solve(&s->in, s->fld, s->chargeden, s->E, s->mode_re, s->mode_im);
+  orc_field_solve_ranks(&s->in, s->fld, s->npe, s->chargeden, s->E, s->mode_re, s->mode_im);
 }
 
 /* interaction_push_particle, src/pic1dp_interaction.F90:161-370 */

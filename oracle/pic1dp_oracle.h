@@ -153,6 +153,12 @@ void orc_field_free(orc_field *f);
 void orc_field_solve(const orc_input *in, const orc_field *f,
                      const double *chargeden, double *E, double *mode_re,
                      double *mode_im);
+/* the same with the forward sums in the order of an npe-rank run (MPI-AIJ:
+ * every rank's row block summed from zero, the blocks added owner first, then in
+ * rank order); npe = 1 is orc_field_solve */
+void orc_field_solve_ranks(const orc_input *in, const orc_field *f, int npe,
+                           const double *chargeden, double *E, double *mode_re,
+                           double *mode_im);
 /* the engine's opt-in finite-difference solver (not in the reference) */
 void orc_field_solve_fd(const orc_input *in, const double *rho, double *E);
 /* int E^2 dx as output_field does (src/pic1dp_output.F90:120-124) */

@@ -82,13 +82,6 @@ SIGNATURES = {
                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "pic1dp_hip_host_particle_load": [_INP, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64],
     "pic1dp_hip_host_multirand_int64": [C.c_int32] * 5 + [_P, C.c_int64],
-    "pic1dp_hip_host_div_check": [C.c_double, C.c_int32, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
-    "pic1dp_hip_debug_div_check": [_P, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
-    "pic1dp_hip_host_divc_check": [C.c_double, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
-    "pic1dp_hip_debug_divc_check": [_P, C.c_int32, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)],
-    "pic1dp_hip_stream_probe": [_P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _D],
-    "pic1dp_hip_debug_exp": [_P, _P, _P, C.c_int64],
-    "pic1dp_hip_debug_layout_probe": [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _D],
     "pic1dp_hip_create": [_INP, C.POINTER(Layout), C.POINTER(_P)],
     "pic1dp_hip_destroy": [_P],
     "pic1dp_hip_local_sizes": [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
@@ -138,6 +131,7 @@ SIGNATURES = {
     "pic1dp_hip_get_stream": [_P, C.POINTER(_P)],
     "pic1dp_hip_kernel_stats": [_P, C.c_int32, _D, C.POINTER(C.c_int64)],
     "pic1dp_hip_kernel_stats_enable": [_P, C.c_int32],
+    "pic1dp_hip_kernel_bytes": [_P, C.c_int32, _D, _D, _D, C.c_char_p, C.c_int32],
 }
 
 _lib = None

@@ -1,12 +1,17 @@
-"""Build the gfx950 shared library libpic1dp_hip.so in-tree with hipcc.
+"""Build the gfx950 shared libraries in-tree with hipcc.
 
     python pic1dp_amd/build.py [--force]      (run as a script: importing the
                                                package needs the built library)
 
-hipcc cross-compiles for gfx950 without a GPU.  The library is the whole
-product: HIP kernels + C ABI + native host loader.  It is git-ignored but
-travels to the GPU box with gpurun.
+hipcc cross-compiles for gfx950 without a GPU.  lib/libpic1dp_hip.so is the whole
+product: HIP kernels + C ABI + native host loader; lib/libpic1dp_probe.so holds the
+measurement / test-support kernels (include/pic1dp_probe.h), built from the same
+device headers.  Both are git-ignored but travel to the GPU box with gpurun.
+
+The translation units are compiled in parallel (objects under csrc/build/);
+kernels_step.hip once per distribution (-DPIC1DP_STEP_DIST=0..5).
 """
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -14,19 +19,29 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpic1dp_hip.so")
-SOURCES = ["kernels.hip", "capi.cpp", "loader.cpp", "multirand.cpp", "optimize.cpp"]
-HEADERS = ["kernels.hpp", "loader.hpp", "multirand.hpp", "optimize.hpp", "rccl_dyn.hpp",
-           os.path.join("..", "..", "include", "pic1dp_hip.h")]
+PROBE_LIB = os.path.join(LIBDIR, "libpic1dp_probe.so")
+STEP_DISTS = (0, 1, 2, 3, 4, 5)
+# (source, extra flags, object stem)
+PRODUCT_UNITS = [("kernels_step.hip", ["-DPIC1DP_STEP_DIST=%d" % d], "kernels_step_d%d" % d) for d in STEP_DISTS] + [
+    ("kernels_push.hip", [], "kernels_push"), ("kernels_field.hip", [], "kernels_field"),
+    ("kernels_diag.hip", [], "kernels_diag"), ("step_dispatch.cpp", [], "step_dispatch"),
+    ("capi.cpp", [], "capi"), ("loader.cpp", [], "loader"), ("multirand.cpp", [], "multirand"),
+    ("optimize.cpp", [], "optimize"), ("species.cpp", [], "species"), ("hostcheck.cpp", [], "hostcheck")]
+PROBE_UNITS = [("probe.hip", [], "probe")]
+PROBE_SHARED = ["species", "hostcheck"]      # objects of the product the probe library links as well
+HEADERS = ["kernels.hpp", "device_math.hpp", "device_diag.hpp", "step_args.hpp", "check_values.hpp", "loader.hpp",
+           "multirand.hpp", "optimize.hpp", "rccl_dyn.hpp",
+           os.path.join("..", "..", "include", "pic1dp_hip.h"), os.path.join("..", "..", "include", "pic1dp_probe.h")]
 
 # -ffp-contract=off : products and sums round separately, like the reference's
 #                     plain -O3 x86-64 build (no FMA) -- needed for bit-exact
 #                     positions / cell indices
 # -munsafe-fp-atomics: native ds_add_f64 / global_atomic_add_f64, no CAS loops
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-result",
-         "-x", "hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
+         "-Wall", "-Wno-unused-result", "-x", "hip"]
 
 
 def hipcc():
@@ -37,11 +52,23 @@ def hipcc():
 
 
 def stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    for lib in (LIB, PROBE_LIB):
+        if not os.path.exists(lib):
+            return True
+    t = min(os.path.getmtime(LIB), os.path.getmtime(PROBE_LIB))
+    srcs = sorted({u[0] for u in PRODUCT_UNITS + PROBE_UNITS})
+    deps = [os.path.join(CSRC, f) for f in srcs + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(cc, unit, extra, objdir, verbose):
+    src, flags, stem = unit
+    obj = os.path.join(objdir, stem + ".o")
+    cmd = [cc] + FLAGS + extra + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return obj
 
 
 def build(force=False, verbose=False):
@@ -49,16 +76,31 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     # tuning builds: PIC1DP_EXTRA_FLAGS="-DPIC1DP_NT=0" PIC1DP_LIB_OUT=/path/variant.so
-    # (load one with PIC1DP_LIB=/path/variant.so)
+    # (load one with PIC1DP_LIB=/path/variant.so); their objects go to a directory of their own
     out = os.environ.get("PIC1DP_LIB_OUT") or LIB
     extra = os.environ.get("PIC1DP_EXTRA_FLAGS", "").split()
-    tmp = out + ".tmp.%d" % os.getpid()
-    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + [
-        "-o", tmp, "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
-    os.replace(tmp, out)
+    variant = out != LIB
+    objdir = OBJDIR if not variant else OBJDIR + "." + os.path.basename(out)
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    units = PRODUCT_UNITS + ([] if variant else PROBE_UNITS)
+    jobs = int(os.environ.get("PIC1DP_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(lambda u: _compile(cc, u, extra, objdir, verbose), units))
+    by_stem = {u[2]: o for u, o in zip(units, objs)}
+
+    def link(target, stems):
+        tmp = target + ".tmp.%d" % os.getpid()
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [by_stem[s] for s in stems] + [
+            "-o", tmp, "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, target)
+
+    link(out, [u[2] for u in PRODUCT_UNITS])
+    if not variant:
+        link(PROBE_LIB, [u[2] for u in PROBE_UNITS] + PROBE_SHARED)
     return out
 
 

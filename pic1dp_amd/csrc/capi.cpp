@@ -54,15 +54,11 @@ constexpr double kSqrtEps = 1.490116119384766e-08;       // PETSC_SQRT_MACHINE_E
 constexpr int kTagFused = 100, kTagPush = 101, kTagDeposit = 102, kTagStepHalf = 103, kTagStepFull = 104, kTagStepOne = 106,
               kNumTags = 128;
 constexpr int64_t kHistCap = 1 << 20;
+constexpr bool kCarryOneExpDefault = false;  // k_step_one with the one-exp form of -f0'/f0: carry it (72 B) or evaluate it again (56 B)
 constexpr int kEnergyBlocks = 1024;
+constexpr size_t kCuLds = 160 * 1024, kStaticLds = 1024;  // LDS of a CU; static LDS of a marker kernel (the exp table)
 // states of the lazy call sites (pic1dp_ctx::lz)
 enum { LZ_CLEAN = 0, LZ_PUSH1, LZ_HALF, LZ_PUSH2 };
-
-bool is_pow2(double c) {
-  if (!(c > 0.0) || !std::isfinite(c)) return false;
-  int e;
-  return std::frexp(c, &e) == 0.5;
-}
 
 struct Species {
   int64_t nalloc = 0, np = 0;
@@ -131,8 +127,8 @@ struct pic1dp_ctx {
   int lz = 0;                    // LZ_CLEAN / LZ_PUSH1 / LZ_HALF / LZ_PUSH2
   double *d_E0 = nullptr;        // field the noted push(1) saw
   double *d_rho_dummy = nullptr; // accumulator of a wrap-only deposit
-  std::vector<double *> probe_keep;  // slabs a layout probe was asked to leave allocated
-  int carry = 1;           // whole-step kernels may carry -f0'/f0 between them (PIC1DP_CARRY=0: never)
+  int carry = -1;          // whole-step kernels carry -f0'/f0 between them: -1 where measured to pay, 0 never
+                           // (PIC1DP_CARRY=0), 1 wherever -f0'/f0 bears an exp, 2 also two-stream2 between k_step_half / _full
   int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
   int field_solver = 0;    // 0 the reference's mode-filter DFT solve, 1 finite-difference tridiagonal (opt-in)
   // marker state (bytes) above which k_step_half / k_step_full stream non-temporally
@@ -186,6 +182,11 @@ struct pic1dp_ctx {
   size_t ev_used = 0;
   double acc_ms[kNumTags] = {0};
   int64_t acc_n[kNumTags] = {0};
+  // what the marker kernel launched last under a tag moves per marker (pic1dp_hip_kernel_bytes)
+  struct KernelBytes {
+    double rd = 0.0, wr = 0.0, carry = 0.0;
+    char name[64] = {0};
+  } kbytes[kNumTags];
 };
 
 namespace {
@@ -240,8 +241,7 @@ LaunchCfg particle_launch(const pic1dp_ctx *c, int64_t np, bool with_E, bool wit
   LaunchCfg lc{};
   lc.lds = sizeof(double) * ((with_E ? static_cast<size_t>((nx + 2) & ~1) : 0) +
                              (with_rho ? static_cast<size_t>(nx) * c->grid.rcopies + 1 : 0));  // + guard cell
-  const size_t lds_cap = PARTICLE_LDS_CAP;
-  int by_lds = lc.lds ? static_cast<int>(lds_cap / lc.lds) : 8;
+  int by_lds = lc.lds ? static_cast<int>(kCuLds / (lc.lds + kStaticLds)) : 8;
   if (by_lds < 1) by_lds = 1;
   int threads = c->threads_req > 0 ? c->threads_req : 512;
   if (c->threads_req <= 0 && by_lds * threads < 2048) threads = 1024;
@@ -256,52 +256,6 @@ LaunchCfg particle_launch(const pic1dp_ctx *c, int64_t np, bool with_E, bool wit
   lc.threads = threads;
   lc.blocks = static_cast<int>(blocks);
   return lc;
-}
-
-SpeciesConst make_species_const(const pic1dp_input &in, int s) {
-  SpeciesConst c{};
-  const double T = in.species_temperature[s], T2 = in.species_temperature2[s];
-  c.Z = in.species_charge[s];
-  c.m = in.species_mass[s];
-  c.den = in.species_density[s];
-  c.beam = 1.0 - c.den;
-  c.v0 = in.species_v0[s];
-  c.T = T;
-  c.tm = T / c.m;
-  c.tm2 = T2 / c.m;
-  c.two_tm = 2.0 * T / c.m;
-  c.two_tm2 = 2.0 * T2 / c.m;
-  c.stm = std::sqrt(c.tm);
-  c.stm2 = std::sqrt(c.tm2);
-  c.r_m = 1.0 / c.m;
-  c.r_T = 1.0 / T;
-  c.r_tm = 1.0 / c.tm;
-  c.r_tm2 = 1.0 / c.tm2;
-  c.r_two_tm = 1.0 / c.two_tm;
-  c.r_two_tm2 = 1.0 / c.two_tm2;
-  c.r_stm = 1.0 / c.stm;
-  c.r_stm2 = 1.0 / c.stm2;
-  c.pow2 = is_pow2(c.m) && is_pow2(T) && is_pow2(c.tm) && is_pow2(c.tm2) && is_pow2(c.two_tm) &&
-           is_pow2(c.two_tm2) && is_pow2(c.stm) && is_pow2(c.stm2);
-  c.unit = c.m == 1.0 && T == 1.0 && T2 == 1.0 && c.tm == 1.0 && c.tm2 == 1.0 && c.stm == 1.0 &&
-           c.stm2 == 1.0 && c.two_tm == 2.0 && c.two_tm2 == 2.0;
-  if (const char *e = std::getenv("PIC1DP_UNIT_SPECIALISATION")) c.unit = c.unit && std::atoi(e) != 0;
-  // general divisors: a/c through div_const (kernels.hip) if every one of the
-  // eight is in a sane range and a randomised host comparison with the true
-  // quotient finds no difference (the theorem behind it holds for every finite
-  // c; this guards the implementation, not the mathematics)
-  c.fastc = 0;
-  if (!c.pow2) {
-    const double divisors[8] = {c.m, T, c.tm, c.tm2, c.two_tm, c.two_tm2, c.stm, c.stm2};
-    bool ok = true;
-    for (double d : divisors) {
-      const double ad = std::fabs(d);
-      ok = ok && ad > 0x1p-200 && ad < 0x1p+200 && host_divc_check(d, 0x5EEDull + static_cast<uint64_t>(s), 50000) == 0;
-    }
-    c.fastc = ok ? 1 : 0;
-  }
-  if (const char *e = std::getenv("PIC1DP_FAST_DIVC")) c.fastc = c.fastc && std::atoi(e) != 0;
-  return c;
 }
 
 int validate(const pic1dp_input &in, const pic1dp_layout &lay) {
@@ -439,6 +393,14 @@ int enqueue_push(pic1dp_ctx *c, int irk, bool fused, const double *E = nullptr) 
     PushArgs a = make_push_args(c, s, irk, E);
     if (a.np <= 0) continue;
     LaunchCfg lc = particle_launch(c, a.np, true, fused);
+    {  // irk 1 reads x, v, p (+ w); irk 2 also the RK base x (+ v) (+ w); both write x (+ v) (+ w)
+      pic1dp_ctx::KernelBytes &kb = c->kbytes[fused ? kTagFused : kTagPush];
+      const double pushed = 8.0 * (1 + (c->in.linear ? 0 : 1) + (c->in.deltaf ? 1 : 0));
+      kb.rd = 8.0 * (3 + (c->in.deltaf ? 1 : 0)) + (irk == 2 ? pushed : 0.0);
+      kb.wr = pushed;
+      kb.carry = 0.0;
+      std::snprintf(kb.name, sizeof kb.name, "%s", fused ? "k_push<FUSED>" : "k_push");
+    }
     Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
     Span ks(c, fused ? kTagFused : kTagPush, c->stats_on);
     HIP_TRY(launch_push(a, fused, lc, c->st));
@@ -457,6 +419,11 @@ int enqueue_deposit(pic1dp_ctx *c) {
     double *x = S.set[c->cur].x;
     const double *q = c->in.deltaf ? S.set[c->cur].w : S.p;  // :84-91
     LaunchCfg lc = particle_launch(c, S.np, false, true);
+    {
+      pic1dp_ctx::KernelBytes &kb = c->kbytes[kTagDeposit];
+      kb.rd = 16.0, kb.wr = 8.0, kb.carry = 0.0;  // x, q read; wrapped x written
+      std::snprintf(kb.name, sizeof kb.name, "k_deposit");
+    }
     Span ks(c, kTagDeposit, c->stats_on);
     HIP_TRY(launch_deposit(x, q, S.rho, S.np, c->grid, lc, c->st));
     if (int rc = ks.end()) return rc;
@@ -604,12 +571,6 @@ int pic1dp_hip_host_multirand_int64(int32_t al_int, int32_t seed_type, int32_t m
   return 0;
 }
 
-int pic1dp_hip_host_div_check(double lx, int32_t nx, int64_t n, uint64_t seed, int64_t *mismatches) {
-  if (!mismatches || !(lx > 0.0) || nx < 1 || n < 0) return fail(PIC1DP_ERR_ARG, "bad argument");
-  *mismatches = host_div_check(lx, nx, seed, n);
-  return 0;
-}
-
 static bool step_recompute_ok(const pic1dp_ctx *c);
 static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag = false,
                           bool pred = false);
@@ -723,7 +684,9 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     S.nalloc = nalloc;
     S.np = 0;
     for (int b = 0; b < c->nblk; ++b) S.np += block_np(*in, s, c->blk0 + b, npe);
-    S.sc = make_species_const(*in, s);
+    S.sc = make_species_const(SpeciesInput{in->iptcldist, in->species_charge[s], in->species_mass[s],
+                                           in->species_temperature[s], in->species_temperature2[s],
+                                           in->species_density[s], in->species_v0[s]}, s);
     S.rho = c->d_rho_sp + static_cast<size_t>(s) * nx;
     // x, v, w, p of a species interleaved in tiles in ONE slab (kernels.hpp: 32 B per
     // marker, 9e9 markers in 288 GB); the slab of the RK ping-pong set is allocated on
@@ -747,7 +710,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMalloc(&c->d_E0, sizeof(double) * nx));
   HIP_TRY_C(hipMalloc(&c->d_rho_dummy, sizeof(double) * rho_doubles));
   if (const char *e = std::getenv("PIC1DP_LAZY_CALLS")) c->lazy_calls = std::atoi(e) != 0;
-  if (const char *e = std::getenv("PIC1DP_CARRY")) c->carry = std::atoi(e);
+  if (const char *e = std::getenv("PIC1DP_CARRY")) c->carry = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("PIC1DP_PREDICT")) c->predict = std::atoi(e);
   HIP_TRY_C(hipMalloc(&c->d_mode_re, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_mode_im, sizeof(double) * nm));
@@ -783,11 +746,12 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     // grids with one kept mode (k_step_sums); PIC1DP_PRED_KIND=1|2 insists on one of them (tests)
     if (nm <= PRED_MAX_MODES && step_one_lds_bytes(nx, c->grid.rcopies, nm) <= PARTICLE_LDS_CAP)
       c->pred_kind = 1;
-    else if (nm == 1 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP)
+    // (the six sums travel in the head of an nx-vector on the call-site path: nx >= 8)
+    else if (nm == 1 && nx >= 8 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP)
       c->pred_kind = 2;
     if (const char *e = std::getenv("PIC1DP_PRED_KIND")) {
       const int k = std::atoi(e);
-      if (k == 2 && nm == 1 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP) c->pred_kind = 2;
+      if (k == 2 && nm == 1 && nx >= 8 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP) c->pred_kind = 2;
       if (k == 1 && c->pred_kind != 1) c->pred_kind = 0;
     }
     if (c->pred_kind) {  // the tables: E = 2*(cos re + (-sin) im) (src/pic1dp_field.F90:251-257)
@@ -833,6 +797,9 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   f.nmode = nm;
   f.nspecies = ns;
   f.deltaf = in->deltaf;
+  f.npe = c->lay.npe;  // the summation order of the reference run being reproduced (PIC1DP_FIELD_ONE_RANK_ORDER=1: tests)
+  if (const char *e = std::getenv("PIC1DP_FIELD_ONE_RANK_ORDER"))
+    if (std::atoi(e) != 0) f.npe = 1;
   f.tab_lds = (static_cast<size_t>(2) * nm * nx * sizeof(double) <= 96 * 1024) ? 1 : 0;
   f.lx = in->lx;
   f.dnx = static_cast<double>(nx);
@@ -868,7 +835,6 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
   double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
                     c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred, c->d_cd_h, c->d_mode_h, c->d_Ehn, c->d_pack};
   for (double *b : bufs) (void)hipFree(b);
-  for (double *b : c->probe_keep) (void)hipFree(b);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -1452,7 +1418,7 @@ static int64_t oversubscribed(const pic1dp_ctx *c, int64_t np, int64_t resident,
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
   LaunchCfg lc{};
   lc.lds = step_lds_bytes(c->in.nx, full, c->grid.rcopies);
-  int by_lds = static_cast<int>(PARTICLE_LDS_CAP / lc.lds);
+  int by_lds = static_cast<int>(kCuLds / (lc.lds + kStaticLds));
   if (by_lds < 1) by_lds = 1;
   // two workgroups of 768 threads per CU (24 waves): measured inside one process
   // (tools/ab_launch.py) best or within 1 % of best from 6.4e6 to 1e8 markers --
@@ -1546,7 +1512,8 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     // updates/s; two-stream2 (one division fewer per exp pair) 1.05e11 either way, so only
     // bump-on-tail carries.  PIC1DP_CARRY=0 switches it off, 2 also carries for two-stream2.
     const uint64_t read_version = full ? c->state_version - 1 : c->state_version;
-    const bool carry2 = c->carry && c->in.deltaf && !S.sc.pow2 && (c->in.iptcldist == 3 || (c->carry == 2 && c->in.iptcldist == 2));
+    const bool carry2 = c->carry != 0 && c->in.deltaf && !S.sc.pow2 && !S.sc.one_exp &&
+                        (c->in.iptcldist == 3 || (c->carry == 2 && c->in.iptcldist == 2));
     if (carry2 && !pred) {
       if (!S.t2) HIP_TRY(hipMalloc(&S.t2, sizeof(double) * static_cast<size_t>(S.nalloc + 2)));
       // the second kernel may only load what the first one stored for these very markers
@@ -1570,7 +1537,11 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       // 1e8 markers, tools/ab_pred.sh).  PIC1DP_CARRY=0: evaluated again instead.
       // Only where -f0'/f0 costs something: two-stream2 and bump-on-tail (two exp and a division);
       // Maxwellian and two-stream1 evaluate it in one or two operations.
-      if (c->carry && c->in.deltaf && (c->in.iptcldist == 2 || c->in.iptcldist == 3)) {
+      // With the one-exp form of -f0'/f0 (device_math.hpp) an evaluation costs about what its 16 B of carry
+      // traffic cost: measured (profiles/r03/experiments/ab_one_exp.log), PIC1DP_CARRY=1 / 0 insists either way.
+      const bool exp_bearing = c->in.deltaf && (c->in.iptcldist == 2 || c->in.iptcldist == 3);
+      const bool carry_one = c->carry < 0 ? (S.sc.one_exp ? kCarryOneExpDefault : true) : c->carry > 0;
+      if (exp_bearing && carry_one) {
         if (!S.t2) HIP_TRY(hipMalloc(&S.t2, sizeof(double) * static_cast<size_t>(S.nalloc + 2)));
         a.t2 = S.t2;
         a.t2_mode = S.t2_version == read_version ? 2 : 1;
@@ -1578,7 +1549,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       }
       lc.lds = c->pred_kind == 2 ? step_sums_lds_bytes(c->in.nx, c->grid.rcopies)
                                  : step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode);
-      bool two = 2 * lc.lds <= PARTICLE_LDS_CAP;
+      bool two = 2 * (lc.lds + kStaticLds) <= kCuLds;  // both workgroups resident: each also holds the static exp table
       int th2 = 768;
       int th1 = 1024;
       if (c->pred_kind == 2) {
@@ -1611,8 +1582,19 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       c->diag_pending[s] = 1;
       c->diag_version[s] = c->state_version;  // the caller has bumped it for this step already
     }
+    const int tag = pred ? kTagStepOne : (full ? kTagStepFull : kTagStepHalf);
+    {  // the bytes this instantiation moves per marker: x, v, p (+ w) read; x (+ v) (+ w) written by a full step
+      pic1dp_ctx::KernelBytes &kb = c->kbytes[tag];
+      kb.rd = 8.0 * (3 + (c->in.deltaf ? 1 : 0));
+      kb.wr = full ? 8.0 * (1 + (c->in.linear ? 0 : 1) + (c->in.deltaf ? 1 : 0)) : 0.0;
+      kb.carry = 0.0;
+      if (a.t2) kb.carry = pred ? (a.t2_mode == 2 ? 16.0 : 8.0) : 8.0;  // k_step_one: 8 read (mode 2) + 8 written
+      std::snprintf(kb.name, sizeof kb.name, "%s%s", pred ? (c->pred_kind == 2 ? "k_step_sums" : "k_step_one")
+                                                          : (full ? (diag ? "k_step_full<DIAG>" : "k_step_full") : "k_step_half"),
+                    S.sc.one_exp && c->in.deltaf ? " (one-exp -f0'/f0)" : "");
+    }
     Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
-    Span ks(c, pred ? kTagStepOne : (full ? kTagStepFull : kTagStepHalf), c->stats_on);
+    Span ks(c, tag, c->stats_on);
     HIP_TRY(launch_step(a, full, lc, c->st));
     if (int rc = ks.end()) return rc;
     if (int rc = tm.end()) return rc;
@@ -2145,147 +2127,6 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *mark
   return 0;
 }
 
-int pic1dp_hip_stream_probe(pic1dp_ctx *c, int32_t nread, int32_t nwrite, int64_t n, int32_t reps,
-                            double *gbytes_per_s) {
-  CHECK_CTX(c);
-  if (!gbytes_per_s || n < 2 || reps < 1) return fail(PIC1DP_ERR_ARG, "bad argument");
-  if ((nread != 1 && nread != 4 && nread != 7) || (nwrite != 0 && nwrite != 1 && nwrite != 3))
-    return fail(PIC1DP_ERR_ARG, "nread must be 1, 4 or 7 and nwrite 0, 1 or 3");
-  HIP_TRY(hipSetDevice(c->device));
-  const int nbuf = nread + (nwrite > 0 ? nwrite : 1);
-  double *base = nullptr;
-  HIP_TRY(hipMalloc(&base, sizeof(double) * static_cast<size_t>(n) * nbuf));
-  int rc = 0;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  do {
-    hipError_t e = hipMemsetAsync(base, 0, sizeof(double) * static_cast<size_t>(n) * nbuf, c->st);
-    double *in[8] = {nullptr}, *out[4] = {nullptr};
-    for (int k = 0; k < nread; ++k) in[k] = base + static_cast<size_t>(k) * n;
-    for (int k = 0; k < (nwrite > 0 ? nwrite : 1); ++k) out[k] = base + static_cast<size_t>(nread + k) * n;
-    LaunchCfg lc = particle_launch(c, n, false, false);
-    // non-temporal accesses like the particle kernels; PIC1DP_PROBE_VARIANT (tuning
-    // only): 0 plain, 1 non-temporal, 2 plain with two pairs per lane
-    int variant = 1;
-    if (const char *ev = std::getenv("PIC1DP_PROBE_VARIANT")) variant = std::atoi(ev);
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = launch_stream_probe(in, nread, out, nwrite, n, lc.blocks, lc.threads, variant, c->st);  // warm-up
-    if (e == hipSuccess) e = hipEventRecord(e0, c->st);
-    for (int r = 0; r < reps && e == hipSuccess; ++r)
-      e = launch_stream_probe(in, nread, out, nwrite, n, lc.blocks, lc.threads, variant, c->st);
-    if (e == hipSuccess) e = hipEventRecord(e1, c->st);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e != hipSuccess) {
-      rc = fail(PIC1DP_ERR_HIP, "stream probe: %s", hipGetErrorString(e));
-      break;
-    }
-    *gbytes_per_s = 8.0 * static_cast<double>(n) * (nread + nwrite) * reps / (ms * 1e-3) / 1e9;
-  } while (false);
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  (void)hipFree(base);
-  return rc;
-}
-
-// tuning only (tools/layout_probe.py): time k_step_full's traffic shape (4 arrays read,
-// 3 written in place) over a fresh slab, SoA against tiled; keep != 0 leaves the slab
-// allocated until destroy so that the next call lands in other physical memory
-int pic1dp_hip_debug_layout_probe(pic1dp_ctx *c, int64_t n, int32_t log2_tile, int64_t stagger_bytes, int32_t reps,
-                                  int32_t keep, double ms[6]) {
-  CHECK_CTX(c);
-  if (!ms || n < 2 || reps < 1 || log2_tile < 2 || log2_tile > 24) return fail(PIC1DP_ERR_ARG, "bad argument");
-  HIP_TRY(hipSetDevice(c->device));
-  const int64_t tile = static_cast<int64_t>(1) << log2_tile;
-  n = n / tile * tile;
-  const size_t unit = static_cast<size_t>(2) << 20;
-  const size_t stride = (sizeof(double) * static_cast<size_t>(n) + unit - 1) / unit * unit + static_cast<size_t>(stagger_bytes);
-  double *base = nullptr;
-  HIP_TRY(hipMalloc(&base, 4 * stride));
-  int rc = 0;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  hipError_t e = hipMemsetAsync(base, 0, 4 * stride, c->st);
-  if (e == hipSuccess) e = hipEventCreate(&e0);
-  if (e == hipSuccess) e = hipEventCreate(&e1);
-  LaunchCfg lc = step_launch(c, n, true);
-  // ms[]: SoA r/w, tiled r/w, SoA read-only, tiled read-only, tiled r/w one workgroup per tile, the same read-only
-  const int variants[6] = {0, 1, 2, 3, 5, 7};
-  for (int k = 0; k < 6 && e == hipSuccess; ++k) {
-    for (int r = 0; r < 3 && e == hipSuccess; ++r)
-      e = launch_layout_probe(base, static_cast<int64_t>(stride / sizeof(double)), log2_tile, n, variants[k], lc.blocks, lc.threads, c->st);
-    if (e == hipSuccess) e = hipEventRecord(e0, c->st);
-    for (int r = 0; r < reps && e == hipSuccess; ++r)
-      e = launch_layout_probe(base, static_cast<int64_t>(stride / sizeof(double)), log2_tile, n, variants[k], lc.blocks, lc.threads, c->st);
-    if (e == hipSuccess) e = hipEventRecord(e1, c->st);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    float t = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
-    ms[k] = t / reps;
-  }
-  if (e != hipSuccess) rc = fail(PIC1DP_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  if (keep && rc == 0)
-    c->probe_keep.push_back(base);
-  else
-    (void)hipFree(base);
-  return rc;
-}
-
-int pic1dp_hip_debug_divc_check(pic1dp_ctx *c, int32_t isp, int64_t n, uint64_t seed, int64_t *mismatches) {
-  CHECK_CTX(c);
-  if (!mismatches || n < 0) return fail(PIC1DP_ERR_ARG, "bad argument");
-  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
-  HIP_TRY(hipSetDevice(c->device));
-  const SpeciesConst &k = c->sp[isp].sc;
-  const double divisors[8] = {k.m, k.T, k.tm, k.tm2, k.two_tm, k.two_tm2, k.stm, k.stm2};
-  unsigned long long *d = reinterpret_cast<unsigned long long *>(c->d_scratch);
-  HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->st));
-  for (int i = 0; i < 8; ++i) HIP_TRY(launch_divc_check(divisors[i], seed + i, n, d, c->st));
-  HIP_TRY(hipStreamSynchronize(c->st));
-  unsigned long long h = 0;
-  HIP_TRY(hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost));
-  *mismatches = static_cast<int64_t>(h);
-  return 0;
-}
-
-int pic1dp_hip_debug_exp(pic1dp_ctx *c, const double *x, double *y, int64_t n) {
-  CHECK_CTX(c);
-  if (!x || !y || n < 0) return fail(PIC1DP_ERR_ARG, "bad argument");
-  if (n == 0) return 0;
-  HIP_TRY(hipSetDevice(c->device));
-  double *d = nullptr;
-  HIP_TRY(hipMalloc(&d, sizeof(double) * 2 * static_cast<size_t>(n)));
-  hipError_t e = hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = launch_exp_array(d, d + n, n, c->st);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->st);
-  if (e == hipSuccess) e = hipMemcpy(y, d + n, sizeof(double) * n, hipMemcpyDeviceToHost);
-  (void)hipFree(d);
-  HIP_TRY(e);
-  return 0;
-}
-
-int pic1dp_hip_host_divc_check(double divisor, int64_t n, uint64_t seed, int64_t *mismatches) {
-  if (!mismatches || n < 0 || !(divisor != 0.0)) return fail(PIC1DP_ERR_ARG, "bad argument");
-  *mismatches = host_divc_check(divisor, seed, n);
-  return 0;
-}
-
-int pic1dp_hip_debug_div_check(pic1dp_ctx *c, int64_t n, uint64_t seed, int64_t *mismatches) {
-  CHECK_CTX(c);
-  if (!mismatches || n < 0) return fail(PIC1DP_ERR_ARG, "bad argument");
-  HIP_TRY(hipSetDevice(c->device));
-  unsigned long long *d = reinterpret_cast<unsigned long long *>(c->d_scratch);
-  HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned long long), c->st));
-  HIP_TRY(launch_div_check(c->grid, seed, n, d, c->st));
-  HIP_TRY(hipStreamSynchronize(c->st));
-  unsigned long long h = 0;
-  HIP_TRY(hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost));
-  *mismatches = static_cast<int64_t>(h);
-  return 0;
-}
-
 // ---------------------------------------------------------------------------
 // split-phase deposit
 // ---------------------------------------------------------------------------
@@ -2382,12 +2223,19 @@ int pic1dp_hip_xchg_create(pic1dp_ctx *c, unsigned char handle[PIC1DP_XCHG_HANDL
   if (c->xc.local) return fail(PIC1DP_ERR_STATE, "exchange area already created");
   HIP_TRY(hipSetDevice(c->device));
   const size_t bytes = kXchgFlagBytes + sizeof(double) * 2 * static_cast<size_t>(c->lay.nranks) * XCHG_MAX_VEC * c->in.nx;
-  // memory the peers' stores and this GPU's polls meet in: fine-grained (coherent
-  // across agents inside a kernel); PIC1DP_XCHG_MEM = 2 uncached, 3 plain hipMalloc
-  int want = 1;
-  if (const char *e = std::getenv("PIC1DP_XCHG_MEM")) want = std::atoi(e);
+  // memory the peers' stores and this GPU's polls meet in has to be coherent across agents INSIDE a kernel:
+  // fine-grained, else uncached.  Plain (coarse-grained) hipMalloc memory is not -- a stale L2 line of the
+  // same-parity slot of exchange e - 2 would be summed without any error showing -- so the automatic chain stops
+  // after the two coherent kinds and reports PIC1DP_ERR_COMM (the host then agrees on RCCL or its own sum);
+  // kind 3 only when PIC1DP_XCHG_MEM=3 asks for it by name (experiments).
+  int want = 1, last = 2;
+  if (const char *e = std::getenv("PIC1DP_XCHG_MEM")) {
+    want = std::atoi(e);
+    if (want < 1 || want > 3) return fail(PIC1DP_ERR_ARG, "PIC1DP_XCHG_MEM must be 1 (fine-grained), 2 (uncached) or 3 (plain)");
+    last = want == 3 ? 3 : 2;
+  }
   hipError_t e = hipErrorUnknown;
-  for (int kind = want; kind <= 3 && e != hipSuccess; ++kind) {
+  for (int kind = want; kind <= last && e != hipSuccess; ++kind) {
     if (kind == 1) e = hipExtMallocWithFlags(&c->xc.local, bytes, hipDeviceMallocFinegrained);
     if (kind == 2) e = hipExtMallocWithFlags(&c->xc.local, bytes, hipDeviceMallocUncached);
     if (kind == 3) e = hipMalloc(&c->xc.local, bytes);
@@ -2404,7 +2252,9 @@ int pic1dp_hip_xchg_create(pic1dp_ctx *c, unsigned char handle[PIC1DP_XCHG_HANDL
     }
     if (e != hipSuccess) (void)hipGetLastError();
   }
-  if (e != hipSuccess) return fail(PIC1DP_ERR_HIP, "exchange area: %s", hipGetErrorString(e));
+  if (e != hipSuccess)
+    return fail(PIC1DP_ERR_COMM, "exchange area: no fine-grained or uncached device memory with an IPC handle (%s)",
+                hipGetErrorString(e));
   HIP_TRY(hipMemset(c->xc.local, 0, bytes));
   if (!c->xc.err) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->xc.err), 64, hipHostMallocDefault));
@@ -2519,6 +2369,18 @@ int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *l
   const int tag = which == 6 ? kTagStepOne : kTagFused + which;
   if (ms) *ms = c->acc_ms[tag];
   if (launches) *launches = c->acc_n[tag];
+  return 0;
+}
+
+int pic1dp_hip_kernel_bytes(pic1dp_ctx *c, int32_t which, double *read_bytes, double *written_bytes, double *carry_bytes,
+                            char *name, int32_t name_len) {
+  CHECK_CTX(c);
+  if (which < 0 || which > 6 || which == 5) return fail(PIC1DP_ERR_ARG, "which must be 0..4 or 6");
+  const pic1dp_ctx::KernelBytes &kb = c->kbytes[which == 6 ? kTagStepOne : kTagFused + which];
+  if (read_bytes) *read_bytes = kb.rd;
+  if (written_bytes) *written_bytes = kb.wr;
+  if (carry_bytes) *carry_bytes = kb.carry;
+  if (name && name_len > 0) std::snprintf(name, static_cast<size_t>(name_len), "%s", kb.name);
   return 0;
 }
 

@@ -22,7 +22,18 @@ struct SpeciesConst {
   int pow2;             // 1: all divisors above are powers of two
   int unit;             // 1: m = T = T2 = 1 (T/m = sqrt(T/m) = 1, 2T/m = 2): divisions vanish
   int fastc;            // 1: a/c by reciprocal + two FMA corrections for all eight divisors (host-verified)
+  // one-exp form of -f0'/f0 (device_math.hpp dlnf0_one_exp; iptcldist 2 and 3): L(v) = (fq2 v + fq1) v + fq0 is
+  // the log of the ratio of the two Maxwellians, tmp2 = (fm1 v + fm0) + (fd1 v + fd0) tanh(L / 2)
+  int one_exp;          // 1: the marker kernels use it (default; PIC1DP_DLNF0=ref: the reference's operation order)
+  double fq2, fq1, fq0, fm1, fm0, fd1, fd0;
 };
+// one species of the input file (src/pic1dp_input.F90:43-72) -> the constants above (host; species.cpp).
+// PIC1DP_UNIT_SPECIALISATION, PIC1DP_FAST_DIVC, PIC1DP_DLNF0 (tuning / cross-check) are read here.
+struct SpeciesInput {
+  int iptcldist;
+  double charge, mass, temperature, temperature2, density, v0;
+};
+SpeciesConst make_species_const(const SpeciesInput &in, int species_index);
 
 struct GridConst {
   double lx, dnx, dt_full;
@@ -180,6 +191,8 @@ struct FieldArgs {
   const double *grad_inv;      // [nmode]
   double *history;       // energy slot to write, or nullptr
   int nx, nmode, nspecies, deltaf;
+  int npe;               // reference ranks reproduced: > 1 takes the forward sums in the npe-rank order (MPI-AIJ row
+                         // blocks, kernels_field.hip rank_block), 1 in the one-rank ascending order
   int tab_lds;           // 1: stage the tables in LDS (they fit)
   double lx, dnx, sc_re, sc_im;
   double Z[8], n0[8];
@@ -272,26 +285,10 @@ hipError_t launch_ptcldist(const double *x, const double *v, const double *p, co
                            int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
                            double *out, double *partial, int num_cu, hipStream_t st);
 int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu);
-// streaming-bandwidth probe with the particle kernels' access pattern:
-// (nr, nw) in {1,4,7} x {0,1,3} arrays of n doubles read / written
-hipError_t launch_stream_probe(double *const *in, int nr, double *const *out, int nw, int64_t n,
-                               int blocks, int threads, int variant, hipStream_t st);
-// tuning only: k_step_full's traffic shape over one slab, SoA (arrays step_doubles apart)
-// or tiled ([x|v|w|p] tiles of 2^log2_tile markers); n markers, n a multiple of the tile
-// variant: bit 0 tiled, bit 1 read-only (the first sub-step's shape), bit 2 one workgroup per tile
-hipError_t launch_layout_probe(double *base, int64_t step_doubles, int log2_tile, int64_t n, int variant, int blocks,
-                               int threads, hipStream_t st);
-// div_lx (reciprocal + FMA corrections) against the hardware division on n test
-// positions; *bad counts results that differ in any bit
-hipError_t launch_div_check(const GridConst &g, uint64_t seed, int64_t n, unsigned long long *bad,
-                            hipStream_t st);
+// div_lx's / div_const's algorithm (reciprocal + two FMA corrections) with the host's fma against the true
+// quotient on n generated operands: the number of results that differ in any bit (hostcheck.cpp)
 int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n);
-// div_const (a / c for a species constant c) against the true quotient on n
-// generated dividends, on the device and with the host's fma
-hipError_t launch_divc_check(double c, uint64_t seed, int64_t n, unsigned long long *bad, hipStream_t st);
 int64_t host_divc_check(double c, uint64_t seed, int64_t n);
-// y[i] = exp(x[i]) as the push kernels evaluate it (device arrays)
-hipError_t launch_exp_array(const double *x, double *y, int64_t n, hipStream_t st);
 // cell index per marker and per-cell counts from (wrapped) x
 hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
                                unsigned long long *count, hipStream_t st);

@@ -1,0 +1,182 @@
+// kernels_diag.hip -- off the timed path: the fused diagnostics pass of output_all (k_ptcldist), kinetic sums of
+// tail slots, cell indices per marker (parity tests), and the copies between contiguous host-side buffers and the
+// tiled marker slabs.  gfx950, wave64.
+#include "device_diag.hpp"
+#include "device_math.hpp"
+
+namespace pic1dp {
+
+// ---------------------------------------------------------------------------
+// diagnostics
+// ---------------------------------------------------------------------------
+namespace {
+
+// sum v^2, v^2 p, v^2 w (src/pic1dp_output.F90:126-151): per-workgroup partials,
+// the host adds them in workgroup order
+__global__ void __launch_bounds__(256)
+k_energy_sums(const double *v, const double *p, const double *w, int64_t i0, int64_t n, double *partial) {
+  __shared__ double scr[16];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const int64_t i = tidx(i0 + k);
+    const double v2 = v[i] * v[i];
+    s0 += v2;
+    s1 += v2 * p[i];
+    if (w) s2 += v2 * w[i];
+  }
+  const double t0 = block_sum(s0, scr);
+  const double t1 = block_sum(s1, scr);
+  const double t2 = block_sum(s2, scr);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 3 + 0] = t0;
+    partial[blockIdx.x * 3 + 1] = t1;
+    partial[blockIdx.x * 3 + 2] = t2;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_cell_indices(const double *x, int64_t np, const GridConst g, int32_t *ixo,
+               unsigned long long *count) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < np; i += stride) {
+    int ix;
+    double wl;
+    locate(x[tidx(i)], g, ix, wl);
+    if (ixo) ixo[i] = ix;
+    if (count) atomicAdd(&count[ix], 1ULL);
+  }
+}
+
+}  // namespace
+
+namespace {
+
+// One pass over a species for everything output_all needs from the markers:
+// * the (x,v) and v histograms of output_ptcldist, src/pic1dp_output.F90:239-315:
+//   4-point bilinear weights on an nx_opd x nv_opd grid, markers with
+//   |v| >= v_max skipped (:241);
+// * the kinetic sums of output_field, sum v^2, v^2 p, v^2 w over ALL markers
+//   (:126-151), as per-workgroup partials the host adds in workgroup order.
+// LDS = true keeps a private copy of the histograms per workgroup
+// (3*(nxo*nvo)+3*nvo doubles) and flushes it with global atomics.  There the v
+// histograms are not accumulated marker by marker (64 hot bins: the LDS atomics
+// of a wave collide) but formed once per workgroup as the row sums of its (x,v)
+// histograms -- the same numbers in exact arithmetic, (sx + (1-sx))*sv = sv, and
+// within rounding (<= 1e-15 relative per term) of the separate accumulation.
+// LDS = false (grids too large for 160 KiB) adds everything straight to memory.
+// The per-marker part and the finish are shared with the DIAG variant of k_step_full.
+template <bool LDS, bool DELTAF>
+__global__ void __launch_bounds__(1024)
+k_ptcldist(const double *x, const double *v, const double *p, const double *w, int64_t np, const DistGeom dg,
+           double *out, double *partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntot = 3 * dg.nxo * dg.nvo + 3 * dg.nvo;
+  DistBins b{LDS ? reinterpret_cast<double *>(smem) : out, dg.nxo * dg.nvo, dg.nvo};
+  double *scr = reinterpret_cast<double *>(smem) + (LDS ? ntot : 0);  // [16]
+  if constexpr (LDS) {
+    for (int i = threadIdx.x; i < ntot; i += blockDim.x) b.h[i] = 0.0;
+    __syncthreads();
+  }
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  DistSums sm;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < np; k += stride) {
+    const int64_t i = tidx(k);
+    ptcldist_one<LDS, DELTAF>(x[i], v[i], p[i], DELTAF ? w[i] : 0.0, dg, b, sm);
+  }
+  ptcldist_finish<LDS, DELTAF>(dg, b, sm, scr, out, partial);
+}
+
+}  // namespace
+
+int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu) {
+  const size_t bytes = sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo));
+  const bool lds = bytes <= 150 * 1024;
+  int64_t blocks = lds ? num_cu : static_cast<int64_t>(num_cu) * 2;
+  const int64_t need = (np + 1023) / 1024;
+  if (blocks > need) blocks = need;
+  if (blocks < 1) blocks = 1;
+  return static_cast<int>(blocks);
+}
+
+hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
+                           int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
+                           double *out, double *partial, int num_cu, hipStream_t st) {
+  const size_t hist = sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo));
+  const bool lds = hist <= 150 * 1024;
+  const size_t bytes = (lds ? hist : 0) + 16 * sizeof(double);  // + block_sum scratch
+  const int threads = 1024;
+  const int blocks = ptcldist_blocks(np, nxo, nvo, num_cu);
+  const DistGeom dg{lx, vmax, nxo, nvo};
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds && bytes > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), bytes, st, x, v, p, w, np, dg, out,
+                       partial);
+    return hipGetLastError();
+  };
+  if (lds) return deltaf ? go(k_ptcldist<true, true>) : go(k_ptcldist<true, false>);
+  return deltaf ? go(k_ptcldist<false, true>) : go(k_ptcldist<false, false>);
+}
+
+hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t i0, int64_t n,
+                              double *partial, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(k_energy_sums, dim3(blocks), dim3(256), 0, st, v, p, w, i0, n, partial);
+  return hipGetLastError();
+}
+
+namespace {
+
+// host arrays are contiguous, marker arrays tiled: the two meet in these kernels
+__global__ void __launch_bounds__(256) k_tile_scatter(double *arr, int64_t i0, const double *src, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride)
+    arr[tidx(i0 + k)] = src[k];
+}
+__global__ void __launch_bounds__(256) k_tile_gather(const double *arr, int64_t i0, double *dst, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride)
+    dst[k] = arr[tidx(i0 + k)];
+}
+__global__ void __launch_bounds__(256) k_tile_copy(double *dst, const double *src, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride)
+    dst[tidx(k)] = src[tidx(k)];
+}
+
+int copy_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return static_cast<int>(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+hipError_t launch_tile_scatter(double *arr, int64_t i0, const double *src, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tile_scatter, dim3(copy_blocks(n)), dim3(256), 0, st, arr, i0, src, n);
+  return hipGetLastError();
+}
+hipError_t launch_tile_gather(const double *arr, int64_t i0, double *dst, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tile_gather, dim3(copy_blocks(n)), dim3(256), 0, st, arr, i0, dst, n);
+  return hipGetLastError();
+}
+hipError_t launch_tile_copy(double *dst, const double *src, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tile_copy, dim3(copy_blocks(n)), dim3(256), 0, st, dst, src, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,
+                               unsigned long long *count, hipStream_t st) {
+  int blocks = static_cast<int>((np + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_cell_indices, dim3(blocks), dim3(256), 0, st, x, np, g, ix, count);
+  return hipGetLastError();
+}
+
+}  // namespace pic1dp

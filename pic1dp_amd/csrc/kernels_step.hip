@@ -1,0 +1,630 @@
+// kernels_step.hip -- the whole-time-step marker kernels (pic1dp_hip_step and the lazy call sites): k_step_half,
+// k_step_full, k_step_one, k_step_sums.  gfx950 (CDNA4, wave64), compiled with -ffp-contract=off: every product /
+// sum the reference rounds separately is rounded separately here, so positions, velocities and cell indices are
+// bit-identical to the CPU arithmetic; only exp() and the order of the charge sums differ.
+// All kernels are HBM-bound streaming passes over the tiled FP64 marker slabs (16 B per lane, coalesced,
+// grid-stride); no dense contraction, so no MFMA.  Grid tiles (E0, Eh, rho, the prediction's tables and
+// accumulators) live in LDS; deposits are ds_add_f64, flushed with one global atomic per cell and workgroup.
+// DESIGN.md section 3 has the numbers.
+//
+// One translation unit per distribution: the build compiles this file once for every value of
+// -DPIC1DP_STEP_DIST (0 Maxwellian, 1 two-stream1, 2 two-stream2, 3 bump-on-tail, 4 / 5 the one-exp forms of 2 / 3),
+// in parallel; step_dispatch.cpp picks the instance.
+#include "device_diag.hpp"
+#include "device_math.hpp"
+#include "step_args.hpp"
+
+#ifndef PIC1DP_STEP_DIST
+#error "compile with -DPIC1DP_STEP_DIST=0..5 (pic1dp_amd/build.py does)"
+#endif
+
+namespace pic1dp {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Whole-time-step kernels (pic1dp_hip_step): the half-step state is never
+// written to memory.  RK2 (midpoint) needs, for the second sub-step, the state
+// after the first one; instead of storing it (24 B) and loading it back (24 B)
+// it is recomputed from the step-start state and the step-start field E0 with
+// the very same instruction sequence, hence bit-identical:
+//   k_step_half : x0,v0,w0,p (32 B in, 0 B out) -> half-step x', w' -> deposit
+//   k_step_full : x0,v0,w0,p (32 B in)          -> recompute x',v',w' from E0,
+//                 push from the base with the half-step field Eh, wrap, deposit,
+//                 store x,v,w in place (24 B out)
+// 88 B per marker per time step instead of 136 B (ping-pong) or the reference's
+// 256 B data flow; arithmetic per marker roughly doubles (still under the
+// FP64 rate at the HBM-bound pace).
+// ---------------------------------------------------------------------------
+
+// CARRY: a species whose divisor constants are general numbers spends most of either kernel
+// in -f0'/f0 (two exp, eight constant divisions, one true division: FP64-issue-bound).  The
+// second kernel evaluates it twice -- at the step-start velocity again, to recompute the
+// half-step state, and at the half-step velocity.  With CARRY the first kernel stores its
+// value (8 B per marker, contiguous array) and the second loads it: 16 B more traffic per
+// marker and step for a third less arithmetic.  Same value, same bits.
+// NT: non-temporal loads and stores.  They win once the marker state no longer
+// fits the 256 MiB Infinity Cache (+15 % at 2e7 markers); below that, plain
+// accesses keep the state cache-resident between the two kernels of a step
+// (+5 % at the reference's default 6.4e6 markers).  Chosen per launch.
+template <int DIST, int MODE, int POW2, bool NT, bool CARRY>
+__global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  exp_table_init();
+  double *sE = reinterpret_cast<double *>(smem);
+  const int nx = a.g.nx;
+  double *sR0 = sE + ((nx + 2) & ~1);
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) sE[i] = a.E0[i];
+  zero_rho(sR0, a.g);
+  if (threadIdx.x == 0) sE[nx] = a.E0[0];
+  __syncthreads();
+  double *sR = my_rho_copy(sR0, a.g);
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const double2 *x2 = reinterpret_cast<const double2 *>(a.x);
+  const double2 *v2 = reinterpret_cast<const double2 *>(a.v);
+  const double2 *w2 = reinterpret_cast<const double2 *>(a.w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+    const int64_t o = tidx2(j);
+    const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
+    double2 W = make_double2(0.0, 0.0);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
+    double t0 = 0.0, t1 = 0.0;
+    const One h0 = push_one<DIST, MODE, POW2, CARRY ? 1 : 0>(X.x, V.x, W.x, P.x, X.x, V.x, W.x, sE, a.dt_half, a.g, a.s, &t0);
+    deposit_one(h0.x, HAS_W ? h0.w : P.x, sR, a.g);
+    PAIR_FENCE();
+    const One h1 = push_one<DIST, MODE, POW2, CARRY ? 1 : 0>(X.y, V.y, W.y, P.y, X.y, V.y, W.y, sE, a.dt_half, a.g, a.s, &t1);
+    deposit_one(h1.x, HAS_W ? h1.w : P.y, sR, a.g);
+    if constexpr (CARRY) st2t<NT>(reinterpret_cast<double2 *>(a.t2) + j, t0, t1);
+  }
+  if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = tidx(a.np - 1);
+    const double x = a.x[i], v = a.v[i], p = a.p[i];
+    const double w = HAS_W ? a.w[i] : 0.0;
+    double t0 = 0.0;
+    const One h = push_one<DIST, MODE, POW2, CARRY ? 1 : 0>(x, v, w, p, x, v, w, sE, a.dt_half, a.g, a.s, &t0);
+    if constexpr (CARRY) a.t2[a.np - 1] = t0;
+    deposit_one(h.x, HAS_W ? h.w : p, sR, a.g);
+  }
+  __syncthreads();
+  flush_rho(sR0, a.rho, a.g);
+}
+
+// one marker through the second half of the time step
+template <int DIST, int MODE, int POW2, bool CARRY = false, class FH = const double *>
+__device__ __forceinline__ One step_full_one(double x, double v, double w, double p, const double *sE0,
+                                             const FH &sEh, double *sR, const StepArgsDev &a, double t2 = 0.0,
+                                             int *ix_out = nullptr, double *wl_out = nullptr) {
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  // sub-step 1 again (identical arithmetic), with the wrap the deposit applied
+  One h = push_one<DIST, MODE, POW2, CARRY ? 2 : 0>(x, v, w, p, x, v, w, sE0, a.dt_half, a.g, a.s, &t2);
+  h.x = wrap(h.x, a.g.lx);
+  // sub-step 2: derivatives at the half-step state, base = step-start state
+  One n = push_one<DIST, MODE, POW2>(h.x, h.v, h.w, p, x, v, w, sEh, a.dt_full, a.g, a.s);
+  n.x = deposit_one(n.x, HAS_W ? n.w : p, sR, a.g, ix_out, wl_out);
+  return n;
+}
+
+// DIAG: on a step after which the host will call output_all, the histograms of output_ptcldist and
+// the kinetic sums of output_field (k_ptcldist's work: another 32 B per marker read) are taken here on
+// the state just computed, into an LDS copy of the histograms next to the grid tiles (one workgroup
+// of 1024 threads per CU then).
+template <int DIST, int MODE, int POW2, bool NT, bool CARRY, bool DIAG>
+__global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  exp_table_init();
+  const int nx = a.g.nx;
+  const int ne = (nx + 2) & ~1;
+  double *sE0 = reinterpret_cast<double *>(smem);
+  double *sEh = sE0 + ne;
+  double *sR0 = sEh + ne;
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    sE0[i] = a.E0[i];
+    sEh[i] = a.Eh[i];
+  }
+  zero_rho(sR0, a.g);
+  if (threadIdx.x == 0) {
+    sE0[nx] = a.E0[0];
+    sEh[nx] = a.Eh[0];
+  }
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
+  // DIAG: histograms behind the rho copies (16-byte aligned), then the block_sum scratch
+  double *sH = sR0 + ((nx * a.g.rcopies + 2) & ~1);
+  const int ntot = DIAG ? 3 * a.dg.nxo * a.dg.nvo + 3 * a.dg.nvo : 0;
+  const DistBins bins{sH, a.dg.nxo * a.dg.nvo, a.dg.nvo};
+  DistSums sums;
+  if constexpr (DIAG)
+    for (int i = threadIdx.x; i < ntot; i += blockDim.x) sH[i] = 0.0;
+  __syncthreads();
+  double *sR = my_rho_copy(sR0, a.g);
+  const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double2 *x2 = reinterpret_cast<double2 *>(a.x);
+  double2 *v2 = reinterpret_cast<double2 *>(a.v);
+  double2 *w2 = reinterpret_cast<double2 *>(a.w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+    const int64_t o = tidx2(j);
+    const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
+    double2 W = make_double2(0.0, 0.0);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
+    double2 T = make_double2(0.0, 0.0);
+    if constexpr (CARRY) T = ld2t<NT>(reinterpret_cast<const double2 *>(a.t2) + j);
+    const One n0 = step_full_one<DIST, MODE, POW2, CARRY>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x);
+    PAIR_FENCE();
+    const One n1 = step_full_one<DIST, MODE, POW2, CARRY>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y);
+    st2t<NT>(x2 + o, n0.x, n1.x);
+    if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
+    if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
+    if constexpr (DIAG) {
+      ptcldist_one<true, HAS_W>(n0.x, n0.v, P.x, n0.w, a.dg, bins, sums);
+      ptcldist_one<true, HAS_W>(n1.x, n1.v, P.y, n1.w, a.dg, bins, sums);
+    }
+  }
+  if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = tidx(a.np - 1);
+    const double w = HAS_W ? a.w[i] : 0.0;
+    const One n = step_full_one<DIST, MODE, POW2, CARRY>(a.x[i], a.v[i], w, a.p[i], sE0, sEh, sR, a,
+                                                         CARRY ? a.t2[a.np - 1] : 0.0);
+    a.x[i] = n.x;
+    if constexpr (PUSH_V) a.v[i] = n.v;
+    if constexpr (HAS_W) a.w[i] = n.w;
+    if constexpr (DIAG) ptcldist_one<true, HAS_W>(n.x, n.v, a.p[i], n.w, a.dg, bins, sums);
+  }
+  __syncthreads();
+  flush_rho(sR0, a.rho, a.g);
+  if constexpr (DIAG) ptcldist_finish<true, HAS_W>(a.dg, bins, sums, sH + ntot, a.dist_out, a.dist_partial);
+}
+
+// ---------------------------------------------------------------------------
+// k_step_one: ONE pass over the markers per time step.
+// The first sub-step's kernel exists only to deposit the half-step charge, from which the
+// half-step field Eh follows.  But the half push is LINEAR in the field it sees:
+//     x' = x + dt/2 v                                     (no field at all, :261)
+//     w' = w + dt/2 (p - w) (-f0'/f0)(v) Z/m * E(x)        (:268-329; linear: p instead of p - w)
+// and the field is the kept modes' amplitudes times fixed tables (src/pic1dp_field.F90:251-257):
+//     E(x) = sum_m  re_m A_m(x) + im_m B_m(x),   A_m = gather of 2 cos, B_m = gather of -2 sin.
+// Hence the charge the NEXT step's first sub-step would deposit is
+//     rho_h = R0 + sum_m re_m RA_m + im_m RB_m,
+//     R0 = deposit of w at x',  RA_m = deposit of c A_m(x) at x',  RB_m likewise,
+//     c = dt/2 (p - w)(-f0'/f0)(v) Z/m,
+// and R0, RA_m, RB_m depend on the markers only -- this kernel, which has just computed the new
+// (x, v, w), deposits them as well.  When the field of the new state is solved (re, im known),
+// rho_h is one small combination (k_pred_combine), Eh one more solve, and the next step needs no
+// first-sub-step pass: 56 B per marker and step instead of 88.  The second sub-step's push is
+// untouched (same operations, same order as the reference given E0 and Eh); rho_h differs from a
+// marker-by-marker deposit of w' by rounding only (same algebra, different grouping: ~1e-15 relative,
+// the order of magnitude the atomics' order contributes anyway).  Full-f: rho_h = R0 (p at x').
+// Falls back to k_step_half + k_step_full when nmode > PRED_MAX_MODES or the tiles outgrow the LDS.
+// ---------------------------------------------------------------------------
+
+// c = dt/2 * (p - w) * (-f0'/f0)(v) * Z / m  (linear: p), and -f0'/f0(v) itself for the carry
+template <int DIST, int MODE, int POW2, class D>
+__device__ __forceinline__ double pred_coef_core(double v, double w, double p, double dt, const SpeciesConst &s, D &dv,
+                                                 double &t2) {
+  const double tmp1 = (MODE == MODE_DF_LIN) ? p : (p - w);
+  t2 = dlnf0<DIST, POW2>(v, s, dv);
+  return divc<POW2>(dt * tmp1 * t2 * s.Z, s.m, s.r_m, dv);
+}
+template <int DIST, int MODE, int POW2>
+__device__ __forceinline__ double pred_coef(double v, double w, double p, double dt, const SpeciesConst &s, double &t2) {
+  if constexpr (POW2 == 0) {
+    if (s.fastc) {
+      DivFast dv;
+      const double c = pred_coef_core<DIST, MODE, POW2>(v, w, p, dt, s, dv, t2);
+      if (dv.ok()) return c;
+    }
+  }
+  DivTrue dv;
+  return pred_coef_core<DIST, MODE, POW2>(v, w, p, dt, s, dv, t2);
+}
+
+// the prediction deposits of one marker in its NEW state n (x wrapped); returns -f0'/f0(n.v)
+// (ix, wl): cell and left weight of n.x, where the next step gathers its field (:250-257) -- the deposit
+// of the new state has just computed them.
+// The kernel runs at the package power limit with its FP64 pipes ~77 % busy at the clock that leaves
+// (DESIGN.md 7), so instructions are what this part is written for:
+// * the tables lie cell by cell, sAB[cell][A_0 B_0 (A_1 B_1)] with a guard cell, and the accumulators likewise,
+//   sP[cell][R0 RA_0 RB_0 (...)] with TWO guard cells (folded into cells 0 and 1 at the flush): one address
+//   per cell instead of one per tile and cell, no wrap-around of the right-hand cell, no clamp;
+// * the cell of x' needs no exact division and no wrap of the position: the prediction equals a marker-by-
+//   marker deposit to rounding anyway, and a deposit is continuous across a cell boundary (a position within
+//   an ulp of one puts ~0 into the far cell either way) -- s = x' * (nx / lx), one multiplication, and the
+//   CELL is wrapped (x' in (-lx, 2 lx) unless a marker crosses a box length in half a step: cells 0 ... nx,
+//   right-hand neighbour up to nx + 1; cvt(NaN) = 0);
+// * the constants of c are folded (pred_k = dt/2 Z/m).
+// * the number of kept modes is a template parameter (1 or 2): the tile and accumulator addresses of a cell
+//   are immediate offsets of one base address instead of a run-time loop's address arithmetic (a dozen integer
+//   instructions per marker).
+template <int DIST, int MODE, int POW2, int NM>
+__device__ __forceinline__ double pred_one(const One &n, double p, int ix, double wl, const double *sAB, double *sP,
+                                           const StepArgsDev &a) {
+  constexpr int nm = NM, np1 = 1 + 2 * NM;
+  const double xh = fma(a.dt_half, n.v, n.x);     // the next step's half push of x (:261), to rounding
+  const double sh = xh * a.snx;                   // its cell, wrapped as an integer (:102-108 to rounding)
+  const double fh = floor(sh);
+  int ih = static_cast<int>(fh);
+  const double wr = sh - fh, wh = 1.0 - wr;
+  ih = ih < 0 ? ih + a.g.nx : ih;
+  ih = ih > a.g.nx ? ih - a.g.nx : ih;            // (cell nx is a guard cell)
+  if (static_cast<unsigned>(ih) > static_cast<unsigned>(a.g.nx)) {  // more than a box length in half a step, NaN
+    ih = ih % a.g.nx;
+    if (ih < 0) ih += a.g.nx;
+  }
+  double *cl = sP + __mul24(ih, np1), *cr = cl + np1;
+  double t2 = 0.0;
+  if constexpr (MODE == MODE_FULLF) {
+    lds_add(cl, wh * p);
+    lds_add(cr, wr * p);
+  } else {
+    lds_add(cl, wh * n.w);
+    lds_add(cr, wr * n.w);
+    const double tmp1 = (MODE == MODE_DF_LIN) ? p : (p - n.w);
+    if constexpr (POW2 == 0) {
+      if (a.s.fastc) {
+        DivFast dv;
+        t2 = dlnf0<DIST, POW2>(n.v, a.s, dv);
+        if (!dv.ok()) {
+          DivTrue dt;
+          t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+        }
+      } else {
+        DivTrue dt;
+        t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+      }
+    } else {
+      DivTrue dt;
+      t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+    }
+    const double c = tmp1 * t2 * a.pred_k;
+    const double *gl = sAB + __mul24(ix, 2 * nm), *gr = gl + 2 * nm;
+    const double wlr = 1.0 - wl;
+#pragma unroll
+    for (int m = 0; m < nm; ++m) {
+      const double2 tl = *reinterpret_cast<const double2 *>(gl + 2 * m), tr = *reinterpret_cast<const double2 *>(gr + 2 * m);
+      const double A = fma(tr.x, wlr, tl.x * wl), B = fma(tr.y, wlr, tl.y * wl);  // (contraction is fine here)
+      const double cA = c * A, cB = c * B;
+      lds_add(cl + 1 + m, wh * cA);
+      lds_add(cr + 1 + m, wr * cA);
+      lds_add(cl + 1 + nm + m, wh * cB);
+      lds_add(cr + 1 + nm + m, wr * cB);
+    }
+  }
+  return t2;
+}
+
+// T2: 0 no carry of -f0'/f0; 1 this step evaluates it, the next step's value is stored; 2 this
+// step's value is loaded (stored by the previous k_step_one), the next step's stored
+template <int DIST, int MODE, int POW2, bool NT, int T2, int NM>
+__global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  exp_table_init();
+  const int nx = a.g.nx;
+  constexpr int nm = NM, np1 = 1 + 2 * NM;
+  const int ne = (nx + 2) & ~1;
+  double *sE0 = reinterpret_cast<double *>(smem);
+  double *sEh = sE0 + ne;
+  double *sAB = sEh + ne;                                        // [nx + 1][2 nm]: A_0 B_0 (A_1 B_1) per cell
+  double *sR0 = sAB + static_cast<size_t>(nx + 1) * 2 * nm;
+  double *sP = sR0 + ((nx * a.g.rcopies + 2) & ~1);              // [nx + 2][1 + 2 nm]: R0 RA_m RB_m per cell
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    sE0[i] = a.E0[i];
+    sEh[i] = a.Eh[i];
+  }
+  for (int i = threadIdx.x; i < nm * (nx + 1); i += blockDim.x) {
+    const int m = i / (nx + 1), c = i - m * (nx + 1), cs = c < nx ? c : 0;  // cell nx: the guard, = cell 0
+    sAB[c * 2 * nm + 2 * m] = a.tabA[m * nx + cs];
+    sAB[c * 2 * nm + 2 * m + 1] = a.tabB[m * nx + cs];
+  }
+  zero_rho(sR0, a.g);
+  for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
+  if (threadIdx.x == 0) {
+    sE0[nx] = a.E0[0];
+    sEh[nx] = a.Eh[0];
+  }
+  __syncthreads();
+  double *sR = my_rho_copy(sR0, a.g);
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
+  constexpr bool CARRY_IN = (T2 == 2) && HAS_W;
+  constexpr bool CARRY_OUT = (T2 != 0) && HAS_W;
+  const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double2 *x2 = reinterpret_cast<double2 *>(a.x);
+  double2 *v2 = reinterpret_cast<double2 *>(a.v);
+  double2 *w2 = reinterpret_cast<double2 *>(a.w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+  double2 *t2 = reinterpret_cast<double2 *>(a.t2);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+    const int64_t o = tidx2(j);
+    const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
+    double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
+    if constexpr (CARRY_IN) T = ld2t<NT>(t2 + j);
+    int i0, i1;
+    double l0, l1;
+    // the two markers of a pair one after the other (PAIR_FENCE): interleaving their four exp chains
+    // costs more registers than six waves per SIMD leave
+    const One n0 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x, &i0, &l0);
+    const double u0 = pred_one<DIST, MODE, POW2, NM>(n0, P.x, i0, l0, sAB, sP, a);
+    PAIR_FENCE();
+    const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y, &i1, &l1);
+    const double u1 = pred_one<DIST, MODE, POW2, NM>(n1, P.y, i1, l1, sAB, sP, a);
+    st2t<NT>(x2 + o, n0.x, n1.x);
+    if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
+    if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
+    if constexpr (CARRY_OUT) st2t<NT>(t2 + j, u0, u1);
+  }
+  if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = tidx(a.np - 1);
+    const double w = HAS_W ? a.w[i] : 0.0, p = a.p[i];
+    int ic;
+    double lc;
+    const One n = step_full_one<DIST, MODE, POW2, CARRY_IN>(a.x[i], a.v[i], w, p, sE0, sEh, sR, a,
+                                                            CARRY_IN ? a.t2[a.np - 1] : 0.0, &ic, &lc);
+    a.x[i] = n.x;
+    if constexpr (PUSH_V) a.v[i] = n.v;
+    if constexpr (HAS_W) a.w[i] = n.w;
+    const double u = pred_one<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP, a);
+    if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
+  }
+  __syncthreads();
+  flush_rho(sR0, a.rho, a.g);
+  // the guard cells nx, nx + 1 are cells 0, 1 (mod nx); then one global atomic per cell and slice
+  if (threadIdx.x < 2 * np1) {
+    const int g = threadIdx.x / np1, k = threadIdx.x - g * np1;
+    const int to = (nx + g) % nx;
+    if (g == 0 || to != 0 || nx > 1) lds_add(&sP[to * np1 + k], sP[(nx + g) * np1 + k]);
+  }
+  __syncthreads();
+  {
+    const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);
+    for (int i = threadIdx.x; i < np1 * nx; i += blockDim.x) {
+      const int k = i / nx;
+      int c = i - k * nx + rot;
+      if (c >= nx) c -= nx;
+      const double val = sP[c * np1 + k];
+      if (val != 0.0) glb_add(&a.pred[static_cast<size_t>(k) * nx + c], val);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_step_sums: the one pass per step for grids whose prediction tiles outgrow the LDS (nx > ~2400: the
+// Landau scaling run's nx = 4096), one kept mode.  Two observations replace five of k_step_one's tiles:
+// * the solve that turns the predicted half-step charge into Eh only ever looks at its projections on the
+//   kept mode's tables (src/pic1dp_field.F90:231-240), and the projection of a linear (CIC) deposit of q at x'
+//   is q times the gather of the table at x':  sum_c fre[c] deposit[c] = q A(x') / 2.  Hence, with
+//   c = dt/2 (p - w)(-f0'/f0)(v) Z/m at the marker's NEW state,
+//       sum_c fre[c] rho_h[c] = 1/2 [ K0c + re K1c + im K2c ],   K0c = sum_i Z w_i A(x'_i),
+//       K1c = sum_i Z c_i A(x_i) A(x'_i),  K2c = sum_i Z c_i B(x_i) A(x'_i),  and K0s, K1s, K2s with B(x'_i):
+//   six scalars per rank instead of three tiles -- accumulated in registers, reduced per workgroup, one
+//   global atomic each; when the new state's field is solved (re, im known) Eh follows from them
+//   (k_field_solve_pair_sums);
+// * Eh is its kept mode times the tables the kernel holds anyway: gathered from A, B and (re_h, im_h)
+//   (ModeField: the same bits as a staged tile of Eh).
+// LDS: E0, A, B, rho = 4 tiles (128 KiB at nx = 4096).  The six accumulators and the extra gathers cost
+// registers (101-117 VGPRs for the exp-bearing distributions: four waves per SIMD), which is why k_step_one
+// stays the kernel wherever its tiles fit (profiles/r02/experiments/pred_six_sums_*.log).
+// The second sub-step's push is untouched; Eh differs from the solve of a marker-by-marker deposit by
+// rounding only, as with k_step_one.  Full-f: q = p, K1 = K2 = 0.
+// ---------------------------------------------------------------------------
+struct PredSums {
+  double k0c = 0.0, k1c = 0.0, k2c = 0.0, k0s = 0.0, k1s = 0.0, k2s = 0.0;
+};
+
+// the six sums' terms of one marker in its NEW state n (x wrapped); (ix, wl): cell and left weight of n.x,
+// where the next step gathers its field (:250-257).  Returns -f0'/f0(n.v) for the carry.
+template <int DIST, int MODE, int POW2>
+__device__ __forceinline__ double pred_one_sums(const One &n, double p, int ix, double wl, const double *sA,
+                                                const double *sB, PredSums &k, const StepArgsDev &a) {
+  double t2 = 0.0;
+  double cA = 0.0, cB = 0.0;
+  if constexpr (MODE != MODE_FULLF) {
+    // the long chain first (-f0'/f0: exp, division), with little else alive
+    const double c = a.s.Z * pred_coef<DIST, MODE, POW2>(n.v, n.w, p, a.dt_half, a.s, t2);
+    PAIR_FENCE();
+    double A = sA[ix] * wl;                       // tables at x: the field the half push will see
+    A = A + sA[ix + 1] * (1.0 - wl);
+    double B = sB[ix] * wl;
+    B = B + sB[ix + 1] * (1.0 - wl);
+    cA = c * A, cB = c * B;
+  }
+  double xh = n.x + a.dt_half * n.v;              // the next step's half push of x (:261)
+  xh = wrap(xh, a.g.lx);                          // and the wrap + cell of its deposit (:102-108)
+  int ih;
+  double wh;
+  locate(xh, a.g, ih, wh);
+  double Ah = sA[ih] * wh;                        // tables at x': the deposit's projection weights
+  Ah = Ah + sA[ih + 1] * (1.0 - wh);
+  double Bh = sB[ih] * wh;
+  Bh = Bh + sB[ih + 1] * (1.0 - wh);
+  const double q = a.s.Z * (MODE == MODE_FULLF ? p : n.w);
+  k.k0c += q * Ah;
+  k.k0s += q * Bh;
+  if constexpr (MODE != MODE_FULLF) {
+    k.k1c += cA * Ah;
+    k.k2c += cB * Ah;
+    k.k1s += cA * Bh;
+    k.k2s += cB * Bh;
+  }
+  return t2;
+}
+
+template <int DIST, int MODE, int POW2, bool NT, int T2>
+__global__ void __launch_bounds__(1024) k_step_sums(const StepArgsDev a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  exp_table_init();
+  const int nx = a.g.nx;
+  const int ne = (nx + 2) & ~1;
+  double *sE0 = reinterpret_cast<double *>(smem);
+  double *sA = sE0 + ne;
+  double *sB = sA + ne;
+  double *sR0 = sB + ne;
+  double *sScr = sR0 + ((nx * a.g.rcopies + 2) & ~1);  // [16] reduction scratch
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    sE0[i] = a.E0[i];
+    sA[i] = a.tabA[i];
+    sB[i] = a.tabB[i];
+  }
+  zero_rho(sR0, a.g);
+  if (threadIdx.x == 0) {
+    sE0[nx] = a.E0[0];
+    sA[nx] = a.tabA[0];
+    sB[nx] = a.tabB[0];
+  }
+  __syncthreads();
+  const ModeField sEh{sA, sB, *a.eh_re, *a.eh_im};
+  double *sR = my_rho_copy(sR0, a.g);
+  constexpr bool HAS_W = (MODE != MODE_FULLF);
+  constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
+  constexpr bool CARRY_IN = (T2 == 2) && HAS_W;
+  constexpr bool CARRY_OUT = (T2 != 0) && HAS_W;
+  PredSums ks;
+  const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double2 *x2 = reinterpret_cast<double2 *>(a.x);
+  double2 *v2 = reinterpret_cast<double2 *>(a.v);
+  double2 *w2 = reinterpret_cast<double2 *>(a.w);
+  const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
+  double2 *t2 = reinterpret_cast<double2 *>(a.t2);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+    const int64_t o = tidx2(j);
+    const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
+    double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);
+    if constexpr (HAS_W) W = ld2t<NT>(w2 + o);
+    if constexpr (CARRY_IN) T = ld2t<NT>(t2 + j);
+    int i0, i1;
+    double l0, l1;
+    const One n0 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x, &i0, &l0);
+    PAIR_FENCE();
+    const double u0 = pred_one_sums<DIST, MODE, POW2>(n0, P.x, i0, l0, sA, sB, ks, a);
+    PAIR_FENCE();
+    const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y, &i1, &l1);
+    PAIR_FENCE();
+    const double u1 = pred_one_sums<DIST, MODE, POW2>(n1, P.y, i1, l1, sA, sB, ks, a);
+    st2t<NT>(x2 + o, n0.x, n1.x);
+    if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
+    if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
+    if constexpr (CARRY_OUT) st2t<NT>(t2 + j, u0, u1);
+  }
+  if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = tidx(a.np - 1);
+    const double w = HAS_W ? a.w[i] : 0.0, p = a.p[i];
+    int ic;
+    double lc;
+    const One n = step_full_one<DIST, MODE, POW2, CARRY_IN>(a.x[i], a.v[i], w, p, sE0, sEh, sR, a,
+                                                            CARRY_IN ? a.t2[a.np - 1] : 0.0, &ic, &lc);
+    a.x[i] = n.x;
+    if constexpr (PUSH_V) a.v[i] = n.v;
+    if constexpr (HAS_W) a.w[i] = n.w;
+    const double u = pred_one_sums<DIST, MODE, POW2>(n, p, ic, lc, sA, sB, ks, a);
+    if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
+  }
+  __syncthreads();
+  flush_rho(sR0, a.rho, a.g);
+  // the six sums: workgroup reduction, one global atomic each
+  const double r0 = block_sum(ks.k0c, sScr), r1 = block_sum(ks.k1c, sScr), r2 = block_sum(ks.k2c, sScr);
+  const double r3 = block_sum(ks.k0s, sScr), r4 = block_sum(ks.k1s, sScr), r5 = block_sum(ks.k2s, sScr);
+  if (threadIdx.x == 0) {
+    glb_add(a.pred + 0, r0);
+    glb_add(a.pred + 1, r1);
+    glb_add(a.pred + 2, r2);
+    glb_add(a.pred + 3, r3);
+    glb_add(a.pred + 4, r4);
+    glb_add(a.pred + 5, r5);
+  }
+}
+
+template <typename K>
+hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
+  if (lc.lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (idempotent, cheap)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PARTICLE_LDS_CAP);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(lc.blocks), dim3(lc.threads), lc.lds, st, d);
+  return hipGetLastError();
+}
+
+static_assert(PRED_MAX_MODES == 2, "k_step_one is instantiated for one and two kept modes");
+template <int DIST, int MODE, int POW2, int NM>
+hipError_t launch_step_one(const StepArgsDev &d, int t2m, const LaunchCfg &lc, hipStream_t st) {
+  if (d.nt) {
+    if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, NM>, d, lc, st);
+    if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, NM>, d, lc, st);
+    return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, NM>, d, lc, st);
+  }
+  if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, NM>, d, lc, st);
+  if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, NM>, d, lc, st);
+  return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, NM>, d, lc, st);
+}
+
+template <int DIST, int MODE, int POW2, bool CARRY = false>
+hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
+  if (full && d.pred && d.pred_nm < 0) {  // one pass per step, prediction as six sums (large grids)
+    const int t2m = d.t2 ? d.t2_mode : 0;
+    if (d.nt) {
+      if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 2>, d, lc, st);
+      if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1>, d, lc, st);
+      return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 0>, d, lc, st);
+    }
+    if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 2>, d, lc, st);
+    if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 1>, d, lc, st);
+    return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 0>, d, lc, st);
+  }
+  if (full && d.pred) {  // one pass per step: also predicts the next step's first-sub-step charge
+    const int t2m = d.t2 ? d.t2_mode : 0;
+    if (d.pred_nm == 1) return launch_step_one<DIST, MODE, POW2, 1>(d, t2m, lc, st);
+    if (d.pred_nm == 2) return launch_step_one<DIST, MODE, POW2, 2>(d, t2m, lc, st);
+    return hipErrorInvalidValue;  // PRED_MAX_MODES
+  }
+  if (full && d.dist_out)  // with the diagnostics of output_all
+    return d.nt ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY, true>, d, lc, st)
+                : launch_step_kernel(k_step_full<DIST, MODE, POW2, false, CARRY, true>, d, lc, st);
+  if (d.nt)
+    return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY, false>, d, lc, st)
+                : launch_step_kernel(k_step_half<DIST, MODE, POW2, true, CARRY>, d, lc, st);
+  return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, false, CARRY, false>, d, lc, st)
+              : launch_step_kernel(k_step_half<DIST, MODE, POW2, false, CARRY>, d, lc, st);
+}
+
+template <int DIST>
+hipError_t launch_step_d(const StepArgsDev &d, int deltaf, int linear, bool full, const LaunchCfg &lc,
+                         hipStream_t st) {
+  const bool pow2 = d.s.pow2 != 0;
+  // full-f evaluates no f0 derivative (one instantiation serves all DIST), but
+  // still divides by the mass in the v push
+  if (!deltaf) {
+    if constexpr (DIST == 0)
+      return pow2 ? launch_step_dmp<0, MODE_FULLF, 1>(d, full, lc, st)
+                  : launch_step_dmp<0, MODE_FULLF, 0>(d, full, lc, st);
+    return hipErrorInvalidValue;  // step_dispatch.cpp sends every full-f species to the DIST 0 unit
+  }
+  // general divisor constants and an exp-bearing distribution: -f0'/f0 carried between the kernels
+  const bool carry = !pow2 && d.t2 != nullptr && (DIST == 2 || DIST == 3);
+  if (linear) {
+    if constexpr (DIST == 2 || DIST == 3)
+      if (carry) return launch_step_dmp<DIST, MODE_DF_LIN, 0, true>(d, full, lc, st);
+    return pow2 ? launch_step_dmp<DIST, MODE_DF_LIN, 1>(d, full, lc, st)
+                : launch_step_dmp<DIST, MODE_DF_LIN, 0>(d, full, lc, st);
+  }
+  if (d.s.unit) return launch_step_dmp<DIST, MODE_DF_NL, 2>(d, full, lc, st);
+  if constexpr (DIST == 2 || DIST == 3)
+    if (carry) return launch_step_dmp<DIST, MODE_DF_NL, 0, true>(d, full, lc, st);
+  return pow2 ? launch_step_dmp<DIST, MODE_DF_NL, 1>(d, full, lc, st)
+              : launch_step_dmp<DIST, MODE_DF_NL, 0>(d, full, lc, st);
+}
+
+}  // namespace
+
+template <>
+hipError_t launch_step_dist<PIC1DP_STEP_DIST>(const StepArgsDev &d, int deltaf, int linear, bool full, const LaunchCfg &lc,
+                                              hipStream_t st) {
+  return launch_step_d<PIC1DP_STEP_DIST>(d, deltaf, linear, full, lc, st);
+}
+
+}  // namespace pic1dp

@@ -157,14 +157,6 @@ class Pic1dp:
         1: two fused sub-steps through the RK ping-pong sets"""
         check(self.L.pic1dp_hip_set_step_mode(self._ctx, mode))
 
-    def layout_probe(self, n, log2_tile=12, reps=10):
-        """pure streams of the whole-step kernels' traffic shape over a fresh slab (tuning / bench denominator):
-        ms per launch of [arrays apart r/w, tiled r/w, arrays apart read-only, tiled read-only, tiled r/w one
-        workgroup per tile, the same read-only]; r/w = 4 arrays of n doubles read, 3 written back in place"""
-        ms = (C.c_double * 6)()
-        check(self.L.pic1dp_hip_debug_layout_probe(self._ctx, int(n), log2_tile, 0, reps, 0, ms))
-        return list(ms)
-
     def predict_kind(self):
         """how step mode 0 predicts the next first sub-step's charge: 0 not (two passes per step),
         1 prediction tiles (k_step_one), 2 six sums (k_step_sums, large grids)"""
@@ -340,14 +332,17 @@ class Pic1dp:
     def set_launch(self, threads=0, blocks_per_cu=0):
         check(self.L.pic1dp_hip_set_launch(self._ctx, threads, blocks_per_cu))
 
-    def stream_probe(self, nread, nwrite, n, reps=10):
-        """measured GB/s of a pure streaming pass with the kernels' access shape"""
-        g = C.c_double()
-        check(self.L.pic1dp_hip_stream_probe(self._ctx, nread, nwrite, n, reps, C.byref(g)))
-        return g.value
-
     def kernel_stats_enable(self, on=True):
         check(self.L.pic1dp_hip_kernel_stats_enable(self._ctx, int(on)))
+
+    def kernel_bytes(self, which=6):
+        """what the marker kernel launched last under `which` (kernel_stats numbering) moves per marker and
+        launch: dict(read, written, carry, name) -- read + written are compulsory for its data flow, carry
+        is the traffic it chooses to spend on not evaluating -f0'/f0 again"""
+        rd, wr, ca = C.c_double(), C.c_double(), C.c_double()
+        name = C.create_string_buffer(64)
+        check(self.L.pic1dp_hip_kernel_bytes(self._ctx, which, C.byref(rd), C.byref(wr), C.byref(ca), name, 64))
+        return dict(read=rd.value, written=wr.value, carry=ca.value, name=name.value.decode())
 
     def kernel_stats(self, which=0):
         ms, n = C.c_double(), C.c_int64()

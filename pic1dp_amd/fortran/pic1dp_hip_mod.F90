@@ -109,50 +109,6 @@ interface
     integer(c_int64_t), value :: n
     integer(c_int) :: ierr
   end function pic1dp_hip_host_multirand_int64
-  function pic1dp_hip_host_div_check(lx, nx, n, seed, mismatches) bind(C, name="pic1dp_hip_host_div_check") result(ierr)
-    import
-    real(c_double), value :: lx
-    integer(c_int32_t), value :: nx
-    integer(c_int64_t), value :: n
-    integer(c_int64_t), value :: seed
-    integer(c_int64_t), intent(out) :: mismatches
-    integer(c_int) :: ierr
-  end function pic1dp_hip_host_div_check
-  function pic1dp_hip_debug_div_check(ctx, n, seed, mismatches) bind(C, name="pic1dp_hip_debug_div_check") result(ierr)
-    import
-    type(c_ptr), value :: ctx
-    integer(c_int64_t), value :: n
-    integer(c_int64_t), value :: seed
-    integer(c_int64_t), intent(out) :: mismatches
-    integer(c_int) :: ierr
-  end function pic1dp_hip_debug_div_check
-  function pic1dp_hip_host_divc_check(divisor, n, seed, mismatches) bind(C, name="pic1dp_hip_host_divc_check") result(ierr)
-    import
-    real(c_double), value :: divisor
-    integer(c_int64_t), value :: n
-    integer(c_int64_t), value :: seed
-    integer(c_int64_t), intent(out) :: mismatches
-    integer(c_int) :: ierr
-  end function pic1dp_hip_host_divc_check
-  function pic1dp_hip_debug_divc_check(ctx, ispecies, n, seed, mismatches) bind(C, name="pic1dp_hip_debug_divc_check") result(ierr)
-    import
-    type(c_ptr), value :: ctx
-    integer(c_int32_t), value :: ispecies
-    integer(c_int64_t), value :: n
-    integer(c_int64_t), value :: seed
-    integer(c_int64_t), intent(out) :: mismatches
-    integer(c_int) :: ierr
-  end function pic1dp_hip_debug_divc_check
-  function pic1dp_hip_stream_probe(ctx, nread, nwrite, n, reps, gbytes_per_s) bind(C, name="pic1dp_hip_stream_probe") result(ierr)
-    import
-    type(c_ptr), value :: ctx
-    integer(c_int32_t), value :: nread
-    integer(c_int32_t), value :: nwrite
-    integer(c_int64_t), value :: n
-    integer(c_int32_t), value :: reps
-    real(c_double), intent(out) :: gbytes_per_s
-    integer(c_int) :: ierr
-  end function pic1dp_hip_stream_probe
   function pic1dp_hip_create(inp, layout, ctx) bind(C, name="pic1dp_hip_create") result(ierr)
     import
     type(pic1dp_input_t), intent(in) :: inp
@@ -432,26 +388,6 @@ interface
     integer(c_int64_t), intent(out) :: exchanges
     integer(c_int) :: ierr
   end function pic1dp_hip_xchg_info
-  function pic1dp_hip_debug_exp(ctx, x, y, n) bind(C, name="pic1dp_hip_debug_exp") result(ierr)
-    import
-    type(c_ptr), value :: ctx
-    real(c_double), intent(in) :: x(*)
-    real(c_double), intent(out) :: y(*)
-    integer(c_int64_t), value :: n
-    integer(c_int) :: ierr
-  end function pic1dp_hip_debug_exp
-  function pic1dp_hip_debug_layout_probe(ctx, n, log2_tile, stagger_bytes, reps, keep, ms) &
-      bind(C, name="pic1dp_hip_debug_layout_probe") result(ierr)
-    import
-    type(c_ptr), value :: ctx
-    integer(c_int64_t), value :: n
-    integer(c_int32_t), value :: log2_tile
-    integer(c_int64_t), value :: stagger_bytes
-    integer(c_int32_t), value :: reps
-    integer(c_int32_t), value :: keep
-    real(c_double), intent(out) :: ms(6)
-    integer(c_int) :: ierr
-  end function pic1dp_hip_debug_layout_probe
   function pic1dp_hip_timers_enable(ctx, on) bind(C, name="pic1dp_hip_timers_enable") result(ierr)
     import
     type(c_ptr), value :: ctx
@@ -497,6 +433,18 @@ interface
     integer(c_int32_t), value :: on
     integer(c_int) :: ierr
   end function pic1dp_hip_kernel_stats_enable
+  function pic1dp_hip_kernel_bytes(ctx, which, read_bytes, written_bytes, carry_bytes, name, name_len) &
+      bind(C, name="pic1dp_hip_kernel_bytes") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: which
+    real(c_double), intent(out) :: read_bytes
+    real(c_double), intent(out) :: written_bytes
+    real(c_double), intent(out) :: carry_bytes
+    character(kind=c_char), intent(out) :: name(*)
+    integer(c_int32_t), value :: name_len
+    integer(c_int) :: ierr
+  end function pic1dp_hip_kernel_bytes
 end interface
 
 contains

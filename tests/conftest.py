@@ -29,6 +29,15 @@ def amd():
     return pic1dp_amd
 
 
+@pytest.fixture(scope="session")
+def probe():
+    """libpic1dp_probe.so (measurement / test support, include/pic1dp_probe.h): array evaluations of the
+    device functions the marker kernels call, and the streaming probes"""
+    from pic1dp_amd import probe as mod
+    mod.load()
+    return mod
+
+
 # input keyword sets shared by CPU and GPU tests: (id, kwargs)
 DIST_CASES = [
     ("bump_on_tail", dict()),

@@ -155,3 +155,124 @@ def test_random_call_sequences_lazy_equals_eager(amd, monkeypatch, seed):
             for e in (a, b):
                 e.particle_optimize(2)
     same("end: " + " ".join(log[-8:]))
+
+
+@pytest.mark.parametrize("kind", [1, 2], ids=["tiles", "sums"])
+@pytest.mark.parametrize("seed", range(10))
+def test_random_call_sequences_predicted_equals_two_pass(amd, monkeypatch, seed, kind):
+    """differential test of the state machine behind the one-pass step (state_version,
+    field_version, pred_version, eh_*, t2_version, cd_lazy, lz): random VALID sequences of every entry point that
+    reads, bumps or voids one of them -- step(n), substep, the three call sites, the split-phase deposit
+    (charge_local / charge_reduced), set_chargeden, set_electric, set_field_solver, diagnostics, downloads --
+    on the default engine (lazy call sites, prediction as tiles or as the six sums) and on one that runs every
+    call eagerly with two marker passes per step (PIC1DP_LAZY_CALLS=0, PIC1DP_PREDICT=0).  The prediction is the
+    same algebra regrouped, so the two follow each other to rounding: fields, energies and markers within
+    1e-10 at every look and at the end -- a stale prediction, a stale carry or a stale half-step field would show
+    at 1e-5 (the size of the perturbation) or worse."""
+    rng = np.random.default_rng(7000 + seed)
+    dist = int(rng.choice([0, 2, 3, 3]))
+    kw = dict(nparticle_max=30001, nx=int(rng.choice([32, 64, 96])), iptcldist=dist,
+              linear=int(rng.random() < 0.25), init_mode_sin=[1e-3])
+    if dist == 2:
+        kw.update(species_density=[1.0], species_v0=[3.0])
+    if rng.random() < 0.3:
+        kw.update(species_temperature=[1.3], species_temperature2=[0.7], species_mass=[1.1])
+    monkeypatch.setenv("PIC1DP_PRED_KIND", str(kind))
+    a = amd.Pic1dp(amd.make_input(**kw))
+    monkeypatch.setenv("PIC1DP_LAZY_CALLS", "0")
+    monkeypatch.setenv("PIC1DP_PREDICT", "0")
+    b = amd.Pic1dp(amd.make_input(**kw))
+    monkeypatch.delenv("PIC1DP_LAZY_CALLS")
+    monkeypatch.delenv("PIC1DP_PREDICT")
+    assert a.predict_kind() == kind and b.predict_kind() == 0
+    for e in (a, b):
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+    nx = kw["nx"]
+    TOL = 1e-10
+
+    def close(x, y, what):
+        scale = max(np.max(np.abs(y)), 1e-300)
+        assert np.max(np.abs(x - y)) <= TOL * scale, (what, log[-8:], float(np.max(np.abs(x - y)) / scale))
+
+    def look(tag):
+        ga, gb = a.particles_download(), b.particles_download()
+        for k in "xvw":
+            close(ga[k], gb[k], (tag, k))
+        fa, fb = a.get_field(), b.get_field()
+        close(fa["electric"], fb["electric"], (tag, "E"))
+
+    def sub_step(irk, how):
+        """one RK sub-step, four ways"""
+        if how == "substep":
+            for e in (a, b):
+                e.substep(irk)
+            return
+        for e in (a, b):
+            e.interaction_push_particle(irk)
+        if how == "host_sum":                   # a host that owns the reduction (MPI): charge_local / charge_reduced
+            for e in (a, b):
+                e.charge_reduced(e.charge_local())
+        elif how == "set_cd":                   # ... or that hands the charge density in itself
+            for e in (a, b):
+                e.interaction_collect_charge()
+            cd = b.get_field()["chargeden"]
+            if not (kind == 2 and irk == 1):    # with the six sums a's chargeden holds the kept mode's content only
+                close(a.get_field()["chargeden"], cd, "chargeden")
+            for e in (a, b):
+                e.set_chargeden(cd)
+        else:
+            for e in (a, b):
+                e.interaction_collect_charge()
+        for e in (a, b):
+            e.field_solve_electric()
+
+    log, phase, fd = [], 0, 0
+    for i in range(40):
+        r = rng.random()
+        if phase == 1:                          # mid-step: finish it, perhaps after a look or a field change
+            op = str(rng.choice(["sub2", "sub2", "sub2", "look", "setE", "sums"]))
+        elif r < 0.45:
+            op = "step"
+        elif r < 0.75:
+            op = "sub1"
+        else:
+            op = str(rng.choice(["look", "setE", "sums", "dist", "solver", "resolve"]))
+        log.append(op)
+        if op == "step":
+            n = int(rng.integers(1, 4))
+            for e in (a, b):
+                e.step(n)
+        elif op in ("sub1", "sub2"):
+            how = str(rng.choice(["calls", "calls", "substep", "host_sum", "set_cd"]))
+            log[-1] = op + ":" + how
+            sub_step(int(op[-1]), how)
+            phase = 1 - phase
+        elif op == "look":
+            look("look")
+        elif op == "setE":
+            E = 0.02 * np.sin(2 * np.pi * np.arange(nx) / nx + rng.random()) + 0.002 * rng.standard_normal(nx)
+            for e in (a, b):
+                e.set_electric(E)
+        elif op == "sums":
+            assert np.allclose(a.energy_sums(), b.energy_sums(), rtol=1e-9, atol=0)
+        elif op == "dist":
+            da, db = a.ptcldist(0, finish=False), b.ptcldist(0, finish=False)
+            assert np.allclose(da["markr_xv"], db["markr_xv"], rtol=1e-9, atol=1e-9)
+        elif op == "solver":                    # the opt-in finite-difference solver and back
+            fd = 1 - fd
+            for e in (a, b):
+                e.set_field_solver(fd)
+        elif op == "resolve":                   # solve again from the chargeden at hand (an out-of-order solve_field)
+            for e in (a, b):
+                e.field_solve_electric()
+    if phase == 1:
+        sub_step(2, "calls")
+    for e in (a, b):
+        e.step(2)
+    look("end")
+    ha, hb = a.energy_history(), b.energy_history()
+    assert len(ha) == len(hb)
+    if len(hb):
+        close(ha, hb, "energy history")

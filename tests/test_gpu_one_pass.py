@@ -1,4 +1,4 @@
-"""One pass over the markers per time step (kernels.hip k_step_one): the second sub-step's
+"""One pass over the markers per time step (kernels_step.hip k_step_one): the second sub-step's
 kernel also deposits what the NEXT step's first sub-step would deposit, as coefficients of the
 kept field modes (the half push is linear in the field it sees, src/pic1dp_interaction.F90:261,
 268-329; the field is its kept modes times fixed tables, src/pic1dp_field.F90:251-257), so from
@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 N = 200_001
 
 
-def engine(amd, monkeypatch, predict, kind=None, **kw):
+def engine(amd, monkeypatch, predict, kind=None, npe=1, **kw):
     """kind 2: the large-grid kernel (k_step_sums: prediction as six sums, Eh from its kept mode) insisted on"""
     monkeypatch.setenv("PIC1DP_PREDICT", "1" if predict else "0")
     if kind == 2 and predict:
         monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
     else:
         monkeypatch.delenv("PIC1DP_PRED_KIND", raising=False)
-    e = amd.Pic1dp(amd.make_input(**kw))
+    e = amd.Pic1dp(amd.make_input(**kw), npe=npe)
     e.particle_load()
     e.interaction_collect_charge()
     e.field_solve_electric()
@@ -82,6 +82,37 @@ def test_one_pass_against_oracle(oracle_mod, amd, monkeypatch, kind):
 
 
 @pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
+@pytest.mark.parametrize("name,kw", DIST_CASES, ids=[c[0] for c in DIST_CASES])
+@pytest.mark.parametrize("mname,mkw", MODES, ids=[m[0] for m in MODES])
+def test_one_pass_against_oracle_every_distribution(oracle_mod, amd, monkeypatch, name, kw, mname, mkw, kind):
+    """the path the bench times against the CPU arithmetic DIRECTLY, for every distribution and mode (not through
+    the two-pass engine): field energy at every one of 80 steps within 1e-10, markers to 1e-9 at the end"""
+    if mkw.get("deltaf") == 0 and name != "maxwellian":
+        pytest.skip("full-f evaluates no f0 derivative: one distribution covers it")
+    kw = dict(kw, nparticle_max=N, nx=64, **mkw)
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    eng = engine(amd, monkeypatch, True, kind, **kw)
+    assert eng.predict_kind() == kind
+    eng.kernel_stats_enable(True)
+    nsteps = 80
+    eo = []
+    for _ in range(nsteps):
+        sim.step(1)
+        eo.append(sim.field_energy())
+    eng.step(nsteps)
+    assert np.max(np.abs(eng.energy_history() / np.array(eo) - 1.0)) < 1e-10
+    assert eng.kernel_stats(3)[1] == 1 and eng.kernel_stats(6)[1] == nsteps
+    g = eng.particles_download()
+    assert np.max(np.abs(g["x"] - sim.gather("x"))) < 1e-9
+    assert np.max(np.abs(g["v"] - sim.gather("v"))) < 1e-9
+    if kw.get("deltaf", 1):
+        assert np.max(np.abs(g["w"] - sim.gather("w"))) < 1e-9 * max(1.0, np.max(np.abs(sim.gather("w"))))
+
+
+@pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
 def test_one_pass_through_the_call_sites(amd, monkeypatch, kind):
     """the reference's three call sites: collect_charge after push(1) combines the prediction
     (no marker pass), its chargeden is the eager deposit's to rounding -- with the six sums: the kept mode's
@@ -124,7 +155,8 @@ def test_one_pass_through_the_call_sites(amd, monkeypatch, kind):
                                      species_density=[1.0, 1.0], species_v0=[0.0, 0.0], lx=4 * np.pi)],
                          ids=["nx96", "nx1000", "nx2050_full_f", "two_species"])
 @pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
-def test_lean_pair_solve_equals_the_plain_one(oracle_mod, amd, monkeypatch, kw, kind):
+@pytest.mark.parametrize("npe", [1, 4, 9], ids=lambda v: "npe%d" % v)
+def test_lean_pair_solve_equals_the_plain_one(oracle_mod, amd, monkeypatch, kw, kind, npe):
     """k_field_solve_pair1 / k_field_solve_pair_sums1 (one kept mode: everything that does not wait for the
     serial sums in front of them) against k_field_solve_pair / k_field_solve_pair_sums: the predicted half-step field and the run to rounding; and the field of the
     new state from ITS charge density against the oracle's solve bit for bit, both kernels"""
@@ -132,9 +164,9 @@ def test_lean_pair_solve_equals_the_plain_one(oracle_mod, amd, monkeypatch, kw, 
     if kind == 2 and kw["nx"] == 1000:
         kw["nx"] = 4096               # the grid the sums are for: 1024 threads, four cells each
     monkeypatch.setenv("PIC1DP_PAIR_PLAIN", "1")
-    a = engine(amd, monkeypatch, True, kind, **kw)
+    a = engine(amd, monkeypatch, True, kind, npe, **kw)
     monkeypatch.delenv("PIC1DP_PAIR_PLAIN")
-    b = engine(amd, monkeypatch, True, kind, **kw)
+    b = engine(amd, monkeypatch, True, kind, npe, **kw)
     assert a.predict_kind() == kind and b.predict_kind() == kind
     field = oracle_mod.Field(oracle_mod.make_input(**kw))
     for it in range(4):
@@ -144,7 +176,7 @@ def test_lean_pair_solve_equals_the_plain_one(oracle_mod, amd, monkeypatch, kw, 
         assert relerr(fa["electric"], fb["electric"]) < 1e-11, it
         assert relerr(a.get_field_half(), b.get_field_half()) < 1e-11, it
         for f in (fa, fb):
-            E, re, im = field.solve(f["chargeden"])
+            E, re, im = field.solve(f["chargeden"], npe)   # in the order of an npe-rank reference run
             assert np.array_equal(f["electric"], E) and np.array_equal(f["mode_re"], re) and np.array_equal(f["mode_im"], im)
     assert np.max(np.abs(a.energy_history() / b.energy_history() - 1.0)) < 1e-11
 

@@ -63,6 +63,78 @@ def w_cancellation(inp, v):
     return np.where(np.isfinite(k), k, 1e300)
 
 
+def dlnf0_pieces(inp, v):
+    """-f0'/f0 of the two-Maxwellian distributions in extended precision, in the pieces the error bounds below
+    are made of (src/pic1dp_interaction.F90:278-321; pic1dp_amd/csrc/device_math.hpp dlnf0_one_exp): with rho the
+    ratio of the two Maxwellians and L = ln rho, tmp2 = (A + rho B)/(1 + rho) = M + D tanh(L/2).
+    Returns dict(tmp2, M, D, L, argmag = the magnitude of the two exp arguments the reference form rounds,
+    Lmag = the magnitude of the terms the one-exp form's L is summed from)."""
+    ld = np.longdouble
+    v = np.asarray(v, dtype=ld)
+    T, T2, m = ld(inp.species_temperature[0]), ld(inp.species_temperature2[0]), ld(inp.species_mass[0])
+    den, v0 = ld(inp.species_density[0]), ld(inp.species_v0[0])
+    tm, tm2 = T / m, T2 / m
+    if inp.iptcldist == 3:
+        A, B = v / tm, (v - v0) / tm2
+        lnK = np.log((1 - den) * np.sqrt(tm)) - np.log(den * np.sqrt(tm2))
+        a1, a2 = v * v / (2 * tm), (v - v0) ** 2 / (2 * tm2)
+        L = lnK + a1 - a2
+        h1, h2 = 1 / (2 * tm), 1 / (2 * tm2)
+        Lmag = np.abs(h1 - h2) * v * v + np.abs(2 * h2 * v0 * v) + np.abs(lnK - h2 * v0 * v0)
+    elif inp.iptcldist == 2:
+        A, B = (v - v0) / tm, (v + v0) / tm
+        a1, a2 = (v + v0) ** 2 / (2 * tm), (v - v0) ** 2 / (2 * tm)
+        L = -2 * v * v0 / tm
+        Lmag = np.abs(L)
+    else:
+        raise ValueError("no exp in this distribution")
+    M, D = (A + B) / 2, (B - A) / 2
+    return dict(tmp2=M + D * np.tanh(L / 2), M=M, D=D, L=L, argmag=a1 + a2, argmax=np.maximum(a1, a2), Lmag=Lmag)
+
+
+def dlnf0_bound(pc, one_exp):
+    """how far an evaluation of -f0'/f0 may lie from the exact value (absolute).  The ratio rho of the two
+    Maxwellians carries the rounding of the exp arguments -- relative 2^-53 each, i.e. ABSOLUTE |argument| 2^-53
+    in the exponent -- plus the exp itself (EXP_ULP_MAX) and a few operations; it enters tmp2 with the
+    sensitivity D 2 rho/(1 + rho)^2 <= D/2; M and D t then round at the scale |M| + |D| (where they cancel --
+    the minimum of f0 between the two humps -- that is the kappa of the reference's numerator)."""
+    f = np.float64
+    E = np.exp(-np.abs(pc["L"]))
+    sens = 2 * E / (1 + E) ** 2
+    mag = 3 * pc["Lmag"] if one_exp else 2 * pc["argmag"]
+    drho = EPS * (mag + 2 * (EXP_ULP_MAX + 1) + 8)
+    with np.errstate(invalid="ignore"):
+        ratio_term = np.where(sens > 0, np.abs(pc["D"]) * sens * drho, 0)     # one Maxwellian absent: rho = 0 or inf
+    return (ratio_term + 8 * EPS * (np.abs(pc["M"]) + np.abs(pc["D"]))).astype(f)
+
+
+def assert_w_close_one_exp(inp, v, w_gpu, w_orc, wb_orc):
+    """w = wb + dt tmp1 tmp2 Z/m (:329) with tmp2 from the one-exp form on the device and from the reference's
+    operation order in the CPU arithmetic: both lie within their bound of the exact value (dlnf0_bound), the
+    update is tmp2 times dt tmp1 Z/m = upd / tmp2, three products and a division add 3 ulp of the update, the
+    final sum half an ulp of w"""
+    pc = dlnf0_pieces(inp, v)
+    upd = np.abs(w_orc - wb_orc)
+    tmp2 = np.abs(pc["tmp2"]).astype(np.float64)
+    d = dlnf0_bound(pc, True) + dlnf0_bound(pc, False)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        scale = np.where(tmp2 > 4 * d, upd / (tmp2 - d), np.inf)   # |dt tmp1 Z/m|, from the oracle's own update
+    tol = 2.0 * (scale * d + 3 * EPS * upd + 0.5 * EPS * np.abs(w_orc)) + 1e-300
+    # where tmp2 itself is within a few bounds of zero the update is rounding: bound by the weights' scale
+    tol = np.where(np.isfinite(tol), tol, 64 * EPS * (np.abs(w_orc) + np.abs(wb_orc)))
+    err = np.abs(w_gpu - w_orc)
+    bad = err > tol
+    assert not bad.any(), "w off by %g (tolerance %g, update %g, tmp2 %g) at %d of %d" % (
+        err[bad].max(), tol[bad][np.argmax(err[bad])], upd[bad][np.argmax(err[bad])], tmp2[bad][np.argmax(err[bad])],
+        np.flatnonzero(bad)[0], bad.sum())
+
+
+def one_exp_active(probe, inp):
+    """does the library evaluate -f0'/f0 of this input's species in the one-exp form (default for iptcldist 2, 3;
+    PIC1DP_DLNF0=ref: the reference's operation order)"""
+    return inp.deltaf == 1 and probe.species_const(probe.species(inp))["one_exp"] == 1
+
+
 def assert_w_close(w_gpu, w_orc, wb_orc, exact, kappa=None):
     """w = wb + dt*tmp1*tmp2*Z/m (:329).  Everything but exp() is the same IEEE
     operation on both sides; with exp within EXP_ULP_MAX ulp of libm each of the four
@@ -84,7 +156,7 @@ def assert_w_close(w_gpu, w_orc, wb_orc, exact, kappa=None):
         np.flatnonzero(bad)[0])
 
 
-def test_device_exp_against_libm(oracle_mod, amd):
+def test_device_exp_against_libm(oracle_mod, probe):
     """the one operation of the push that is not bit-identical by construction: the
     device's exp (OCML) against libm's on the arguments the weight equation forms,
     -(v -+ v0)^2 / (2T/m) with |v| <= v_max + drift: [-260, 0], dense near 0, plus the
@@ -93,9 +165,7 @@ def test_device_exp_against_libm(oracle_mod, amd):
     rng = np.random.default_rng(7)
     x = np.concatenate([-260.0 * rng.random(3_000_000), -rng.random(1_000_000) ** 4, -745.0 * rng.random(500_000),
                         700.0 * rng.random(500_000), -np.logspace(-300, 2, 20001), [0.0, -0.0]])
-    eng = amd.Pic1dp(amd.make_input(nparticle_max=1000, nx=16))
-    y = np.empty_like(x)
-    amd._lib.check(eng.L.pic1dp_hip_debug_exp(eng._ctx, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size))
+    y = probe.device_exp(x)
     ref = np.empty_like(x)
     oracle_mod.lib().orc_exp_array(x, ref, x.size)
     d = ulp_diff(y, ref)
@@ -103,6 +173,50 @@ def test_device_exp_against_libm(oracle_mod, amd):
     # and it is not the same function: a silent switch to a bit-identical exp would make the
     # exp-bearing w comparisons exact -- worth knowing, not an error
     print("device exp vs libm: max %d ulp, %.3f %% of arguments differ" % (d.max(), 100.0 * np.mean(d > 0)))
+
+
+EXP_DIST_CASES = [(n, k) for n, k in DIST_CASES if k.get("iptcldist", 3) in (2, 3)] + [
+    ("bump_hot_beam", dict(iptcldist=3, species_temperature=[0.5], species_temperature2=[4.0], species_density=[0.6],
+                           species_v0=[3.0])),
+    ("bump_heavy", dict(iptcldist=3, species_temperature=[0.013], species_temperature2=[0.02],
+                        species_mass=[1836.15267343], species_density=[0.9], species_v0=[0.01])),
+    ("bump_no_beam", dict(iptcldist=3, species_density=[1.0])),
+]
+
+
+@pytest.mark.parametrize("name,kw", EXP_DIST_CASES, ids=lambda v: v if isinstance(v, str) else "")
+def test_dlnf0_forms_against_extended_precision(amd, probe, name, kw):
+    """-f0'/f0 (src/pic1dp_interaction.F90:278-321) as the marker kernels evaluate it, on its own: the one-exp
+    form (default) and the reference's operation order, each against an 80-bit evaluation, within the bound the
+    w tolerances of the push tests are built from (dlnf0_bound) -- over the loaded velocity range, beyond it
+    (a marker the instability has accelerated), at the humps, at the minimum between them (where the
+    numerator cancels) and at 0"""
+    inp = amd.make_input(nparticle_max=16, **kw)
+    sp = probe.species(inp)
+    assert probe.species_const(sp)["one_exp"] == 1
+    rng = np.random.default_rng(5)
+    v0 = inp.species_v0[0]
+    v = np.concatenate([rng.uniform(-8, 8, 2_000_000), rng.uniform(-40, 40, 500_000), rng.normal(v0, 0.01, 100_000),
+                        rng.normal(0.0, 1e-3, 100_000), np.linspace(-8, 8, 100_001), [0.0, -0.0, v0, -v0, 1e-300, 200.0]])
+    pc = dlnf0_pieces(inp, v)
+    exact = pc["tmp2"]
+    for form in (1, 0):
+        got = probe.dlnf0(sp, v, form)
+        err = np.abs(got.astype(np.longdouble) - exact).astype(np.float64)
+        bound = dlnf0_bound(pc, form == 1)
+        vv = v
+        if form == 0:
+            # the reference's operation order loses its ratio where a Maxwellian leaves the normal range (exp
+            # arguments beyond ~ -700: denormal, then 0/0) -- far outside the loaded |v| <= 8; the one-exp form has
+            # no such limit.  Compared where both are normal numbers.
+            ok = np.asarray(pc["argmax"] < 690.0)
+            assert ok[np.abs(v) <= 12].all() and np.isfinite(got[ok]).all()
+            err, bound, vv = err[ok], bound[ok], v[ok]
+        else:
+            assert np.isfinite(got).all()
+        worst = np.argmax(err / bound)
+        assert (err <= bound).all(), "form %d: off by %g (bound %g) at v = %r" % (form, err[worst], bound[worst], vv[worst])
+        print("%s form %d: max error / bound %.3f, max error %.3g" % (name, form, (err / bound).max(), err.max()))
 
 
 # --------------------------------------------------------------------------
@@ -242,13 +356,21 @@ def test_tiny_particle_counts(oracle_mod, amd, n):
                                       (256, list(range(1, 129))), (1000, list(range(1, 500))),
                                       (2048, list(range(1, 1025)))],
                          ids=lambda v: str(v) if isinstance(v, int) else "m%d" % len(v))
-def test_field_solve_bit_exact(oracle_mod, amd, nx, modes):
-    """same chargeden in -> identical E, mode_re, mode_im (the forward sums run
-    in the reference's ascending-ix order, one thread per mode component)"""
-    sim, eng = pair(oracle_mod, amd, load=False, nparticle_max=16, nx=nx, nmode=len(modes), modes=modes)
+@pytest.mark.parametrize("npe", [1, 2, 4, 7, 8, 16])
+def test_field_solve_bit_exact(oracle_mod, amd, nx, modes, npe):
+    """same chargeden in -> identical E, mode_re, mode_im: the forward sums run in the reference's order -- one
+    rank (SeqAIJ): ascending ix, one thread per mode component; npe ranks (MPI-AIJ, `mpiexec -n 4` is the
+    reference's own launch line): every rank's PETSC_DECIDE row block from zero, the blocks added owner first then
+    in rank order (oracle: orc_field_solve_ranks), here as partial chains side by side"""
+    if npe > 1 and nx > 1100 and len(modes) > 600:
+        pytest.skip("one large many-mode case per order is enough")
+    sim, eng = pair(oracle_mod, amd, load=False, npe=npe, nparticle_max=max(16, npe), nx=nx, nmode=len(modes), modes=modes)
     rng = np.random.default_rng(nx)
     rho = rng.standard_normal(nx) * 1e-3
-    E, re, im = oracle_mod.Field(sim.inp).solve(rho)
+    E, re, im = oracle_mod.Field(sim.inp).solve(rho, npe)
+    if npe > 1 and nx >= 64:   # the order is observable: not the one-rank sums
+        E1, re1, im1 = oracle_mod.Field(sim.inp).solve(rho, 1)
+        assert not (np.array_equal(re, re1) and np.array_equal(im, im1)) or len(modes) == 1
     eng.set_chargeden(rho)
     eng.field_solve_electric()
     f = eng.get_field()
@@ -304,25 +426,38 @@ PUSH_CASES = [(n, kw, lin) for n, kw in DIST_CASES for lin in (0, 1)]
 
 
 @pytest.mark.parametrize("name,kw,linear", PUSH_CASES, ids=lambda v: str(v) if not isinstance(v, dict) else "")
-def test_push_particle(oracle_mod, amd, name, kw, linear):
+@pytest.mark.parametrize("form", ["one_exp", "ref"])
+def test_push_particle(oracle_mod, amd, probe, monkeypatch, name, kw, linear, form):
     """interaction_push_particle against the oracle on identical particles and
     field: x and v bit-exact; w bit-exact where no exp is involved, else within
-    a few ulp of the update's scale"""
+    the bound derived from the exp's measured distance to libm and the conditioning of
+    -f0'/f0 -- with the one-exp form of -f0'/f0 (the default) and with the reference's
+    operation order (PIC1DP_DLNF0=ref)"""
+    if form == "ref":
+        if kw.get("iptcldist", 3) not in (2, 3):
+            pytest.skip("no exp in this distribution: one form only")
+        monkeypatch.setenv("PIC1DP_DLNF0", "ref")
     sim, eng = pair(oracle_mod, amd, linear=linear, **kw)
     nx = sim.inp.nx
     exact_w = sim.inp.iptcldist in (0, 1)
+    one_exp = one_exp_active(probe, sim.inp)
+    assert one_exp == (form == "one_exp" and not exact_w)
     for irk, seed in ((1, 11), (2, 12)):
         E = smooth_field(nx, seed)
         sim.set_field(E)
         eng.set_electric(E)
         wb = sim.gather("w") if irk == 1 else sim.gather("wb")
-        kappa = w_cancellation(sim.inp, sim.gather("v"))      # v the derivatives are evaluated at
+        v_at = sim.gather("v")                                 # v the derivatives are evaluated at
+        kappa = w_cancellation(sim.inp, v_at)
         sim.push(irk)
         eng.interaction_push_particle(irk)
         g = eng.particles_download()
         assert np.array_equal(g["x"], sim.gather("x")), "x irk=%d" % irk
         assert np.array_equal(g["v"], sim.gather("v")), "v irk=%d" % irk
-        assert_w_close(g["w"], sim.gather("w"), wb, exact_w, kappa)
+        if one_exp:
+            assert_w_close_one_exp(sim.inp, v_at, g["w"], sim.gather("w"), wb)
+        else:
+            assert_w_close(g["w"], sim.gather("w"), wb, exact_w, kappa)
         if irk == 1:
             b = eng.particles_download_bak()
             assert np.array_equal(b["xb"], sim.gather("xb"))
@@ -697,13 +832,11 @@ def test_full_size_properties(amd, n, nx):
 
 @pytest.mark.parametrize("kw", [dict(nx=1024), dict(nx=4096, lx=4 * np.pi), dict(nx=192, lx=17.0),
                                 dict(nx=64, lx=1.0 / 3.0)], ids=lambda d: "nx%d" % d["nx"])
-def test_exact_division_by_lx_device(amd, kw):
+def test_exact_division_by_lx_device(amd, probe, kw):
     """div_lx (reciprocal + two FMA corrections) against the hardware IEEE
     division on 4e8 generated positions, cell boundaries +- ulps included"""
-    eng = amd.Pic1dp(amd.make_input(nparticle_max=16, **kw))
-    m = C.c_int64(-1)
-    amd._lib.check(eng.L.pic1dp_hip_debug_div_check(eng._ctx, 400_000_000, 77, C.byref(m)))
-    assert m.value == 0
+    inp = amd.make_input(nparticle_max=16, **kw)
+    assert probe.div_lx_mismatches(inp.lx, inp.nx, 400_000_000, 77) == 0
 
 
 @pytest.mark.parametrize("kw", [
@@ -711,13 +844,15 @@ def test_exact_division_by_lx_device(amd, kw):
     dict(species_temperature=[2.0], species_temperature2=[0.5]),
     dict(species_temperature=[0.013], species_temperature2=[37.0], species_mass=[1836.15267343]),
 ], ids=["T1.3", "T2", "m1836"])
-def test_exact_division_by_species_constant_device(amd, kw):
+def test_exact_division_by_species_constant_device(amd, probe, kw):
     """div_const on the device against the hardware IEEE division: 1e8 dividends
-    for each of the eight divisor constants of the species"""
-    eng = amd.Pic1dp(amd.make_input(nparticle_max=16, **kw))
-    m = C.c_int64(-1)
-    amd._lib.check(eng.L.pic1dp_hip_debug_divc_check(eng._ctx, 0, 100_000_000, 99, C.byref(m)))
-    assert m.value == 0
+    for each of the eight divisor constants of the species (m, T, T/m, T2/m, 2T/m, 2T2/m and the two roots,
+    formed as the library forms them: pic1dp_amd/csrc/species.cpp)"""
+    inp = amd.make_input(nparticle_max=16, **kw)
+    m, T, T2 = inp.species_mass[0], inp.species_temperature[0], inp.species_temperature2[0]
+    divisors = [m, T, T / m, T2 / m, 2.0 * T / m, 2.0 * T2 / m, np.sqrt(T / m), np.sqrt(T2 / m)]
+    for i, d in enumerate(divisors):
+        assert probe.div_const_mismatches(float(d), 100_000_000, 99 + i) == 0, d
 
 
 @pytest.mark.parametrize("fast", ["0", "1"])
@@ -727,6 +862,7 @@ def test_non_unit_species_fast_and_hardware_division_agree(oracle_mod, amd, monk
     the two settings give bit-identical weights"""
     kw = dict(iptcldist=3, species_temperature=[1.3], species_temperature2=[0.7], species_mass=[1.1],
               species_density=[0.85], species_v0=[4.5])
+    monkeypatch.setenv("PIC1DP_DLNF0", "ref")      # the ten constant divisions live in the reference's operation order
     monkeypatch.setenv("PIC1DP_FAST_DIVC", fast)
     sim, eng = pair(oracle_mod, amd, **kw)
     monkeypatch.setenv("PIC1DP_FAST_DIVC", "0")

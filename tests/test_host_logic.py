@@ -210,27 +210,21 @@ def test_fortran_binding_matches_header(amd):
 
 @pytest.mark.parametrize("lx,nx", [(2.0 * 3.1415926535897932384626 / 0.36, 1024), (4 * 3.141592653589793, 4096),
                                     (17.0, 192), (1.0 / 3.0, 64), (0.007, 100), (1e5 / 7.0, 8192)])
-def test_exact_division_by_lx_host(amd, lx, nx):
+def test_exact_division_by_lx_host(probe, lx, nx):
     """the kernels divide by the constant lx with a reciprocal and two FMA
     corrections; the result must equal the IEEE quotient bit for bit (cell
     indices depend on it).  Same algorithm on the host, with libm's exact fma."""
-    L = amd._lib.load()
-    m = C.c_int64(-1)
-    assert L.pic1dp_hip_host_div_check(lx, nx, 5_000_000, 20261003, C.byref(m)) == 0
-    assert m.value == 0
+    assert probe.div_lx_mismatches(lx, nx, 5_000_000, 20261003, host=True) == 0
 
 
 @pytest.mark.parametrize("divisor", [1.3, 0.7, 1.1, 1.3 / 1.1, 2 * 0.7 / 1.1, (1.3 / 1.1) ** 0.5, 3.0, 1.0 / 3.0,
                                      float.fromhex("0x1.fffffffffffffp+0"), float.fromhex("0x1.0000000000001p-3"),
                                      25.0, 1836.15267343, 2.0 ** 0.5, -1.7])
-def test_exact_division_by_species_constant_host(amd, divisor):
+def test_exact_division_by_species_constant_host(probe, divisor):
     """species constants that are not powers of two (T = 1.3, m = 1836, ...) divide
     through the same reciprocal + two-FMA-correction sequence; it must return the
     IEEE quotient bit for bit for every dividend (v and w pushes depend on it)"""
-    L = amd._lib.load()
-    m = C.c_int64(-1)
-    assert L.pic1dp_hip_host_divc_check(divisor, 3_000_000, 424242, C.byref(m)) == 0
-    assert m.value == 0
+    assert probe.div_const_mismatches(divisor, 3_000_000, 424242, host=True) == 0
 
 
 def test_product_never_touches_the_oracle(amd):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """isa_loop_count.py -- static instruction mix of the marker loop of one kernel instantiation (cross-compiled,
-no GPU): python tools/isa_loop_count.py 'k_step_one<3, 0, 2, true, 2>'"""
+no GPU): python tools/isa_loop_count.py 'k_step_one<5, 0, 2, true, 0>'"""
 import collections
 import os
 import re
@@ -8,11 +8,14 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "pic1dp_amd", "csrc", "kernels.hip")
+# the translation unit and, for kernels_step.hip, the distribution it is compiled for (pic1dp_amd/build.py):
+#   PIC1DP_TU=kernels_step.hip PIC1DP_STEP_DIST=5 (default: the one-exp bump-on-tail unit of the default input)
+src = os.path.join(ROOT, "pic1dp_amd", "csrc", os.environ.get("PIC1DP_TU", "kernels_step.hip"))
+DIST_FLAG = ["-DPIC1DP_STEP_DIST=" + os.environ.get("PIC1DP_STEP_DIST", "5")] if src.endswith("kernels_step.hip") else []
 out = "/tmp/isa_loop_count.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                 "-munsafe-fp-atomics", "-x", "hip", "-S", "--cuda-device-only", src, "-o", out] +
-               os.environ.get("PIC1DP_EXTRA_FLAGS", "").split(), check=True, capture_output=True)
+               os.environ.get("PIC1DP_EXTRA_FLAGS", "").split() + DIST_FLAG, check=True, capture_output=True)
 s = open(out).read()
 want = sys.argv[1]
 names = re.findall(r'^(_ZN6pic1dp[^\n:]*):', s, re.M)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""kernel_resources.py -- VGPRs / scratch / occupancy of every kernel of kernels.hip as hipcc
+"""kernel_resources.py -- VGPRs / scratch / occupancy of every kernel of the marker / field translation units as hipcc
 reports them (-Rpass-analysis=kernel-resource-usage); runs on the CPU (cross-compile).
     python tools/kernel_resources.py [filter]"""
 import os
@@ -8,10 +8,13 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "pic1dp_amd", "csrc", "kernels.hip")
+# the translation unit and, for kernels_step.hip, the distribution it is compiled for (pic1dp_amd/build.py):
+#   PIC1DP_TU=kernels_step.hip PIC1DP_STEP_DIST=5 (default: the one-exp bump-on-tail unit of the default input)
+src = os.path.join(ROOT, "pic1dp_amd", "csrc", os.environ.get("PIC1DP_TU", "kernels_step.hip"))
+DIST_FLAG = ["-DPIC1DP_STEP_DIST=" + os.environ.get("PIC1DP_STEP_DIST", "5")] if src.endswith("kernels_step.hip") else []
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                     "-munsafe-fp-atomics", "-c", "-x", "hip", src, "-o", "/tmp/kernel_resources.o",
-                    "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("PIC1DP_EXTRA_FLAGS", "").split(),
+                    "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("PIC1DP_EXTRA_FLAGS", "").split() + DIST_FLAG,
                    capture_output=True, text=True)
 blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
 names = [b.split()[0] for b in blocks]

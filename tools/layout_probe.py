@@ -3,21 +3,16 @@
 its seven concurrent streams (4 read, 3 written in place)?  Times that traffic shape
 over fresh slabs, arrays apart (SoA) against interleaved in tiles, while earlier slabs
 stay allocated so that every slab lands in other physical memory."""
-import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import pic1dp_amd  # noqa: E402
-from pic1dp_amd._lib import check  # noqa: E402
+from pic1dp_amd import probe as probe_lib  # noqa: E402  (libpic1dp_probe.so: measurement code, not the product)
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**8
-eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=1000, nx=1024))
-ms = (C.c_double * 6)()
 
 
 def probe(lt, stagger, keep):
-    check(eng.L.pic1dp_hip_debug_layout_probe(eng._ctx, n, lt, stagger, 20, keep, ms))
-    return list(ms)
+    return probe_lib.layout(n, lt, 20, stagger_bytes=stagger, keep=keep)
 
 
 probe(10, 0, 0)
@@ -30,4 +25,4 @@ for keep in (0, 1):
                   " | read-only  SoA %.4f (%4.0f) tiled %.4f (%4.0f) tiled-wg %.4f (%4.0f)"
                   % (keep, rnd, lt, m[0], rw / m[0], m[1], rw / m[1], m[4], rw / m[4], m[2], ro / m[2], m[3], ro / m[3],
                      m[5], ro / m[5]), flush=True)
-eng.close()
+probe_lib.release()

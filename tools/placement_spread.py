@@ -6,6 +6,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pic1dp_amd  # noqa: E402
+from pic1dp_amd import probe  # noqa: E402
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 keep = []
@@ -21,7 +22,7 @@ for r in range(reps):
     eng.sync()
     (hm, hn), (fm, fn) = eng.kernel_stats(3), eng.kernel_stats(4)
     print("create %d: step_half %.4f ms  step_full %.4f ms   probe 4r3w %.0f GB/s" % (
-        r, hm / hn, fm / fn, eng.stream_probe(4, 3, n, 10)), flush=True)
+        r, hm / hn, fm / fn, probe.stream(4, 3, n, 10)), flush=True)
     if "--keep" in sys.argv:
         keep.append(eng)          # keep the allocation alive: the next engine lands elsewhere
     else:

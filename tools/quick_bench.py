@@ -19,11 +19,13 @@ if os.environ.get("PIC1DP_THREADS") or os.environ.get("PIC1DP_BPC"):
     eng.set_launch(int(os.environ.get("PIC1DP_THREADS", "0")), int(os.environ.get("PIC1DP_BPC", "0")))
 if "--probe" in sys.argv:
     for nr, nw in ((1, 1), (4, 0), (4, 3), (7, 3), (1, 0), (7, 0)):
-        print("probe read %d write %d: %.0f GB/s" % (nr, nw, eng.stream_probe(nr, nw, n, 10)), flush=True)
+        from pic1dp_amd import probe
+        print("probe read %d write %d: %.0f GB/s" % (nr, nw, probe.stream(nr, nw, n, 10)), flush=True)
 eng.particle_load()
 eng.interaction_collect_charge()
 eng.field_solve_electric()
-for mode in (0, 1):
+only0 = os.environ.get("PIC1DP_QB_ONLY_STEP") == "1"     # A/B runs: the whole-step path alone
+for mode in ((0,) if only0 else (0, 1)):
     eng.set_step_mode(mode)
     eng.step(int(os.environ.get("PIC1DP_QB_WARMUP", "3")))
     eng.sync()
@@ -38,6 +40,10 @@ for mode in (0, 1):
     parts = ["%s %.4f ms" % (nm, ms / cnt) for nm, (ms, cnt) in zip(names, ks) if cnt]
     print("mode %d: %.4e updates/s  %.4f ms/step  | %s" % (mode, n * 2 * steps / dt, dt / steps * 1e3, ", ".join(parts)), flush=True)
     eng.kernel_stats_enable(False)
+
+if only0:
+    eng.close()
+    sys.exit(0)
 
 # the reference's own call sequence (src/pic1dp.F90:79-93): three call sites per
 # sub-step, served lazily by the whole-step kernels unless PIC1DP_LAZY_CALLS=0
