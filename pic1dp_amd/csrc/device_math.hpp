@@ -292,6 +292,10 @@ __device__ __forceinline__ double2 *exp_table() {
 __device__ __forceinline__ void exp_table_init() {
   if (threadIdx.x < 64) exp_table()[threadIdx.x] = kExpTab[threadIdx.x];
 }
+// HI_ONLY (the one-exp form of -f0'/f0, whose result owes the CPU arithmetic nothing beyond rounding): the
+// kernel that evaluates it is LDS-bound (three table reads per marker among eight atomics and four gathers), and
+// half the bytes per read are worth 2 % of its time (profiles/r03/experiments/ab_variants.log)
+template <bool HI_ONLY = false>
 __device__ __forceinline__ double pexp(double x) {
   x = fmax(x, -750.0);
   const double fn = rint(x * 0x1.71547652b82fep+6);            // n = round(x * 64/ln2)
@@ -304,8 +308,13 @@ __device__ __forceinline__ double pexp(double x) {
   q = fma(q, r, 0.5);
   q = fma(q, r, 1.0);
   const double p = q * r;                                     // e^r - 1
-  const double2 t = exp_table()[n & 63];
-  return ldexp(t.x + fma(t.x, p, t.y), n >> 6);
+  if constexpr (HI_ONLY) {  // 8-byte read, the table's low part dropped: within ~2 ulp instead of 1
+    const double th = exp_table()[n & 63].x;
+    return ldexp(fma(th, p, th), n >> 6);
+  } else {
+    const double2 t = exp_table()[n & 63];
+    return ldexp(t.x + fma(t.x, p, t.y), n >> 6);
+  }
 }
 
 // DIST values of the marker kernels: iptcldist 0..3 with -f0'/f0 in the reference's operation order, and the
@@ -314,10 +323,19 @@ constexpr int DIST_TS2_ONE_EXP = 4;   // iptcldist 2
 constexpr int DIST_BUMP_ONE_EXP = 5;  // iptcldist 3
 
 // 1 / d for d in [1, 2]: v_rcp_f64 and two Newton steps (no scaling, no fix-up: d is a normal number near 1)
+// Newton steps on v_rcp_f64's seed (the divisor is 1 + E in [1, 2]): one step leaves the quotient within a
+// few ulp (measured by test_dlnf0_forms_against_extended_precision against its derived bound); the second was
+// worth 1.5 % of k_step_one (profiles/r03/experiments/ab_variants.log)
+#ifndef PIC1DP_RCP_NR
+#define PIC1DP_RCP_NR 1
+#endif
+#ifndef PIC1DP_ONE_EXP_TAB_HI
+#define PIC1DP_ONE_EXP_TAB_HI true
+#endif
 __device__ __forceinline__ double rcp_1to2(double d) {
   double r = __builtin_amdgcn_rcp(d);
-  r = fma(fma(-d, r, 1.0), r, r);
-  r = fma(fma(-d, r, 1.0), r, r);
+#pragma unroll
+  for (int k = 0; k < PIC1DP_RCP_NR; ++k) r = fma(fma(-d, r, 1.0), r, r);
   return r;
 }
 
@@ -352,7 +370,7 @@ __device__ __forceinline__ double dlnf0_one_exp(double v, const SpeciesConst &c)
     M = fma(v, c.fm1, c.fm0);
     D = fma(v, c.fd1, c.fd0);
   }
-  const double E = pexp(-fabs(L));
+  const double E = pexp<PIC1DP_ONE_EXP_TAB_HI>(-fabs(L));
   const double t = (1.0 - E) * rcp_1to2(1.0 + E);
   return fma(D, copysign(t, L), M);
 }
@@ -409,7 +427,13 @@ __device__ __forceinline__ One push_core(double v, double w, double p, double xb
       tmp2 = dlnf0<DIST, POW2>(v, s, dv);
       if constexpr (T2MODE == 1) *t2io = tmp2;
     }
-    o.w = wb + divc<POW2>(dt * tmp1 * tmp2 * s.Z, s.m, s.r_m, dv);  // :329
+    if constexpr (POW2 == 0 && (DIST == DIST_TS2_ONE_EXP || DIST == DIST_BUMP_ONE_EXP)) {
+      // with the one-exp form tmp2 -- and w -- match the CPU arithmetic to rounding, not bit for bit: the
+      // division by a general mass may be the product with its reciprocal (one operation instead of five)
+      o.w = wb + (dt * tmp1 * tmp2 * s.Z) * s.r_m;
+    } else {
+      o.w = wb + divc<POW2>(dt * tmp1 * tmp2 * s.Z, s.m, s.r_m, dv);  // :329
+    }
   }
   if constexpr (MODE == MODE_DF_LIN) {
     o.v = v;

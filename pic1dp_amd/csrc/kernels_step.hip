@@ -454,8 +454,14 @@ __device__ __forceinline__ double pred_one_sums(const One &n, double p, int ix, 
   return t2;
 }
 
+// tuning builds: -DPIC1DP_SUMS_WAVES=n holds k_step_sums to the register budget of n waves per SIMD
+#ifdef PIC1DP_SUMS_WAVES
+#define PIC1DP_SUMS_ATTR __attribute__((amdgpu_waves_per_eu(PIC1DP_SUMS_WAVES)))
+#else
+#define PIC1DP_SUMS_ATTR
+#endif
 template <int DIST, int MODE, int POW2, bool NT, int T2>
-__global__ void __launch_bounds__(1024) k_step_sums(const StepArgsDev a) {
+__global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   exp_table_init();
   const int nx = a.g.nx;

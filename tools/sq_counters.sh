@@ -13,6 +13,7 @@ cd /tmp
 P1="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"
 P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM"
 i=0
+export PIC1DP_QB_ONLY_STEP=1
 for P in "$P1" "$P2"; do
   i=$((i+1))
   rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 "$R/tools/quick_bench.py" 1e8 1024 4 > "$OUT/pass$i.log" 2>&1
