@@ -772,6 +772,17 @@ def main():
             "field_energy_end": energy,
         }
         if strong is not None:
+            # the charge sum of the strong object follows the measurement: at 1.25e7 markers per GPU the field launch
+            # and the sum are a fifth of the step, and the one-hop exchange (one launch per step, no ring) was measured
+            # beside the headline's sum -- the faster one is the strong figure, both are printed
+            xs = (exchange or {}).get("strong_1e8_total")
+            if xs and "value" in xs and not strong.get("same_run_as_headline"):
+                strong["by_charge_sum"] = {
+                    headline_kind: {"value": strong["value"], "ms_per_step": strong["ms_per_step"]},
+                    "one-hop exchange": {"value": xs["value"], "ms_per_step": xs["ms_per_step"]}}
+                if xs["value"] > strong["value"]:
+                    strong.update(value=xs["value"], ms_per_step=xs["ms_per_step"],
+                                  allreduce="one-hop exchange (measured faster than %s in this run)" % headline_kind)
             out["strong_1e8_total"] = strong
         if exchange is not None:
             out["exchange"] = exchange

@@ -267,10 +267,11 @@ int pic1dp_hip_step(pic1dp_ctx *ctx, int32_t nsteps);
  *     PIC1DP_PREDICT=0 in the environment keeps the two passes, 88 B).  The
  *     prediction is held as LDS tiles (up to two kept modes, nx up to ~2400) or,
  *     for larger grids with one kept mode (nx up to ~5000), as six sums over the
- *     markers -- then, through the call sites, field_chargeden between
- *     collect_charge after push(1) and the collect_charge after push(2) holds the
- *     kept mode's content of the half-step charge density only (all that
- *     solve_field looks at; nothing in the reference driver reads it there).
+ *     markers -- then, through the call sites, the collect_charge after push(1)
+ *     leaves in field_chargeden the kept mode's content of the half-step charge
+ *     density only (all that solve_field looks at; nothing in the reference driver
+ *     reads it there).  A host that DOES read it there gets the reference's vector:
+ *     see pic1dp_hip_get_field.
  *     Falls back to two passes otherwise, and to mode 1 when nx is too large for
  *     three grid tiles in LDS
  *   1 two fused sub-steps through the RK ping-pong sets (136 B per marker) */
@@ -311,7 +312,19 @@ int pic1dp_hip_check_termination(pic1dp_ctx *ctx, int32_t *flag);
 int pic1dp_hip_output_due(pic1dp_ctx *ctx, int32_t itermination, int32_t *flag);
 
 /* ---- field access (what output_field reads, src/pic1dp_output.F90:173-186) */
-/* any pointer may be NULL; E, chargeden: [nx]; mode_re, mode_im: [nmode] */
+/* any pointer may be NULL; E, chargeden: [nx]; mode_re, mode_im: [nmode].
+ * HALF-STEP CHARGE DENSITY -- the one place where the state a host can look at differs
+ * from what the reference would hold: between the collect_charge after push(1) and the
+ * next collect_charge, when that half-step charge was predicted as six sums
+ * (pic1dp_hip_predict_kind = 2: grids beyond nx ~ 2400, one kept mode), field_chargeden
+ * holds its kept mode's content only.  Asking for chargeden here rebuilds the whole
+ * vector on a one-rank context: the half-step state is pushed into memory after all and
+ * deposited (that step then runs as two ordinary sub-steps; results unchanged to
+ * rounding).  On several ranks the rebuild would need the charge sum -- a collective an
+ * inspection on one rank must not start -- so there chargeden keeps the kept mode's
+ * content between the sub-steps; a host that needs the full half-step vector on several
+ * ranks calls pic1dp_hip_set_step_mode(ctx, 1) or sets PIC1DP_PREDICT=0.  Pass
+ * chargeden = NULL to leave it alone. */
 int pic1dp_hip_get_field(pic1dp_ctx *ctx, double *electric, double *chargeden,
                          double *mode_re, double *mode_im);
 /* overwrite field_electric (testing the push against a prescribed field) */
@@ -354,6 +367,20 @@ int pic1dp_hip_output_scalars(pic1dp_ctx *ctx, double *out, int32_t n);
 int pic1dp_hip_ptcldist(pic1dp_ctx *ctx, int32_t ispecies, int32_t finish,
                         double *markr_xv, double *total_xv, double *pertb_xv,
                         double *markr_v, double *total_v, double *pertb_v);
+
+/* ---- split-phase diagnostics for a host that owns the reductions (MPI) ----
+ * output_all sums its diagnostics over the ranks (VecSum / MPI_Reduce, src/pic1dp_output.F90:126-151,333-356).
+ * With an RCCL communicator output_scalars and ptcldist(finish = 1) do that themselves; a host with its own
+ * MPI takes the local sums -- pic1dp_hip_energy_sums per species, pic1dp_hip_ptcldist(finish = 0) --, reduces
+ * them to its rank 0 and hands the sums back:
+ *   output_scalars_from: sums[3*nspecies] = sum v^2, sum v^2 p, sum v^2 w per species, summed over ranks ->
+ *     out[2 + 3*nspecies] as pic1dp_hip_output_scalars writes it (time, int E^2 dx, three energies per
+ *     species, :152-170)
+ *   ptcldist_finish: the six raw histograms summed over ranks -> what the reference writes (:328-331,
+ *     :361-453), in place */
+int pic1dp_hip_output_scalars_from(pic1dp_ctx *ctx, const double *sums, double *out, int32_t n);
+int pic1dp_hip_ptcldist_finish(pic1dp_ctx *ctx, int32_t ispecies, double *markr_xv, double *total_xv,
+                               double *pertb_xv, double *markr_v, double *total_v, double *pertb_v);
 
 /* ---- split-phase deposit for a host that owns the reduction (MPI) ------
  * charge_local: everything of collect_charge up to the all-reduce

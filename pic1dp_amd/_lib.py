@@ -131,6 +131,8 @@ SIGNATURES = {
     "pic1dp_hip_get_stream": [_P, C.POINTER(_P)],
     "pic1dp_hip_kernel_stats": [_P, C.c_int32, _D, C.POINTER(C.c_int64)],
     "pic1dp_hip_kernel_stats_enable": [_P, C.c_int32],
+    "pic1dp_hip_output_scalars_from": [_P, _P, _P, C.c_int32],
+    "pic1dp_hip_ptcldist_finish": [_P, C.c_int32, _P, _P, _P, _P, _P, _P],
     "pic1dp_hip_kernel_bytes": [_P, C.c_int32, _D, _D, _D, C.c_char_p, C.c_int32],
 }
 

@@ -124,6 +124,11 @@ struct pic1dp_ctx {
   // modes) k_step_one's prediction accumulators hold the charge, combination with the kept modes, species sum and
   // scaling pending.  materialize_cd() before anything else looks at charge, chargeden or the accumulators.
   int cd_lazy = 0;
+  // field_chargeden holds only the kept mode's content of the half-step charge density (collect_charge after a
+  // noted push(1) served from the six sums, pred_kind 2): all solve_field looks at, but not what the reference
+  // holds there.  get_field rebuilds the full vector on one rank (rebuild_half_step_chargeden); cleared by
+  // everything that writes field_chargeden.
+  bool cd_kept_mode_only = false;
   int lz = 0;                    // LZ_CLEAN / LZ_PUSH1 / LZ_HALF / LZ_PUSH2
   double *d_E0 = nullptr;        // field the noted push(1) saw
   double *d_rho_dummy = nullptr; // accumulator of a wrap-only deposit
@@ -1148,6 +1153,7 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
     if (int rc = pred_to_chargeden(c, c->fa, c->lazy_calls != 0)) return rc;
     return tm.end();
   }
+  c->cd_kept_mode_only = false;  // a deposit follows: the whole vector again
   const bool noted = c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2;
   if (noted)
     if (int rc = deposit_or_step(c)) return rc;
@@ -1352,6 +1358,7 @@ int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optim
 }
 
 static int substep_impl(pic1dp_ctx *c, int irk, bool record) {
+  c->cd_kept_mode_only = false;
   if (irk == 2 && optimize_due_any(c)) {
     // src/pic1dp.F90:80-88: push, particle_optimize, collect_charge -- the pushed
     // state has to exist in memory for the host-side optimisation
@@ -1630,6 +1637,7 @@ static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer = fal
   c->pred_version = 0;  // consumed: the accumulators are zero again afterwards
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (c->pred_kind == 2) {
+    if (f.chargeden == c->d_chargeden) c->cd_kept_mode_only = true;
     if (!multi) {
       HIP_TRY(launch_pred_chargeden(f, c->pred_tab, c->d_pred, c->d_pred, c->st));
       return 0;
@@ -1726,6 +1734,7 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
   CHECK_CTX(c);
   if (nsteps < 0) return fail(PIC1DP_ERR_ARG, "nsteps < 0");
   if (int rc = require_loaded(c)) return rc;
+  if (nsteps > 0) c->cd_kept_mode_only = false;  // every step ends with the deposit of the new state
   const bool recompute = step_recompute_ok(c);
   for (int it = 0; it < nsteps; ++it) {
     // a step in which a marker optimisation is due goes through the sub-steps
@@ -1829,10 +1838,28 @@ int pic1dp_hip_output_due(pic1dp_ctx *c, int32_t itermination, int32_t *flag) {
 // ---------------------------------------------------------------------------
 // field access
 // ---------------------------------------------------------------------------
+// field_chargeden as the reference holds it between the sub-steps, when the collect_charge after a noted push(1)
+// was served from the six sums (the kept mode's content only): the half-step state is pushed into memory after all
+// (as every inspection of a noted push does) and deposited for real.  One rank only -- on several ranks the
+// reduction is a collective that an inspection on one of them must not start: there chargeden keeps the kept
+// mode's content (include/pic1dp_hip.h says so).  The field solved from either is the same to rounding: the
+// solve only looks at the kept mode.
+static int rebuild_half_step_chargeden(pic1dp_ctx *c) {
+  c->cd_kept_mode_only = false;
+  if (c->lz != LZ_HALF || c->lay.nranks > 1 || c->comm != nullptr) return 0;
+  if (int rc = enqueue_push(c, 1, false, c->d_E0)) return rc;
+  c->lz = LZ_CLEAN;  // memory now holds the half-step state (x not yet wrapped): the deposit wraps and stores it
+  if (int rc = enqueue_deposit(c)) return rc;
+  HIP_TRY(launch_chargeden(c->fa, true, c->st));
+  return 0;
+}
+
 int pic1dp_hip_get_field(pic1dp_ctx *c, double *E, double *cd, double *re, double *im) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
   if (int rc = materialize_cd(c)) return rc;
+  if (cd && c->cd_kept_mode_only)
+    if (int rc = rebuild_half_step_chargeden(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   const size_t nx = c->in.nx, nm = c->in.nmode;
   if (int rc = xchg_check(c)) return rc;
@@ -1862,6 +1889,7 @@ int pic1dp_hip_set_chargeden(pic1dp_ctx *c, const double *cd) {
   if (int rc = materialize_cd(c)) return rc;  // pending deposits are consumed, then overwritten
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(c->d_chargeden, cd, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
+  c->cd_kept_mode_only = false;
   return 0;
 }
 
@@ -2028,6 +2056,13 @@ int pic1dp_hip_output_scalars(pic1dp_ctx *c, double *out, int32_t n) {
     HIP_TRY(hipStreamSynchronize(c->st));
     HIP_TRY(hipMemcpy(sums.data(), d, sizeof(double) * 3 * ns, hipMemcpyDeviceToHost));
   }
+  return pic1dp_hip_output_scalars_from(c, sums.data(), out, n);
+}
+
+int pic1dp_hip_output_scalars_from(pic1dp_ctx *c, const double *sums, double *out, int32_t n) {
+  CHECK_CTX(c);
+  const int ns = c->in.nspecies;
+  if (!sums || !out || n != 2 + 3 * ns) return fail(PIC1DP_ERR_ARG, "sums must hold 3*nspecies and out 2 + 3*nspecies doubles");
   out[0] = c->time;
   if (int rc = pic1dp_hip_field_energy(c, &out[1])) return rc;
   const pic1dp_input &in = c->in;
@@ -2066,6 +2101,39 @@ static double output_f0(const pic1dp_input &in, int s, double sv) {
   return den * std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T / m)) / (std::sqrt(2.0 * kPi) * T / m);
 }
 
+// what output_ptcldist does with the sums over ranks (src/pic1dp_output.F90:328-331, :361-453): linear total +=
+// pertb, scaling by the histogram cell sizes, full-f pertb = total - f0; in place on host arrays
+static void finish_ptcldist(const pic1dp_input &in, int isp, double *mxv, double *txv, double *pxv, double *mv, double *tv,
+                            double *pv) {
+  const int nxo = in.nx_opd, nvo = in.nv_opd;
+  const size_t nxv = static_cast<size_t>(nxo) * nvo;
+  if (in.linear == 1) {  // :328-331
+    for (size_t i = 0; i < nxv; ++i) txv[i] = txv[i] + pxv[i];
+    for (int i = 0; i < nvo; ++i) tv[i] = tv[i] + pv[i];
+  }
+  const double delv_inv = static_cast<double>(nvo - 1) / (2.0 * in.v_max);  // :203-205
+  const double delx_inv = static_cast<double>(nxo) / in.lx;
+  for (size_t i = 0; i < nxv; ++i) {
+    mxv[i] = mxv[i] * delx_inv * delv_inv;
+    txv[i] = txv[i] * delx_inv * delv_inv;
+  }
+  for (int i = 0; i < nvo; ++i) {
+    mv[i] = mv[i] * delv_inv;
+    tv[i] = tv[i] * delv_inv;
+  }
+  if (in.deltaf == 1) {
+    for (size_t i = 0; i < nxv; ++i) pxv[i] = pxv[i] * delx_inv * delv_inv;
+    for (int i = 0; i < nvo; ++i) pv[i] = pv[i] * delv_inv;
+  } else {  // :370-453
+    for (int iv = 0; iv < nvo; ++iv) {
+      const double sv = (static_cast<double>(iv) / static_cast<double>(nvo - 1) * 2.0 - 1.0) * in.v_max;
+      const double f0 = output_f0(in, isp, sv);
+      for (int ix = 0; ix < nxo; ++ix) pxv[static_cast<size_t>(iv) * nxo + ix] = txv[static_cast<size_t>(iv) * nxo + ix] - f0;
+      pv[iv] = tv[iv] - in.lx * f0;
+    }
+  }
+}
+
 int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *markr_xv, double *total_xv,
                         double *pertb_xv, double *markr_v, double *total_v, double *pertb_v) {
   CHECK_CTX(c);
@@ -2088,33 +2156,7 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *mark
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(h.data(), hist, sizeof(double) * ntot, hipMemcpyDeviceToHost));
   double *mxv = h.data(), *txv = mxv + nxv, *pxv = txv + nxv, *mv = pxv + nxv, *tv = mv + nvo, *pv = tv + nvo;
-  if (finish) {
-    if (in.linear == 1) {  // :328-331
-      for (size_t i = 0; i < nxv; ++i) txv[i] = txv[i] + pxv[i];
-      for (int i = 0; i < nvo; ++i) tv[i] = tv[i] + pv[i];
-    }
-    const double delv_inv = static_cast<double>(nvo - 1) / (2.0 * in.v_max);  // :203-205
-    const double delx_inv = static_cast<double>(nxo) / in.lx;
-    for (size_t i = 0; i < nxv; ++i) {
-      mxv[i] = mxv[i] * delx_inv * delv_inv;
-      txv[i] = txv[i] * delx_inv * delv_inv;
-    }
-    for (int i = 0; i < nvo; ++i) {
-      mv[i] = mv[i] * delv_inv;
-      tv[i] = tv[i] * delv_inv;
-    }
-    if (in.deltaf == 1) {
-      for (size_t i = 0; i < nxv; ++i) pxv[i] = pxv[i] * delx_inv * delv_inv;
-      for (int i = 0; i < nvo; ++i) pv[i] = pv[i] * delv_inv;
-    } else {  // :370-453
-      for (int iv = 0; iv < nvo; ++iv) {
-        const double sv = (static_cast<double>(iv) / static_cast<double>(nvo - 1) * 2.0 - 1.0) * in.v_max;
-        const double f0 = output_f0(in, isp, sv);
-        for (int ix = 0; ix < nxo; ++ix) pxv[static_cast<size_t>(iv) * nxo + ix] = txv[static_cast<size_t>(iv) * nxo + ix] - f0;
-        pv[iv] = tv[iv] - in.lx * f0;
-      }
-    }
-  }
+  if (finish) finish_ptcldist(in, isp, mxv, txv, pxv, mv, tv, pv);
   auto give = [&](double *dst, const double *src, size_t n) {
     if (dst) std::memcpy(dst, src, sizeof(double) * n);
   };
@@ -2124,6 +2166,15 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *mark
   give(markr_v, mv, nvo);
   give(total_v, tv, nvo);
   give(pertb_v, pv, nvo);
+  return 0;
+}
+
+int pic1dp_hip_ptcldist_finish(pic1dp_ctx *c, int32_t isp, double *markr_xv, double *total_xv, double *pertb_xv,
+                               double *markr_v, double *total_v, double *pertb_v) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  if (!markr_xv || !total_xv || !pertb_xv || !markr_v || !total_v || !pertb_v) return fail(PIC1DP_ERR_ARG, "null array");
+  finish_ptcldist(c->in, isp, markr_xv, total_xv, pertb_xv, markr_v, total_v, pertb_v);
   return 0;
 }
 
@@ -2145,6 +2196,7 @@ int pic1dp_hip_charge_local(pic1dp_ctx *c, double *charge2) {
     }
     c->pred_version = 0;
   } else {
+    c->cd_kept_mode_only = false;
     if (int rc = deposit_or_step(c)) return rc;
     HIP_TRY(launch_charge_local(c->fa, c->st));
   }
@@ -2163,6 +2215,7 @@ int pic1dp_hip_charge_reduced(pic1dp_ctx *c, const double *charge1) {
   c->charge_pending = false;
   if (c->charge_pending_pred) {  // what came back are the summed prediction sums
     c->charge_pending_pred = false;
+    c->cd_kept_mode_only = true;
     HIP_TRY(launch_pred_chargeden(c->fa, c->pred_tab, nullptr, c->d_charge, c->st));
     return 0;
   }

@@ -216,6 +216,11 @@ __device__ __forceinline__ double chain_sum_lds(const double *prod, int nx) {
   double acc = 0.0;
   int ix = 0;
   constexpr int W = CHAIN_W;
+  if (nx > 0 && (reinterpret_cast<uintptr_t>(prod) & 15) != 0) {  // a row block that starts on an odd element
+    acc = acc + prod[0];
+    ++prod;
+    --nx;
+  }
   if ((reinterpret_cast<uintptr_t>(prod) & 15) == 0) {
     double A[W], B[W];
     const int nb = nx / W;
@@ -348,7 +353,7 @@ __device__ __forceinline__ void solve_body(const FieldArgs &f, double *sCD, doub
       const double *prod = sTab + ((c & 1) ? 0 : nm * nx) + m * nx;
       int lo, len;
       rank_block(nx, f.npe, combine_rank(k, entry_owner(m, nm, f.npe)), lo, len);
-      sCD[pc] = chain_partial([prod](int i) { return prod[i]; }, lo, len);
+      sCD[pc] = chain_sum_lds(prod + lo, len);
     }
     __syncthreads();
   }
@@ -693,7 +698,7 @@ __device__ __forceinline__ double lean_forward_sums(const FieldArgs &f, const do
       const double *prod = (threadIdx.x & 1) ? sPs : sPc;
       int lo, len;
       rank_block(nx, npe, threadIdx.x >> 1, lo, len);
-      sPart[(threadIdx.x & 1) * npe + (threadIdx.x >> 1)] = chain_partial([prod](int i) { return prod[i]; }, lo, len);
+      sPart[(threadIdx.x & 1) * npe + (threadIdx.x >> 1)] = chain_sum_lds(prod + lo, len);
     }
     beside();
     __syncthreads();

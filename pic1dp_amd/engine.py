@@ -206,11 +206,19 @@ class Pic1dp:
         return f.value
 
     # -- field access -------------------------------------------------------------
-    def get_field(self):
+    def get_field(self, chargeden=True):
+        """field_electric, field_chargeden, field_mode_re / _im (src/pic1dp_field.F90:27-31).  chargeden=False
+        leaves field_chargeden alone (no key in the result): asking for it between the sub-steps of a step
+        whose half-step charge was predicted as six sums makes the library push the half-step state into
+        memory and deposit it after all -- the reference's vector, at the price of that step's short cut"""
         nx, nm = self.inp.nx, self.inp.nmode
-        E, cd, re, im = np.empty(nx), np.empty(nx), np.empty(nm), np.empty(nm)
-        check(self.L.pic1dp_hip_get_field(self._ctx, _ptr(E), _ptr(cd), _ptr(re), _ptr(im)))
-        return dict(electric=E, chargeden=cd, mode_re=re, mode_im=im)
+        E, re, im = np.empty(nx), np.empty(nm), np.empty(nm)
+        cd = np.empty(nx) if chargeden else None
+        check(self.L.pic1dp_hip_get_field(self._ctx, _ptr(E), _ptr(cd) if chargeden else None, _ptr(re), _ptr(im)))
+        out = dict(electric=E, mode_re=re, mode_im=im)
+        if chargeden:
+            out["chargeden"] = cd
+        return out
 
     def set_electric(self, E):
         E = np.ascontiguousarray(E, dtype=np.float64)
@@ -266,6 +274,22 @@ class Pic1dp:
         names = ("markr_xv", "total_xv", "pertb_xv", "markr_v", "total_v", "pertb_v")
         out = [np.empty(nxo * nvo) for _ in range(3)] + [np.empty(nvo) for _ in range(3)]
         check(self.L.pic1dp_hip_ptcldist(self._ctx, ispecies, int(finish), *[_ptr(a) for a in out]))
+        return dict(zip(names, out))
+
+    # -- split-phase diagnostics (a host that owns the reductions) --------------------
+    def output_scalars_from(self, sums):
+        """realbuf of output_field from the kinetic sums (energy_sums per species) summed over ranks"""
+        sums = np.ascontiguousarray(sums, dtype=np.float64)
+        n = 2 + 3 * self.inp.nspecies
+        out = np.empty(n)
+        check(self.L.pic1dp_hip_output_scalars_from(self._ctx, _ptr(sums), _ptr(out), n))
+        return out
+
+    def ptcldist_finish(self, raw, ispecies=0):
+        """ptcldist(finish=False) summed over ranks -> what output_ptcldist writes"""
+        names = ("markr_xv", "total_xv", "pertb_xv", "markr_v", "total_v", "pertb_v")
+        out = [np.array(raw[k], dtype=np.float64).ravel().copy() for k in names]
+        check(self.L.pic1dp_hip_ptcldist_finish(self._ctx, ispecies, *[_ptr(a) for a in out]))
         return dict(zip(names, out))
 
     # -- split-phase deposit -------------------------------------------------------

@@ -4,6 +4,7 @@
 module pic1dp_host_output
 use iso_c_binding
 use pic1dp_hip
+use pic1dp_host_ranks
 implicit none
 
 integer, parameter :: output_unit_out = 71
@@ -31,7 +32,7 @@ subroutine output_all(ctx, inp, verbosity)
   type(c_ptr), intent(in) :: ctx
   type(pic1dp_input_t), intent(in) :: inp
   integer(c_int32_t), intent(in) :: verbosity
-  real(c_double) :: scal(2 + 3 * inp%nspecies)
+  real(c_double) :: scal(2 + 3 * inp%nspecies), sums(3 * inp%nspecies)
   real(c_double) :: e(inp%nx), cd(inp%nx), re(inp%nmode), im(inp%nmode)
   real(c_double), allocatable :: mxv(:), txv(:), pxv(:), mv(:), tv(:), pv(:)
   integer(c_int32_t) :: s, itime
@@ -39,17 +40,43 @@ subroutine output_all(ctx, inp, verbosity)
   character :: cprogress
   integer :: nxv
 
-  call pic1dp_hip_check(pic1dp_hip_output_scalars(ctx, scal, int(size(scal), c_int32_t)), 'output_scalars')
-  write (output_unit_out) scal
-  call pic1dp_hip_check(pic1dp_hip_get_field(ctx, e, cd, re, im), 'get_field')
-  call output_vec(re)
-  call output_vec(im)
-  call output_vec(e)
-  call output_vec(cd)
   nxv = inp%nx_opd * inp%nv_opd
   allocate (mxv(nxv), txv(nxv), pxv(nxv), mv(inp%nv_opd), tv(inp%nv_opd), pv(inp%nv_opd))
+  if (ranks_size == 1) then
+    call pic1dp_hip_check(pic1dp_hip_output_scalars(ctx, scal, int(size(scal), c_int32_t)), 'output_scalars')
+  else
+    ! VecSum over ranks (src/pic1dp_output.F90:126-151): local sums, reduced to rank 0, finished there
+    do s = 0, inp%nspecies - 1
+      call pic1dp_hip_check(pic1dp_hip_energy_sums(ctx, s, sums(3 * s + 1 : 3 * s + 3)), 'energy_sums')
+    end do
+    call ranks_reduce_to_root(sums, 3 * inp%nspecies)
+    if (ranks_rank == 0) call pic1dp_hip_check(pic1dp_hip_output_scalars_from(ctx, sums, scal, &
+      int(size(scal), c_int32_t)), 'output_scalars_from')
+  end if
+  if (ranks_rank == 0) then
+    write (output_unit_out) scal
+    call pic1dp_hip_check(pic1dp_hip_get_field(ctx, e, cd, re, im), 'get_field')
+    call output_vec(re)
+    call output_vec(im)
+    call output_vec(e)
+    call output_vec(cd)
+  end if
   do s = 0, inp%nspecies - 1
-    call pic1dp_hip_check(pic1dp_hip_ptcldist(ctx, s, 1_c_int32_t, mxv, txv, pxv, mv, tv, pv), 'ptcldist')
+    if (ranks_size == 1) then
+      call pic1dp_hip_check(pic1dp_hip_ptcldist(ctx, s, 1_c_int32_t, mxv, txv, pxv, mv, tv, pv), 'ptcldist')
+    else
+      ! MPI_Reduce of the six histograms to rank 0 (:333-356), which scales and writes them
+      call pic1dp_hip_check(pic1dp_hip_ptcldist(ctx, s, 0_c_int32_t, mxv, txv, pxv, mv, tv, pv), 'ptcldist')
+      call ranks_reduce_to_root(mxv, nxv)
+      call ranks_reduce_to_root(txv, nxv)
+      call ranks_reduce_to_root(pxv, nxv)
+      call ranks_reduce_to_root(mv, int(inp%nv_opd))
+      call ranks_reduce_to_root(tv, int(inp%nv_opd))
+      call ranks_reduce_to_root(pv, int(inp%nv_opd))
+      if (ranks_rank == 0) call pic1dp_hip_check(pic1dp_hip_ptcldist_finish(ctx, s, mxv, txv, pxv, mv, tv, pv), &
+        'ptcldist_finish')
+    end if
+    if (ranks_rank /= 0) cycle
     write (output_unit_out) mxv
     write (output_unit_out) txv
     write (output_unit_out) pxv

@@ -15,6 +15,7 @@ integer(c_int), parameter :: PIC1DP_MAX_SPECIES = 8
 integer(c_int), parameter :: PIC1DP_MAX_MODES = 4096
 integer(c_int), parameter :: PIC1DP_MAX_INIT_MODES = 16
 integer(c_int), parameter :: PIC1DP_COMM_ID_BYTES = 128
+integer(c_int), parameter :: PIC1DP_XCHG_HANDLE_BYTES = 64
 integer(c_int), parameter :: PIC1DP_MAX_OPT = 32
 
 ! wall-clock timer ids = the reference's (src/pic1dp_global.F90:38-50)
@@ -324,6 +325,23 @@ interface
     real(c_double), intent(inout) :: markr_v(*), total_v(*), pertb_v(*)
     integer(c_int) :: ierr
   end function pic1dp_hip_ptcldist
+  function pic1dp_hip_output_scalars_from(ctx, sums, realbuf, n) bind(C, name="pic1dp_hip_output_scalars_from") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    real(c_double), intent(in) :: sums(*)
+    real(c_double), intent(inout) :: realbuf(*)
+    integer(c_int32_t), value :: n
+    integer(c_int) :: ierr
+  end function pic1dp_hip_output_scalars_from
+  function pic1dp_hip_ptcldist_finish(ctx, ispecies, markr_xv, total_xv, pertb_xv, markr_v, total_v, pertb_v) &
+      bind(C, name="pic1dp_hip_ptcldist_finish") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: ispecies
+    real(c_double), intent(inout) :: markr_xv(*), total_xv(*), pertb_xv(*)
+    real(c_double), intent(inout) :: markr_v(*), total_v(*), pertb_v(*)
+    integer(c_int) :: ierr
+  end function pic1dp_hip_ptcldist_finish
   function pic1dp_hip_charge_local(ctx, charge2) bind(C, name="pic1dp_hip_charge_local") result(ierr)
     import
     type(c_ptr), value :: ctx

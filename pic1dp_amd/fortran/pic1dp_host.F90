@@ -10,6 +10,11 @@
 !   :80      interaction_push_particle       pic1dp_hip_push(ctx, global_irk)
 !   :82      particle_optimize               pic1dp_hip_particle_optimize(ctx, global_irk, flag)
 !
+! As the reference, the host runs as one of N processes, one per GPU (src/pic1dp.F90:43-52; `make run` starts
+! four): rank / size from PIC1DP_RANK / PIC1DP_NRANKS, each rank owns its PETSC_DECIDE block of the markers, the
+! charge is summed over the GPUs inside the library (one-hop exchange; the handles are all-gathered once,
+! host_ranks.F90), and rank 0 alone writes pic1dp.out and the progress lines from diagnostics reduced to it.
+!
 ! With PIC1DP_FUSED=1 in the environment the three calls of a sub-step are
 ! replaced by the fused pic1dp_hip_substep(ctx, global_irk); with PIC1DP_FUSED=2
 ! the whole irk loop is one pic1dp_hip_step(ctx, 1) (fastest: the half-step
@@ -20,6 +25,7 @@ use iso_c_binding
 use pic1dp_hip
 use pic1dp_host_input
 use pic1dp_host_output
+use pic1dp_host_ranks
 implicit none
 
 type(pic1dp_input_t) :: inp
@@ -28,13 +34,27 @@ type(c_ptr) :: ctx
 integer(c_int32_t) :: global_irk, global_itime, itermination, due, flag_optimized
 real(c_double) :: global_time, ms_push, ms_charge, ms_field
 character(len=8) :: buf
-integer :: stat
+integer :: stat, verbosity
 logical :: fused, whole_step
+integer(c_signed_char) :: handle(PIC1DP_XCHG_HANDLE_BYTES)
+integer(c_signed_char), allocatable :: handles(:)
 
 call input_fill(inp)
-lay = pic1dp_layout_t(0, 1, 0, -1)          ! one process, one GPU
+call ranks_init()                           ! MPI_Comm_rank / MPI_Comm_size, src/pic1dp.F90:50-52
+lay = pic1dp_layout_t(ranks_rank, ranks_size, 0, -1)   ! one process per GPU (device = rank mod visible GPUs)
 call pic1dp_hip_check(pic1dp_hip_create(inp, lay, ctx), 'create')      ! particle_init + field_init
-call output_init(inp)
+if (ranks_size > 1) then
+  ! the charge sum over ranks (MPI_Allreduce, src/pic1dp_interaction.F90:130-135) is the library's one-hop
+  ! exchange: every rank's 64-byte handle to every rank, once
+  allocate (handles(PIC1DP_XCHG_HANDLE_BYTES * ranks_size))
+  call pic1dp_hip_check(pic1dp_hip_xchg_create(ctx, handle), 'xchg_create')
+  call ranks_allgather_handles(handle, PIC1DP_XCHG_HANDLE_BYTES, handles)
+  call pic1dp_hip_check(pic1dp_hip_xchg_connect(ctx, handles), 'xchg_connect')
+  call pic1dp_hip_check(pic1dp_hip_set_allreduce(ctx, 2), 'set_allreduce')
+end if
+verbosity = input_verbosity
+if (ranks_rank /= 0) verbosity = 0          ! PetscPrintf prints on rank 0 only (src/pic1dp_global.F90:71-90)
+if (ranks_rank == 0) call output_init(inp)
 call get_environment_variable('PIC1DP_FUSED', buf, status=stat)
 fused = (stat == 0 .and. buf(1:1) == '1')
 whole_step = (stat == 0 .and. buf(1:1) == '2')
@@ -51,8 +71,8 @@ call pic1dp_hip_check(pic1dp_hip_set_time(ctx, global_itime, global_time), 'set_
 ! solve initial field
 call pic1dp_hip_check(pic1dp_hip_collect_charge(ctx), 'collect_charge')
 call pic1dp_hip_check(pic1dp_hip_solve_field(ctx), 'solve_field')
-if (input_verbosity == 1) write (*, '(a/a)') 'Info: progress:', 'progrss  itime     time  int E^2 dx'
-call output_all(ctx, inp, input_verbosity)
+if (verbosity == 1) write (*, '(a/a)') 'Info: progress:', 'progrss  itime     time  int E^2 dx'
+call output_all(ctx, inp, verbosity)
 
 call pic1dp_hip_check(pic1dp_hip_check_termination(ctx, itermination), 'check_termination')
 do while (itermination == 0)                 ! main time evolution loop
@@ -66,7 +86,7 @@ do while (itermination == 0)                 ! main time evolution loop
       else
         call pic1dp_hip_check(pic1dp_hip_push(ctx, global_irk), 'push')
         call pic1dp_hip_check(pic1dp_hip_particle_optimize(ctx, global_irk, flag_optimized), 'particle_optimize')
-        if (flag_optimized == 1) call output_progress_optimized(ctx, inp, input_verbosity)
+        if (flag_optimized == 1) call output_progress_optimized(ctx, inp, verbosity)
         call pic1dp_hip_check(pic1dp_hip_collect_charge(ctx), 'collect_charge')
         call pic1dp_hip_check(pic1dp_hip_solve_field(ctx), 'solve_field')
       end if
@@ -77,11 +97,11 @@ do while (itermination == 0)                 ! main time evolution loop
   end if
   call pic1dp_hip_check(pic1dp_hip_check_termination(ctx, itermination), 'check_termination')
   call pic1dp_hip_check(pic1dp_hip_output_due(ctx, itermination, due), 'output_due')
-  if (due == 1) call output_all(ctx, inp, input_verbosity)
+  if (due == 1) call output_all(ctx, inp, verbosity)
 end do
 
-call output_final
-if (input_verbosity >= 1) then
+if (ranks_rank == 0) call output_final
+if (verbosity >= 1) then
   call pic1dp_hip_check(pic1dp_hip_timer_ms(ctx, PIC1DP_IWT_PUSH_PARTICLE, ms_push), 'timer')
   call pic1dp_hip_check(pic1dp_hip_timer_ms(ctx, PIC1DP_IWT_COLLECT_CHARGE, ms_charge), 'timer')
   call pic1dp_hip_check(pic1dp_hip_timer_ms(ctx, PIC1DP_IWT_FIELD_ELECTRIC, ms_field), 'timer')

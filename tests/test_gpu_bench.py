@@ -138,6 +138,10 @@ def test_bench_two_ranks_share_the_gpu(amd, config, particles, allreduce, self_l
         x = d["exchange"]
         assert x["weak"]["value"] > 0 and x["strong_1e8_total"]["value"] > 0
         assert "field_solve_ms_per_step" in x["weak"]["attribution"]
+        # the strong figure is the faster of the two charge sums, both printed
+        by = d["strong_1e8_total"]["by_charge_sum"]
+        assert set(by) == {d["config"]["allreduce"], "one-hop exchange"}
+        assert d["strong_1e8_total"]["value"] == max(v["value"] for v in by.values())
     else:
         assert "exchange" not in d
     if strong_cfg:

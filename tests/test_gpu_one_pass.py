@@ -132,12 +132,14 @@ def test_one_pass_through_the_call_sites(amd, monkeypatch, kind):
                 e.interaction_push_particle(irk)
                 e.interaction_collect_charge()
                 e.field_solve_electric()
-            fa, fb = a.get_field(), b.get_field()
-            cd, tol = fb["chargeden"], 1e-11
-            if kind == 2 and irk == 1 and it > 0:  # from the six sums: the kept mode's content of it
-                cd = basis @ np.linalg.lstsq(basis, cd, rcond=None)[0]
-                tol *= max(1.0, np.max(np.abs(fb["chargeden"])) / np.max(np.abs(cd)))
-            assert relerr(fa["chargeden"], cd) < tol, (it, irk)
+            # with the six sums field_chargeden holds, between the sub-steps, the kept mode's content of the
+            # half-step charge density -- all solve_field looks at; ASKING for it would rebuild the whole vector
+            # by running the half push after all (test_chargeden_between_the_sub_steps_is_rebuilt_on_inspection),
+            # so this test, which counts kernels, looks at the field only there
+            filtered = kind == 2 and irk == 1 and it > 0
+            fa, fb = a.get_field(chargeden=not filtered), b.get_field()
+            if not filtered:
+                assert relerr(fa["chargeden"], fb["chargeden"]) < 1e-11, (it, irk)
             assert relerr(fa["electric"], fb["electric"]) < 1e-11, (it, irk)
             b.set_electric(fa["electric"])
             a.set_electric(fa["electric"]) if False else None
@@ -147,6 +149,41 @@ def test_one_pass_through_the_call_sites(amd, monkeypatch, kind):
     # step 1: half + one-pass kernel; after every look at the markers the prediction is still valid
     # (downloads do not change them), so steps 2-4 need no first-sub-step pass
     assert a.kernel_stats(3)[1] == 1 and a.kernel_stats(6)[1] == 4
+
+
+def test_chargeden_between_the_sub_steps_is_rebuilt_on_inspection(amd, monkeypatch):
+    """k_step_sums (grids beyond nx ~ 2400; forced here): the collect_charge after push(1) is served from six
+    sums and leaves in field_chargeden the kept mode's content of the half-step charge density.  A host that
+    LOOKS at field_chargeden there (a custom half-step diagnostic; the reference driver never does) gets the
+    reference's full vector: the library pushes the half-step state into memory after all and deposits it --
+    equal to the eager engine's deposit to rounding, not a filtered one --, and the run goes on correctly."""
+    kw = dict(nparticle_max=N, nx=96, init_nmode=2, init_mode=[1, 3], init_mode_cos=[0.0, 0.0], init_mode_sin=[1e-3, 5e-4])
+    a = engine(amd, monkeypatch, True, 2, **kw)
+    monkeypatch.setenv("PIC1DP_LAZY_CALLS", "0")
+    b = engine(amd, monkeypatch, False, **kw)
+    monkeypatch.delenv("PIC1DP_LAZY_CALLS")
+    a.kernel_stats_enable(True)
+    for it in range(4):
+        for irk in (1, 2):
+            for e in (a, b):
+                e.interaction_push_particle(irk)
+                e.interaction_collect_charge()
+                e.field_solve_electric()
+            look = it == 2 and irk == 1          # once, in a step whose half-step charge was predicted
+            fa, fb = a.get_field(chargeden=look), b.get_field()
+            if look:
+                cd = fb["chargeden"]
+                # mode 3 was loaded too and is NOT kept by the field solve: it is in the full vector only
+                spec = np.abs(np.fft.rfft(cd))
+                assert spec[3] > 0.05 * spec[1]
+                assert relerr(fa["chargeden"], cd) < 1e-11
+            assert relerr(fa["electric"], fb["electric"]) < 1e-10, (it, irk)
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-10 * max(1.0, np.max(np.abs(gb[k]))), k
+    # steps 0 (first step) and 2 (the inspection) took the two-pass kernels, 1 and 3 the one-pass kernel... the step
+    # AFTER the inspection has no prediction to start from either
+    assert a.kernel_stats(6)[1] >= 1 and a.kernel_stats(3)[1] >= 2
 
 
 @pytest.mark.parametrize("kw", [dict(nx=96), dict(nx=1000), dict(nx=2050, deltaf=0),

@@ -193,6 +193,68 @@ def test_fortran_host_drop_in(oracle_mod, amd, tmp_path):
         assert relerr(dd.electric[-1], sim.get_field()[0]) < 1e-10
 
 
+def fortran_host_exe():
+    exe = os.path.join(ROOT, "pic1dp_amd", "fortran", "pic1dp_host")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-C", os.path.dirname(exe)], capture_output=True, text=True)
+        if not os.path.exists(exe):
+            flang = shutil.which("flang") or (os.path.exists("/opt/rocm/lib/llvm/bin/flang") and "/opt/rocm/lib/llvm/bin/flang")
+            assert not flang, "Fortran host does not build although flang is present:\n" + r.stdout[-1500:] + r.stderr[-1500:]
+            pytest.skip("no Fortran compiler on this box")
+    return exe
+
+
+@pytest.mark.parametrize("nranks,fused", [(2, "0"), (3, "2")], ids=["two_ranks_call_sites", "three_ranks_whole_step"])
+def test_fortran_host_as_one_of_n_ranks(oracle_mod, amd, tmp_path, nranks, fused):
+    """the reference is an MPI program (src/pic1dp.F90:43-52; `mpiexec -n 4`, run/Makefile:41): N processes of the
+    shipped Fortran host -- rank / size from the environment, each owning its PETSC_DECIDE block, the charge
+    summed by the library's one-hop exchange (here between processes sharing the box's one GPU), the exchange
+    handles all-gathered and the diagnostics reduced to rank 0 through host_ranks.F90 (files standing in for the
+    MPI the image lacks) -- write on rank 0 the pic1dp.out of the N-rank oracle run"""
+    exe = fortran_host_exe()
+    from pic1dp_amd import output
+    rdv = tmp_path / "rendezvous"
+    rdv.mkdir()
+    env = dict(os.environ, PIC1DP_NPARTICLE="90001", PIC1DP_NX="64", PIC1DP_TIME_MAX="1.0", PIC1DP_FUSED=fused,
+               PIC1DP_NRANKS=str(nranks), PIC1DP_RENDEZVOUS=str(rdv), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PIC1DP_XCHG_TIMEOUT_MS="60000")
+    procs = []
+    for r in range(nranks):
+        wd = tmp_path / ("rank%d" % r)
+        wd.mkdir()
+        procs.append(subprocess.Popen([exe], cwd=str(wd), env=dict(env, PIC1DP_RANK=str(r)), stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r])
+    assert "progrss  itime     time  int E^2 dx" in outs[0] and outs[0].count("%") == 3
+    for r in range(1, nranks):                                  # PetscPrintf: rank 0 only
+        assert "%" not in outs[r] and not os.path.exists(str(tmp_path / ("rank%d" % r) / "pic1dp.out"))
+    d = output.OutputData(str(tmp_path / "rank0" / "pic1dp.out"))
+    assert d.ntime == 3 and d.nx == 64 and list(d.scalars[:, 0]) == accumulated_times(0.05, [0, 10, 20])
+    sim = oracle_mod.Sim(oracle_mod.make_input(nparticle_max=90001, nx=64, time_max=1.0), npe=nranks)
+    sim.load()
+    sim.collect_charge()
+    sim.solve_field()
+    want = [sim.output_scalars()]
+    for _ in range(2):
+        sim.step(10)
+        want.append(sim.output_scalars())
+    want = np.array(want)
+    assert np.max(np.abs(d.scalars[:, 1] / want[:, 1] - 1.0)) < 1e-10       # int E^2 dx
+    assert np.max(np.abs(d.scalars[:, 2:] / want[:, 2:] - 1.0)) < 1e-9      # kinetic sums over all ranks
+    assert relerr(d.electric[-1], sim.get_field()[0]) < 1e-10
+    assert relerr(d.ptcldist[-1][0]["total_xv"].ravel(), sim.ptcldist()["total_xv"]) < 1e-9
+    assert relerr(d.ptcldist[-1][0]["markr_v"].ravel(), sim.ptcldist()["markr_v"]) < 1e-9
+
+
 @pytest.mark.parametrize("kw,mode", [
     (dict(), "step"), (dict(), "calls"), (dict(linear=1), "step"),
     (dict(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0]), "step"),

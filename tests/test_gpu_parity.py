@@ -76,7 +76,8 @@ def dlnf0_pieces(inp, v):
     tm, tm2 = T / m, T2 / m
     if inp.iptcldist == 3:
         A, B = v / tm, (v - v0) / tm2
-        lnK = np.log((1 - den) * np.sqrt(tm)) - np.log(den * np.sqrt(tm2))
+        with np.errstate(divide="ignore"):
+            lnK = np.log((1 - den) * np.sqrt(tm)) - np.log(den * np.sqrt(tm2))     # -inf without a beam
         a1, a2 = v * v / (2 * tm), (v - v0) ** 2 / (2 * tm2)
         L = lnK + a1 - a2
         h1, h2 = 1 / (2 * tm), 1 / (2 * tm2)

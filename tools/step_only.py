@@ -12,7 +12,9 @@ nx = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 import json  # noqa: E402
 extra = json.loads(os.environ.get("PIC1DP_INPUT", "{}"))
-eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=n, nx=nx, **extra))
+# PIC1DP_NPE: reference ranks reproduced as virtual ranks of this one process (the field solve then sums in the
+# npe-rank order: npe partial chains side by side)
+eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=n, nx=nx, **extra), npe=int(os.environ.get("PIC1DP_NPE", "1")))
 eng.particle_load()
 eng.interaction_collect_charge()
 eng.field_solve_electric()
