@@ -62,9 +62,10 @@ def main():
     if fused:
         by_kernel["k_push"] = sum(r["hbm_bytes"] * r["launches"] for r in fused) / sum(r["launches"] for r in fused)
     res = dict(particles_per_gpu=n, nx=nx, hbm_bytes_per_launch_by_kernel=by_kernel,
-               compulsory_bytes_per_marker=dict(k_step_half=32.0, k_step_full=56.0, k_step_one=72.0, k_step_sums=56.0),
-               compulsory_note="k_step_one / k_step_sums: 56 B + 16 B carry of -f0'/f0 for the exp-bearing distributions "
-                               "(bump-on-tail, two-stream2); 56 B otherwise (Maxwellian: BASELINE configs[4])",
+               compulsory_bytes_per_marker=dict(k_step_half=32.0, k_step_full=56.0, k_step_one=56.0, k_step_sums=56.0),
+               compulsory_note="32 B read (x, v, w, p) + 24 B written (x, v, w) per marker and launch of a whole-step "
+                               "kernel; a carry of -f0'/f0 (PIC1DP_CARRY=1, or the reference-order form: 8 B read + 8 B "
+                               "written) is traffic the kernel chooses, reported apart by pic1dp_hip_kernel_bytes",
                reference_priced_bytes_per_update=80.0,
                correction="FETCH_SIZE x2 (gfx950 wide coalesced reads), WRITE_SIZE exact; KiB units",
                kernels=rows)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # collect_profiles.sh -- the rocprofv3 evidence of profiles/ in one go (run on the GPU box):
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/collect_profiles.sh r02 [c3|c5]'
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/collect_profiles.sh r03 [c3|c5]'
 # Leaves everything under gpurun_out/<tag>/; copy the summaries into profiles/<tag>/ afterwards
 # (cp).  Counter passes are separate runs with --kernel-trace only.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 CFG=${2:-c3}
 NX=1024
 [ "$CFG" = c5 ] && NX=4096
