@@ -193,6 +193,29 @@ def test_fortran_host_drop_in(oracle_mod, amd, tmp_path):
         assert relerr(dd.electric[-1], sim.get_field()[0]) < 1e-10
 
 
+def test_split_phase_diagnostics_for_a_host_that_owns_the_reduction(amd):
+    """a host with its own MPI_Reduce (src/pic1dp_output.F90:126-151,333-356) takes the local sums, reduces them
+    and hands them back: on one rank the two halves must compose to what the library writes itself -- delta-f,
+    linear (total += pertb) and full-f (pertb = total - f0)"""
+    for kw in (dict(), dict(linear=1), dict(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0])):
+        eng = amd.Pic1dp(amd.make_input(nparticle_max=100_001, nx=64, **kw))
+        eng.particle_load()
+        eng.interaction_collect_charge()
+        eng.field_solve_electric()
+        eng.step(3)
+        whole = eng.output_scalars()
+        halves = eng.output_scalars_from(eng.energy_sums())
+        assert np.array_equal(whole, halves), kw
+        fin = eng.ptcldist(0, finish=True)
+        raw = eng.ptcldist(0, finish=False)
+        again = eng.ptcldist_finish(raw)
+        for k in fin:
+            assert np.array_equal(fin[k].ravel(), again[k]), (kw, k)
+        # and twice the markers (two identical ranks) is twice the sums before the finishing, not after
+        two = eng.ptcldist_finish({k: 2.0 * v for k, v in raw.items()})
+        assert np.allclose(two["markr_xv"], 2.0 * fin["markr_xv"].ravel(), rtol=1e-14)
+
+
 def fortran_host_exe():
     exe = os.path.join(ROOT, "pic1dp_amd", "fortran", "pic1dp_host")
     if not os.path.exists(exe):

@@ -1039,3 +1039,40 @@ def test_lazy_call_sites_field_changes_between_calls(amd, monkeypatch):
     ga, gb = a.particles_download(), b.particles_download()
     for k in "xvw":
         assert np.array_equal(ga[k], gb[k]), k
+
+
+def test_library_reports_the_bytes_its_kernels_move(amd, monkeypatch):
+    """pic1dp_hip_kernel_bytes: what the marker kernel launched last moves per marker -- read and written bytes
+    compulsory for its data flow, the carry of -f0'/f0 apart (bench.py prices its roofline on these instead of
+    guessing from constants)"""
+    def run(**kw):
+        eng = amd.Pic1dp(amd.make_input(nparticle_max=50_001, nx=64, **kw))
+        eng.particle_load()
+        eng.interaction_collect_charge()
+        eng.field_solve_electric()
+        eng.step(3)
+        return eng
+    eng = run()
+    one = eng.kernel_bytes(6)
+    assert (one["read"], one["written"], one["carry"]) == (32.0, 24.0, 0.0) and one["name"].startswith("k_step_one")
+    assert "one-exp" in one["name"]
+    half = eng.kernel_bytes(3)
+    assert (half["read"], half["written"], half["carry"]) == (32.0, 0.0, 0.0) and half["name"] == "k_step_half (one-exp -f0'/f0)"
+    monkeypatch.setenv("PIC1DP_CARRY", "1")
+    assert run().kernel_bytes(6)["carry"] == 16.0
+    monkeypatch.delenv("PIC1DP_CARRY")
+    monkeypatch.setenv("PIC1DP_DLNF0", "ref")          # the reference-order form carries by default
+    ref = run().kernel_bytes(6)
+    assert ref["carry"] == 16.0 and "one-exp" not in ref["name"]
+    monkeypatch.delenv("PIC1DP_DLNF0")
+    lin = run(linear=1).kernel_bytes(6)
+    assert (lin["read"], lin["written"]) == (32.0, 16.0)          # v is not pushed in a linear run
+    ff = run(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0]).kernel_bytes(6)
+    assert (ff["read"], ff["written"], ff["carry"]) == (24.0, 16.0, 0.0)          # no w in a full-f run
+    monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
+    assert run().kernel_bytes(6)["name"].startswith("k_step_sums")
+    eng = run()
+    eng.interaction_push_particle(1)
+    eng.particles_download()                           # materialised: the eager push kernel ran
+    push = eng.kernel_bytes(1)
+    assert (push["read"], push["written"]) == (32.0, 24.0) and push["name"] == "k_push"

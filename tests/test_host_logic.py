@@ -280,3 +280,51 @@ def test_bench_launcher_parent_never_loads_the_hip_library():
     spec.loader.exec_module(mod)
     assert mod.pic1dp_amd is None
     assert not [m for m in set(sys.modules) - before if m.startswith(("pic1dp_amd", "torch"))]
+
+
+def test_probe_library_exports_every_declared_symbol(probe):
+    """libpic1dp_probe.so (measurement / test support) exports what include/pic1dp_probe.h declares, and the
+    product library exports none of it"""
+    src = open(os.path.join(ROOT, "include", "pic1dp_probe.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(pic1dp_probe_\w+)\s*\(", src)))
+    assert len(names) >= 10
+    lib = C.CDLL(probe.LIB_PATH)
+    assert not [n for n in names if not hasattr(lib, n)]
+    assert sorted(probe.SIGNATURES) == names
+    import pic1dp_amd
+    product = C.CDLL(pic1dp_amd._lib.LIB_PATH)
+    assert not [n for n in names if hasattr(product, n)]
+    assert not [n for n in declared_functions() if "probe" in n or "debug" in n]
+
+
+@pytest.mark.parametrize("name,kw", DIST_CASES, ids=[c[0] for c in DIST_CASES])
+def test_one_exp_constants_of_a_species(amd, probe, monkeypatch, name, kw):
+    """the folded constants of the one-exp form of -f0'/f0 (pic1dp_amd/csrc/species.cpp) against their definition
+    (src/pic1dp_interaction.F90:278-321: the log of the ratio of the two Maxwellians is a quadratic in v, the
+    blend of A = v/(T/m) and B = (v - v0)/(T2/m) is linear in v), and the switch that keeps the reference's
+    operation order"""
+    inp = amd.make_input(nparticle_max=16, **kw)
+    sp = probe.species(inp)
+    c = probe.species_const(sp)
+    T, T2, m = inp.species_temperature[0], inp.species_temperature2[0], inp.species_mass[0]
+    den, v0 = inp.species_density[0], inp.species_v0[0]
+    tm, tm2 = T / m, T2 / m
+    assert c["unit"] == int(T == 1.0 and T2 == 1.0 and m == 1.0)
+    if inp.iptcldist not in (2, 3):
+        assert c["one_exp"] == 0
+        return
+    assert c["one_exp"] == 1
+    fq2, fq1, fq0, fm1, fm0, fd1, fd0 = c["f"]
+    v = np.linspace(-8.0, 8.0, 33)
+    if inp.iptcldist == 3:
+        L = np.log((1 - den) * np.sqrt(tm) / (den * np.sqrt(tm2))) + v * v / (2 * tm) - (v - v0) ** 2 / (2 * tm2)
+        A, B = v / tm, (v - v0) / tm2
+    else:
+        L = -2.0 * v * v0 / tm
+        A, B = (v - v0) / tm, (v + v0) / tm
+    assert np.allclose((fq2 * v + fq1) * v + fq0, L, rtol=1e-13, atol=1e-13)
+    assert np.allclose(fm1 * v + fm0, (A + B) / 2, rtol=1e-13, atol=1e-13)
+    assert np.allclose(fd1 * v + fd0, (B - A) / 2, rtol=1e-13, atol=1e-13)
+    monkeypatch.setenv("PIC1DP_DLNF0", "ref")
+    assert probe.species_const(sp)["one_exp"] == 0
