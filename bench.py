@@ -629,7 +629,9 @@ def main():
         half_ms, half_n = ktab["k_step_half"]
         full_ms, full_n = ktab["k_step_full"]
         one_ms, one_n = ktab["k_step_one"]
-        sums = bool(one_n) and eng.predict_kind() == 2
+        one_name = kb["k_step_one"]["name"]
+        sums = bool(one_n) and one_name.startswith("k_step_sums")        # the large-grid kernel
+        priv = bool(one_n) and one_name.startswith("k_step_one<sums>")   # six sums in thread-private LDS slots
         lazy = ", reached through the three reference call sites per sub-step (lazy call sites)" if a.unfused else ""
         if sums:
             dom = "k_step_one"
@@ -638,6 +640,13 @@ def main():
                      "half-step field)")
             path = ("one pass over the markers per step (k_step_sums; the next half-step field follows from six sums "
                     "over the markers taken by the previous step's kernel)" + lazy)
+        elif priv:
+            dom = "k_step_one"
+            kname = ("k_step_one<sums> (one pass per step: recompute half-step state, push+gather, wrap, deposit, store in "
+                     "place, and six sums over the markers -- in thread-private LDS slots -- that predict the next step's "
+                     "half-step field)")
+            path = ("one pass over the markers per step (k_step_one; the next half-step field follows from six sums over "
+                    "the markers taken by the previous step's kernel)" + lazy)
         elif one_n:
             dom = "k_step_one"
             kname = ("k_step_one (one pass per step: recompute half-step state, push+gather, wrap, deposit, store in "
@@ -667,7 +676,7 @@ def main():
         # profiles/ (a profile constant of the same workload, NOT measured in this run)
         traffic, traffic_src, traffic_why = None, None, None
         tkey = "k_step_one" if one_n else ("k_step_full" if full_n else "k_push")
-        if one_n and eng.predict_kind() == 2:
+        if sums:
             tkey = "k_step_sums"
         if world == 1 and not a.no_traffic_pass and not a.unfused and a.step_mode == 0:
             traffic, traffic_why = measure_traffic(a, tkey)
@@ -684,9 +693,7 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("particles_per_gpu") == per_gpu and tj.get("nx") == phys["nx"]:
-                    key = "k_step_one" if one_n else ("k_step_full" if full_n else "k_push")
-                    if one_n and eng.predict_kind() == 2:
-                        key = "k_step_sums"
+                    key = tkey
                     traffic = tj.get("hbm_bytes_per_launch_by_kernel", {}).get(key)
                     traffic_src = "profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
                                   "this command (committed profile of the same workload, not measured in this run%s)" \
@@ -727,7 +734,7 @@ def main():
                 "path": path, "allreduce": headline_kind, "rccl_ranks": world if headline_kind == "rccl" else 0,
                 "exchange_memkind": {0: None, 1: "fine-grained", 2: "uncached", 3: "plain"}[job.xchg_memkind],
                 "marker_layout": "x, v, w, p interleaved in 32 KiB tiles in one slab per species",
-                "kernel_launches_in_timed_steps": {("k_step_sums" if k == "k_step_one" and eng.predict_kind() == 2 else k): v[1]
+                "kernel_launches_in_timed_steps": {("k_step_sums" if k == "k_step_one" and sums else k): v[1]
                                                    for k, v in ktab.items() if v[1]},
                 "sync": sync_kind, "load_seconds": job.load_s,
             },

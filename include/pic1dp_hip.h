@@ -265,9 +265,9 @@ int pic1dp_hip_step(pic1dp_ctx *ctx, int32_t nsteps);
  *     coefficients of the kept field modes: 56-72 B per marker per step; the
  *     half-step charge then equals a marker-by-marker deposit up to rounding;
  *     PIC1DP_PREDICT=0 in the environment keeps the two passes, 88 B).  The
- *     prediction is held as LDS tiles (up to two kept modes, nx up to ~2400) or,
- *     for larger grids with one kept mode (nx up to ~5000), as six sums over the
- *     markers -- then, through the call sites, the collect_charge after push(1)
+ *     prediction is held as LDS tiles (two kept modes, or one on grids below
+ *     nx = 512; nx up to ~2400) or, with one kept mode (nx up to ~5000), as six
+ *     sums over the markers -- then, through the call sites, the collect_charge after push(1)
  *     leaves in field_chargeden the kept mode's content of the half-step charge
  *     density only (all that solve_field looks at; nothing in the reference driver
  *     reads it there).  A host that DOES read it there gets the reference's vector:
@@ -316,7 +316,7 @@ int pic1dp_hip_output_due(pic1dp_ctx *ctx, int32_t itermination, int32_t *flag);
  * HALF-STEP CHARGE DENSITY -- the one place where the state a host can look at differs
  * from what the reference would hold: between the collect_charge after push(1) and the
  * next collect_charge, when that half-step charge was predicted as six sums
- * (pic1dp_hip_predict_kind = 2: grids beyond nx ~ 2400, one kept mode), field_chargeden
+ * (pic1dp_hip_predict_kind = 2: one kept mode on grids from nx = 512 up), field_chargeden
  * holds its kept mode's content only.  Asking for chargeden here rebuilds the whole
  * vector on a one-rank context: the half-step state is pushed into memory after all and
  * deposited (that step then runs as two ordinary sub-steps; results unchanged to

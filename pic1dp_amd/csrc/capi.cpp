@@ -103,6 +103,8 @@ struct pic1dp_ctx {
   int pair_plain = 0;              // PIC1DP_PAIR_PLAIN
   int osub_req = 0;                // PIC1DP_OSUB: grid size of the marker kernels in units of the resident one (0: auto)
   int pred_kind = 0;               // 0 no one-pass step here, 1 prediction tiles (k_step_one), 2 six sums (k_step_sums)
+  int pred_private = 0;            // pred_kind 2 and E0, Eh, the table tiles and the private sums of two workgroups fit a
+                                   // CU's LDS: the sums are taken by k_step_one<PRIV> (thread-private LDS slots)
   PredTab pred_tab{};              // kind 2: sums / Gram matrix of the kept mode's tables (host, libm)
   int eh_modes = 0;                // kind 2: where the kept mode of the Eh about to be used lies: 0 nowhere, 1 fa.mode_*, 2 d_mode_h
   bool charge_pending_pred = false;  // kind 2: charge_local handed out the six sums, not a charge vector
@@ -122,7 +124,9 @@ struct pic1dp_ctx {
   // 0 field_chargeden is current; 1 d_charge holds the summed charge1, its scaling is pending; 2 (one rank) the
   // species accumulators hold the deposits, species sum and scaling pending; 3 (one rank, mode-filter solve, few
   // modes) k_step_one's prediction accumulators hold the charge, combination with the kept modes, species sum and
-  // scaling pending.  materialize_cd() before anything else looks at charge, chargeden or the accumulators.
+  // scaling pending; 4 (one rank, mode-filter solve) the six sums of the prediction are pending: the kept mode's
+  // content of chargeden follows from them.  materialize_cd() before anything else looks at charge, chargeden or the
+  // accumulators.
   int cd_lazy = 0;
   // field_chargeden holds only the kept mode's content of the half-step charge density (collect_charge after a
   // noted push(1) served from the six sums, pred_kind 2): all solve_field looks at, but not what the reference
@@ -749,16 +753,25 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     }
     // one pass per step: with prediction tiles where they fit the LDS (k_step_one), as six sums for larger
     // grids with one kept mode (k_step_sums); PIC1DP_PRED_KIND=1|2 insists on one of them (tests)
+    const bool private_fits = 2 * (step_one_private_lds_bytes(nx, c->grid.rcopies) + kStaticLds) <= kCuLds;
     if (nm <= PRED_MAX_MODES && step_one_lds_bytes(nx, c->grid.rcopies, nm) <= PARTICLE_LDS_CAP)
       c->pred_kind = 1;
     // (the six sums travel in the head of an nx-vector on the call-site path: nx >= 8)
     else if (nm == 1 && nx >= 8 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP)
       c->pred_kind = 2;
+    // One kept mode on a grid of some size: the six sums in thread-private LDS slots (k_step_one<PRIV>) beat the
+    // tiles, whose six atomics per marker at random cells pay ~3x in bank conflicts: -2 % at 1e8 markers / nx 1024,
+    // -1 % at 1.25e7 / 1024, level at nx 256 and 192 where the field launch of the sums is 2-3 us longer
+    // (profiles/r03/experiments/ab_private_sums.log) -- so from nx = 512 up.
+    if (c->pred_kind == 1 && nm == 1 && nx >= 512 && private_fits) c->pred_kind = 2;
     if (const char *e = std::getenv("PIC1DP_PRED_KIND")) {
       const int k = std::atoi(e);
       if (k == 2 && nm == 1 && nx >= 8 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP) c->pred_kind = 2;
-      if (k == 1 && c->pred_kind != 1) c->pred_kind = 0;
+      // 1: the tiles wherever they fit (else the choice above stands)
+      if (k == 1 && nm <= PRED_MAX_MODES && step_one_lds_bytes(nx, c->grid.rcopies, nm) <= PARTICLE_LDS_CAP) c->pred_kind = 1;
     }
+    if (c->pred_kind == 2 && private_fits) c->pred_private = 1;
+    if (const char *e = std::getenv("PIC1DP_PRED_PRIVATE")) c->pred_private = c->pred_private && std::atoi(e) != 0;
     if (c->pred_kind) {  // the tables: E = 2*(cos re + (-sin) im) (src/pic1dp_field.F90:251-257)
       std::vector<double> ta(fre.size()), tb(fim.size());
       for (size_t i = 0; i < fre.size(); ++i) ta[i] = 2.0 * fre[i], tb[i] = 2.0 * fim[i];
@@ -769,7 +782,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
           pt.g11 += fre[ix] * fre[ix], pt.g22 += fim[ix] * fim[ix], pt.g12 += fre[ix] * fim[ix];
         }
       }
-      const size_t pred_doubles = c->pred_kind == 2 ? 8 : static_cast<size_t>(ns) * (1 + 2 * nm) * nx;
+      const size_t pred_doubles = c->pred_kind == 2 ? 8 * PRED_SUM_COPIES : static_cast<size_t>(ns) * (1 + 2 * nm) * nx;
       HIP_TRY_C(hipMalloc(&c->d_tabA, sizeof(double) * nm * nx));
       HIP_TRY_C(hipMalloc(&c->d_tabB, sizeof(double) * nm * nx));
       HIP_TRY_C(hipMalloc(&c->d_pred, sizeof(double) * pred_doubles));
@@ -1051,6 +1064,10 @@ static int materialize_cd(pic1dp_ctx *c) {
   const int pending = c->cd_lazy;
   c->cd_lazy = 0;
   if (pending == 0) return 0;
+  if (pending == 4) {  // the six sums of a predicted push(1): the kept mode's content of chargeden, directly
+    HIP_TRY(launch_pred_chargeden(c->fa, c->pred_tab, c->d_pred, nullptr, c->st));
+    return 0;
+  }
   if (pending == 3) HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
   HIP_TRY(launch_chargeden(c->fa, pending == 2, c->st));
   return 0;
@@ -1208,9 +1225,12 @@ int pic1dp_hip_solve_field(pic1dp_ctx *c) {
   c->cd_lazy = 0;
   if (pending == 3 && c->field_solver == 0) {
     HIP_TRY(launch_field_solve_pred(f, c->d_pred, c->in.nmode, c->st));
+  } else if (pending == 4 && c->field_solver == 0) {
+    HIP_TRY(launch_field_solve_pred_sums(f, c->pred_tab, c->d_pred, c->st));
   } else {
+    if (pending == 4) HIP_TRY(launch_pred_chargeden(c->fa, c->pred_tab, c->d_pred, nullptr, c->st));
     if (pending == 3) HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
-    if (int rc = enqueue_field_solve(c, f, pending == 2, pending == 0)) return rc;
+    if (int rc = enqueue_field_solve(c, f, pending == 2, pending == 0 || pending == 4)) return rc;
   }
   field_written(c, true);
   return tm.end();
@@ -1463,13 +1483,14 @@ static bool predict_capable(const pic1dp_ctx *c) {
   return c->predict && c->pred_kind != 0 && c->d_pred && c->field_solver == 0 && step_recompute_ok(c);
 }
 static size_t pred_doubles(const pic1dp_ctx *c) {
-  return c->pred_kind == 2 ? 8 : static_cast<size_t>(c->in.nspecies) * (1 + 2 * c->in.nmode) * c->in.nx;
+  return c->pred_kind == 2 ? 8 * PRED_SUM_COPIES : static_cast<size_t>(c->in.nspecies) * (1 + 2 * c->in.nmode) * c->in.nx;
 }
 
 // full = true: the caller has bumped state_version for this step; the state the kernel READS is version - 1
 static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag, bool pred) {
   if (pred && (!full || diag || !predict_capable(c))) pred = false;
-  if (pred && c->pred_kind == 2 && c->eh_modes == 0) pred = false;  // k_step_sums forms Eh from its kept mode
+  const bool priv = c->pred_kind == 2 && c->pred_private && c->threads_req <= 0;  // k_step_one<PRIV>: Eh from its tile
+  if (pred && c->pred_kind == 2 && !priv && c->eh_modes == 0) pred = false;  // k_step_sums forms Eh from its kept mode
   if (pred && c->pred_version != 0)  // a prediction nobody used: the accumulators start from zero
     HIP_TRY(hipMemsetAsync(c->d_pred, 0, sizeof(double) * pred_doubles(c), c->st));
   // the diagnostics of output_all inside k_step_full: when asked for, the LDS holds them, and the
@@ -1535,6 +1556,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       a.pred = c->pred_kind == 2 ? c->d_pred  // six sums, all species together (Z folded in)
                                  : c->d_pred + static_cast<size_t>(s) * (1 + 2 * c->in.nmode) * c->in.nx;
       a.pred_nm = c->in.nmode;
+      a.pred_private = priv ? 1 : 0;
       if (c->pred_kind == 2) {
         a.eh_re = c->eh_modes == 2 ? c->d_mode_h : c->fa.mode_re;
         a.eh_im = c->eh_modes == 2 ? c->d_mode_h + 1 : c->fa.mode_im;
@@ -1554,12 +1576,13 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
         a.t2_mode = S.t2_version == read_version ? 2 : 1;
         S.t2_version = c->state_version;
       }
-      lc.lds = c->pred_kind == 2 ? step_sums_lds_bytes(c->in.nx, c->grid.rcopies)
-                                 : step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode);
+      lc.lds = priv ? step_one_private_lds_bytes(c->in.nx, c->grid.rcopies)
+                    : (c->pred_kind == 2 ? step_sums_lds_bytes(c->in.nx, c->grid.rcopies)
+                                         : step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode));
       bool two = 2 * (lc.lds + kStaticLds) <= kCuLds;  // both workgroups resident: each also holds the static exp table
-      int th2 = 768;
+      int th2 = 768;   // (= STEP_PRIVATE_THREADS: the private sums' slot stride is a compile-time constant)
       int th1 = 1024;
-      if (c->pred_kind == 2) {
+      if (c->pred_kind == 2 && !priv) {
         // k_step_sums keeps its registers: four waves per SIMD with the exp-bearing distributions (one
         // workgroup of 1024 per CU), eight with the others, which saturate the memory system with far fewer
         // (tools/ab_sums_shapes.sh: 1e8 markers, Maxwellian, nx 4096: 512 x 1 0.925 ms, 1024 x 1 0.965 ms)
@@ -1596,7 +1619,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       kb.wr = full ? 8.0 * (1 + (c->in.linear ? 0 : 1) + (c->in.deltaf ? 1 : 0)) : 0.0;
       kb.carry = 0.0;
       if (a.t2) kb.carry = pred ? (a.t2_mode == 2 ? 16.0 : 8.0) : 8.0;  // k_step_one: 8 read (mode 2) + 8 written
-      std::snprintf(kb.name, sizeof kb.name, "%s%s", pred ? (c->pred_kind == 2 ? "k_step_sums" : "k_step_one")
+      std::snprintf(kb.name, sizeof kb.name, "%s%s", pred ? (c->pred_kind == 2 ? (priv ? "k_step_one<sums>" : "k_step_sums") : "k_step_one")
                                                           : (full ? (diag ? "k_step_full<DIAG>" : "k_step_full") : "k_step_half"),
                     S.sc.one_exp && c->in.deltaf ? " (one-exp -f0'/f0)" : "");
     }
@@ -1638,8 +1661,12 @@ static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer = fal
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (c->pred_kind == 2) {
     if (f.chargeden == c->d_chargeden) c->cd_kept_mode_only = true;
+    if (defer && !multi && c->field_solver == 0 && f.tab_lds) {
+      c->cd_lazy = 4;  // the sums' combination, chargeden and the solve in the launch of the solve_field that follows
+      return 0;
+    }
     if (!multi) {
-      HIP_TRY(launch_pred_chargeden(f, c->pred_tab, c->d_pred, c->d_pred, c->st));
+      HIP_TRY(launch_pred_chargeden(f, c->pred_tab, c->d_pred, nullptr, c->st));
       return 0;
     }
     HIP_TRY(launch_pred_to_charge(c->fa, c->d_pred, c->st));

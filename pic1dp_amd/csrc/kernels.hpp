@@ -146,12 +146,17 @@ struct StepArgs {
   double *pred;
   int pred_nm, t2_mode;
   // pred_kind 2 (kernels.hip k_step_sums, for grids whose prediction tiles outgrow the LDS; one kept mode): pred is
-  // [8] -- six global sums K0c K1c K2c K0s K1s K2s shared by all species (Z folded in) --, and Eh is not staged
+  // [PRED_SUM_COPIES][8] -- six global sums K0c K1c K2c K0s K1s K2s shared by all species (Z folded in), in copies --, and Eh is not staged
   // but formed from the tables and its kept mode *eh_re, *eh_im (Eh = re A + im B, bit for bit what the solve wrote)
   int pred_kind;  // 1 tiles (k_step_one), 2 sums (k_step_sums)
+  int pred_private;  // pred_kind 2 on a grid whose E0, Eh and table tiles fit the LDS: k_step_one<PRIV>, the six sums in
+                     // thread-private LDS slots (Eh staged from memory like k_step_one's)
   const double *eh_re, *eh_im;
 };
 constexpr int PRED_MAX_MODES = 2;
+// pred_kind 2: the six sums (padded to 8) are kept in this many copies -- workgroup b of the marker kernel adds into
+// copy b % PRED_SUM_COPIES, the field kernels add the copies up: six addresses shared by all workgroups serialise
+constexpr int PRED_SUM_COPIES = 16;
 // dynamic LDS of k_step_sums: E0, A, B tiles (with guard cell), rho copies, reduction scratch
 inline size_t step_sums_lds_bytes(int nx, int rcopies) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
@@ -164,6 +169,15 @@ inline size_t step_one_lds_bytes(int nx, int rcopies, int nm) {
   return sizeof(double) * (2 * ne + (static_cast<size_t>(nx) + 1) * 2 * nm +
                            ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) +
                            (static_cast<size_t>(nx) + 2) * (1 + 2 * nm));
+}
+// dynamic LDS of k_step_one<PRIV>: E0, Eh tiles, the one mode's tables cell by cell (nx + 1 cells of 2), rho copies,
+// six private sums per thread, reduction scratch
+constexpr int STEP_PRIVATE_THREADS = 768;  // k_step_one<PRIV> is launched with exactly this many threads per workgroup
+inline size_t step_one_private_lds_bytes(int nx, int rcopies, int threads = STEP_PRIVATE_THREADS) {
+  const size_t ne = static_cast<size_t>((nx + 2) & ~1);
+  return sizeof(double) * (2 * ne + (static_cast<size_t>(nx) + 1) * 2 +
+                           ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) +
+                           6 * static_cast<size_t>(threads) + 16);
 }
 // dynamic LDS of the DIAG variant beyond the grid tiles: histograms + reduction scratch
 inline size_t step_diag_lds_bytes(int nx, int rcopies, int nxo, int nvo) {
@@ -221,7 +235,7 @@ struct PredTab {
   double sum_fre, sum_fim, g11, g22, g12;
 };
 struct PairArgs {
-  double *pred;     // kind 1: [nspecies][1 + 2 nmode][nx]; kind 2: [8] the six sums; consumed (re-zeroed)
+  double *pred;     // kind 1: [nspecies][1 + 2 nmode][nx]; kind 2: [PRED_SUM_COPIES][8] the six sums; consumed (re-zeroed)
   double *E_h;      // [nx] half-step field of the next step
   double *mode_h;   // [2 nmode] its kept modes (re..., im...)
   double *cd_h;     // [nx] its charge density (scratch; kind 1)
@@ -241,6 +255,9 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
 // kind 2, call-site path: the six sums K (summed over ranks) + the field's kept mode -> field_chargeden with the
 // kept-mode content of the next first sub-step's charge density; pred (or null) is re-zeroed
 hipError_t launch_pred_chargeden(const FieldArgs &f, const PredTab &pt, double *pred, const double *K, hipStream_t st);
+// kind 2, call-site path, one rank: launch_pred_chargeden (from this rank's copies of the sums) and the mode-filter
+// solve in one launch
+hipError_t launch_field_solve_pred_sums(const FieldArgs &f, const PredTab &pt, double *pred, hipStream_t st);
 // kind 2, call-site path, several ranks: this rank's six sums into the head of f.charge (rest zero), pred re-zeroed
 hipError_t launch_pred_to_charge(const FieldArgs &f, double *pred, hipStream_t st);
 // k_step_one's prediction accumulators [nspecies][1 + 2 nm][nx] + the field's kept modes -> this rank's

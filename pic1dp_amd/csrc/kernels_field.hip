@@ -110,43 +110,65 @@ __device__ __forceinline__ void pred_forward_sums(const FieldArgs &f, const Pred
   acc_s = 0.5 * (K[3] + re * K[4] + im * K[5]) * f.dnx / f.lx - off * pt.sum_fim;
 }
 
+// The six sums arrive in PRED_SUM_COPIES copies (kernels.hpp: workgroup b of the marker kernel adds into copy
+// b % PRED_SUM_COPIES -- six addresses shared by every workgroup serialise their atomics at the L2 when the
+// workgroups finish together: 29 us of a 140 us kernel at 1e7 markers).  Sum k over the copies, in copy order, all
+// loads in flight at once; the copies are re-zeroed (consumed).
+__device__ __forceinline__ double pred_sum_take(double *pred, int k) {
+  double t[PRED_SUM_COPIES];
+#pragma unroll
+  for (int c = 0; c < PRED_SUM_COPIES; ++c) t[c] = pred[c * 8 + k];
+#pragma unroll
+  for (int c = 0; c < PRED_SUM_COPIES; ++c) pred[c * 8 + k] = 0.0;
+  double acc = t[0];
+#pragma unroll
+  for (int c = 1; c < PRED_SUM_COPIES; ++c) acc = acc + t[c];
+  return acc;
+}
+
 // Call-site path: collect_charge after a noted push(1).  The host will call solve_field next, which works
 // from field_chargeden -- so chargeden gets the kept mode's content of the half-step charge density,
 //     cd[c] = alpha fre[c] + beta fim[c]   with   sum fre cd = acc_c,  sum fim cd = acc_s,
 // from which the ordinary solve reproduces the predicted Eh (to rounding).  What the filter drops is absent
 // from this chargeden; nothing in the reference driver reads chargeden between the sub-steps.
-// K: the six sums (already summed over ranks); pred (or null) is re-zeroed.
+// One rank: pred = this rank's copies of the six sums (consumed), K null.  Several ranks: pred null, K the six sums
+// already summed over ranks.
 __global__ void __launch_bounds__(FIELD_THREADS) k_pred_chargeden(const FieldArgs f, const PredTab pt, double *pred,
                                                                  const double *K) {
   __shared__ double sab[2];
+  __shared__ double sK[8];
+  if (threadIdx.x < 8) sK[threadIdx.x] = pred ? pred_sum_take(pred, threadIdx.x) : K[threadIdx.x];
+  __syncthreads();
   if (threadIdx.x == 0) {
     double ac, as;
-    pred_forward_sums(f, pt, K, f.mode_re[0], f.mode_im[0], ac, as);
+    pred_forward_sums(f, pt, sK, f.mode_re[0], f.mode_im[0], ac, as);
     const double det = pt.g11 * pt.g22 - pt.g12 * pt.g12;
     sab[0] = (ac * pt.g22 - as * pt.g12) / det;
     sab[1] = (as * pt.g11 - ac * pt.g12) / det;
-    if (pred)
-      for (int k = 0; k < 8; ++k) pred[k] = 0.0;
   }
   __syncthreads();
   const double alpha = sab[0], beta = sab[1];
   for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) f.chargeden[ix] = alpha * f.fre[ix] + beta * f.fim[ix];
 }
 
+// k_pred_chargeden and the mode-filter solve in one launch (call sites, one rank: collect_charge after a noted
+// push(1) leaves both to the solve_field that follows)
+__global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_pred_sums(const FieldArgs f, const PredTab pt, double *pred);
+
 // this rank's six sums into the head of f.charge (rest zero) for a reduction over ranks (call-site path)
 __global__ void __launch_bounds__(FIELD_THREADS) k_pred_to_charge(const FieldArgs f, double *pred) {
-  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) f.charge[ix] = ix < 6 ? pred[ix] : 0.0;
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) f.charge[ix] = 0.0;
   __syncthreads();
-  if (threadIdx.x < 8) pred[threadIdx.x] = 0.0;
+  if (threadIdx.x < 8) {
+    const double k = pred_sum_take(pred, threadIdx.x);
+    if (threadIdx.x < 6) f.charge[threadIdx.x] = k;
+  }
 }
 
 // k_charge_pack for the six sums: pack[0..nx) = charge2 of the new state, pack[nx..nx+8) = the sums (+ pad)
 __global__ void __launch_bounds__(FIELD_THREADS) k_charge_pack_sums(const FieldArgs f, double *pred, double *pack) {
   for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) pack[ix] = charge_local_one(f, ix);
-  if (threadIdx.x < 8) {
-    pack[f.nx + threadIdx.x] = pred[threadIdx.x];
-    pred[threadIdx.x] = 0.0;
-  }
+  if (threadIdx.x < 8) pack[f.nx + threadIdx.x] = pred_sum_take(pred, threadIdx.x);
 }
 
 // field_solve_electric, src/pic1dp_field.F90:231-257, with the one-rank PETSc
@@ -492,6 +514,34 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_pred(const FieldA
     sCD[ix] = cd;
   }
   __syncthreads();  // every thread has read mode_re / mode_im before solve_body overwrites them
+  solve_body(f, sCD, sMode, sScr, sTab);
+}
+
+__global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_pred_sums(const FieldArgs f, const PredTab pt, double *pred) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *sCD = reinterpret_cast<double *>(smem);
+  double *sMode = sCD + f.nx;
+  double *sScr = sMode + 2 * f.nmode;
+  double *sTab = sScr + 16;
+  __shared__ double sab[2];
+  __shared__ double sK[8];
+  if (threadIdx.x < 8) sK[threadIdx.x] = pred_sum_take(pred, threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ac, as;
+    pred_forward_sums(f, pt, sK, f.mode_re[0], f.mode_im[0], ac, as);
+    const double det = pt.g11 * pt.g22 - pt.g12 * pt.g12;
+    sab[0] = (ac * pt.g22 - as * pt.g12) / det;
+    sab[1] = (as * pt.g11 - ac * pt.g12) / det;
+  }
+  __syncthreads();  // (every thread is past its reads of mode_re / mode_im before solve_body overwrites them: only thread 0 read)
+  const double alpha = sab[0], beta = sab[1];
+  for (int ix = threadIdx.x; ix < f.nx; ix += blockDim.x) {
+    const double cd = alpha * f.fre[ix] + beta * f.fim[ix];
+    f.chargeden[ix] = cd;
+    sCD[ix] = cd;
+  }
+  __syncthreads();
   solve_body(f, sCD, sMode, sScr, sTab);
 }
 
@@ -919,8 +969,7 @@ k_field_solve_pair_sums(const FieldArgs f, const XchgArgs x1, const PairArgs pa)
   if constexpr (SRC == 1) {
     for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sV[ix] = charge_local_one(f, ix);
     if (threadIdx.x < 8) {
-      sV[nx + threadIdx.x] = pa.pred[threadIdx.x];
-      pa.pred[threadIdx.x] = 0.0;
+      sV[nx + threadIdx.x] = pred_sum_take(pa.pred, threadIdx.x);
     }
     __syncthreads();  // element i of the packed vector belongs to thread i % blockDim in the exchange
     exchange_vectors(x1, sV, nx + 8);
@@ -943,10 +992,7 @@ k_field_solve_pair_sums(const FieldArgs f, const XchgArgs x1, const PairArgs pa)
       sCD[ix] = cd;
     }
   } else {
-    if (threadIdx.x < 8) {
-      sK[threadIdx.x] = pa.pred[threadIdx.x];
-      pa.pred[threadIdx.x] = 0.0;
-    }
+    if (threadIdx.x < 8) sK[threadIdx.x] = pred_sum_take(pa.pred, threadIdx.x);
     solve_fill_chargeden<true, false>(f, sCD);
   }
   __syncthreads();
@@ -990,10 +1036,7 @@ k_field_solve_pair_sums1(const FieldArgs f, const XchgArgs x1, const PairArgs pa
   const double *pk = pa.pack;
   if constexpr (SRC == 1) {
     for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sV[ix] = charge_local_one(f, ix);
-    if (threadIdx.x < 8) {
-      sV[nx + threadIdx.x] = pa.pred[threadIdx.x];
-      pa.pred[threadIdx.x] = 0.0;
-    }
+    if (threadIdx.x < 8) sV[nx + threadIdx.x] = pred_sum_take(pa.pred, threadIdx.x);
     __syncthreads();
     exchange_vectors(x1, sV, nx + 8);
     __syncthreads();
@@ -1047,8 +1090,8 @@ k_field_solve_pair_sums1(const FieldArgs f, const XchgArgs x1, const PairArgs pa
       const int k = static_cast<int>(threadIdx.x) - (static_cast<int>(blockDim.x) - 64);
       if (k >= 0 && k < 8) {
         if constexpr (SRC == 0) {
-          if (k < 6) sMode[2 + k] = pa.pred[k];
-          pa.pred[k] = 0.0;
+          const double t = pred_sum_take(pa.pred, k);
+          if (k < 6) sMode[2 + k] = t;
         } else {
           if (k < 6) sMode[2 + k] = pk[nx + k];
         }
@@ -1434,6 +1477,14 @@ hipError_t launch_field_solve_pred(const FieldArgs &f, double *pred, int nm_pred
   const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
                                        (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
   hipLaunchKernelGGL(k_field_solve_pred, dim3(1), dim3(FIELD_THREADS), lds, st, f, pred, nm_pred);
+  return hipGetLastError();
+}
+
+hipError_t launch_field_solve_pred_sums(const FieldArgs &f, const PredTab &pt, double *pred, hipStream_t st) {
+  if (f.nmode != 1) return hipErrorInvalidValue;
+  const size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
+                                       (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
+  hipLaunchKernelGGL(k_field_solve_pred_sums, dim3(1), dim3(FIELD_THREADS), lds, st, f, pt, pred);
   return hipGetLastError();
 }
 

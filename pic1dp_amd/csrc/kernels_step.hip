@@ -296,9 +296,78 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
   return t2;
 }
 
+// PRIV: the prediction of ONE kept mode as six sums instead of three tiles (the algebra of k_step_sums below: the
+// solve only ever projects the predicted charge on the kept mode's tables, and the projection of a CIC deposit of q
+// at x' is q times the gather of the table at x'), accumulated in THREAD-PRIVATE LDS slots.  k_step_one is LDS-bound
+// (profiles/r03/sq_counters_c3_onepass.json: the six prediction atomics at random cells cost ~12 cycles each in
+// bank conflicts); an atomic into slot [k][thread] is conflict-free by construction (consecutive lanes, consecutive
+// 8-byte words: 4 cycles), the second table gather is two reads, and -- unlike k_step_sums' register
+// accumulators (126 VGPRs) -- the slots cost no registers: six waves per SIMD as before.
+// sS: this thread's slot of sum 0; sum k lies k * PRIV_THREADS further (the kernel is launched with exactly that many
+// threads).  K = [k0c k1c k2c k0s k1s k2s] as k_step_sums.
+constexpr int PRIV_THREADS = 768;
+template <int DIST, int MODE, int POW2>
+__device__ __forceinline__ double pred_one_private(const One &n, double p, int ix, double wl, const double *sAB, double *sS,
+                                                   const StepArgsDev &a) {
+  constexpr int stride = PRIV_THREADS;            // compile-time: the six slot addresses are immediate offsets of one
+  const int nx = a.g.nx;
+  // the long chain first (-f0'/f0: exp, reciprocal), with little else alive; then the two table gathers
+  double t2 = 0.0, cA = 0.0, cB = 0.0;
+  if constexpr (MODE != MODE_FULLF) {
+    const double tmp1 = (MODE == MODE_DF_LIN) ? p : (p - n.w);
+    if constexpr (POW2 == 0) {
+      if (a.s.fastc) {
+        DivFast dv;
+        t2 = dlnf0<DIST, POW2>(n.v, a.s, dv);
+        if (!dv.ok()) {
+          DivTrue dt;
+          t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+        }
+      } else {
+        DivTrue dt;
+        t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+      }
+    } else {
+      DivTrue dt;
+      t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+    }
+    const double c = tmp1 * t2 * (a.pred_k * a.s.Z);
+    const double *gl = sAB + 2 * ix;              // the tables at x: the field the half push will see
+    const double2 tl = *reinterpret_cast<const double2 *>(gl), tr = *reinterpret_cast<const double2 *>(gl + 2);
+    const double wlr = 1.0 - wl;
+    cA = c * fma(tr.x, wlr, tl.x * wl);
+    cB = c * fma(tr.y, wlr, tl.y * wl);
+  }
+  const double xh = fma(a.dt_half, n.v, n.x);     // the next step's half push of x (:261), to rounding
+  const double sh = xh * a.snx;                   // its cell, wrapped as an integer (:102-108 to rounding)
+  const double fh = floor(sh);
+  int ih = static_cast<int>(fh);
+  const double wr = sh - fh, wh = 1.0 - wr;
+  ih = ih < 0 ? ih + nx : ih;
+  ih = ih >= nx ? ih - nx : ih;
+  if (static_cast<unsigned>(ih) >= static_cast<unsigned>(nx)) {  // more than a box length in half a step, NaN
+    ih = ih % nx;
+    if (ih < 0) ih += nx;
+  }
+  const double *hl = sAB + 2 * ih;                // [A B] of cell ih, then of cell ih + 1 (cell nx: the guard, = cell 0)
+  const double2 ul = *reinterpret_cast<const double2 *>(hl), ur = *reinterpret_cast<const double2 *>(hl + 2);
+  const double Ah = fma(ur.x, wr, ul.x * wh), Bh = fma(ur.y, wr, ul.y * wh);  // projection weights of the deposit at x'
+  const double q = a.s.Z * (MODE == MODE_FULLF ? p : n.w);
+  lds_add(sS, q * Ah);
+  lds_add(sS + 3 * stride, q * Bh);
+  if constexpr (MODE != MODE_FULLF) {
+    lds_add(sS + stride, cA * Ah);
+    lds_add(sS + 2 * stride, cB * Ah);
+    lds_add(sS + 4 * stride, cA * Bh);
+    lds_add(sS + 5 * stride, cB * Bh);
+  }
+  return t2;
+}
+
 // T2: 0 no carry of -f0'/f0; 1 this step evaluates it, the next step's value is stored; 2 this
 // step's value is loaded (stored by the previous k_step_one), the next step's stored
-template <int DIST, int MODE, int POW2, bool NT, int T2, int NM>
+// NM: kept modes of the prediction tiles (1, 2); PRIV (NM = 1): six sums in thread-private slots instead
+template <int DIST, int MODE, int POW2, bool NT, int T2, int NM, bool PRIV = false>
 __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   exp_table_init();
@@ -310,6 +379,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   double *sAB = sEh + ne;                                        // [nx + 1][2 nm]: A_0 B_0 (A_1 B_1) per cell
   double *sR0 = sAB + static_cast<size_t>(nx + 1) * 2 * nm;
   double *sP = sR0 + ((nx * a.g.rcopies + 2) & ~1);              // [nx + 2][1 + 2 nm]: R0 RA_m RB_m per cell
+                                                                 // PRIV: [6][blockDim] private sums, then [16] scratch
   for (int i = threadIdx.x; i < nx; i += blockDim.x) {
     sE0[i] = a.E0[i];
     sEh[i] = a.Eh[i];
@@ -320,7 +390,11 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     sAB[c * 2 * nm + 2 * m + 1] = a.tabB[m * nx + cs];
   }
   zero_rho(sR0, a.g);
-  for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
+  if constexpr (PRIV) {
+    for (int k = 0; k < 6; ++k) sP[k * PRIV_THREADS + threadIdx.x] = 0.0;
+  } else {
+    for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
+  }
   if (threadIdx.x == 0) {
     sE0[nx] = a.E0[0];
     sEh[nx] = a.Eh[0];
@@ -349,10 +423,17 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     // the two markers of a pair one after the other (PAIR_FENCE): interleaving their four exp chains
     // costs more registers than six waves per SIMD leave
     const One n0 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x, &i0, &l0);
-    const double u0 = pred_one<DIST, MODE, POW2, NM>(n0, P.x, i0, l0, sAB, sP, a);
+    double u0, u1;
+    if constexpr (PRIV)
+      u0 = pred_one_private<DIST, MODE, POW2>(n0, P.x, i0, l0, sAB, sP + threadIdx.x, a);
+    else
+      u0 = pred_one<DIST, MODE, POW2, NM>(n0, P.x, i0, l0, sAB, sP, a);
     PAIR_FENCE();
     const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y, &i1, &l1);
-    const double u1 = pred_one<DIST, MODE, POW2, NM>(n1, P.y, i1, l1, sAB, sP, a);
+    if constexpr (PRIV)
+      u1 = pred_one_private<DIST, MODE, POW2>(n1, P.y, i1, l1, sAB, sP + threadIdx.x, a);
+    else
+      u1 = pred_one<DIST, MODE, POW2, NM>(n1, P.y, i1, l1, sAB, sP, a);
     st2t<NT>(x2 + o, n0.x, n1.x);
     if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
     if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
@@ -368,11 +449,25 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     a.x[i] = n.x;
     if constexpr (PUSH_V) a.v[i] = n.v;
     if constexpr (HAS_W) a.w[i] = n.w;
-    const double u = pred_one<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP, a);
+    double u;
+    if constexpr (PRIV)
+      u = pred_one_private<DIST, MODE, POW2>(n, p, ic, lc, sAB, sP + threadIdx.x, a);
+    else
+      u = pred_one<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP, a);
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
   }
   __syncthreads();
   flush_rho(sR0, a.rho, a.g);
+  if constexpr (PRIV) {  // the six sums: every thread's slots, workgroup reduction, one global atomic each
+    double *sScr = sP + 6 * PRIV_THREADS;
+    double r[6];
+    for (int k = 0; k < 6; ++k) r[k] = block_sum(sP[k * PRIV_THREADS + threadIdx.x], sScr);
+    if (threadIdx.x == 0 && !a.g.debug_noflush) {
+      double *mine = a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8;
+      for (int k = 0; k < 6; ++k) glb_add(mine + k, r[k]);
+    }
+    return;
+  }
   // the guard cells nx, nx + 1 are cells 0, 1 (mod nx); then one global atomic per cell and slice
   if (threadIdx.x < 2 * np1) {
     const int g = threadIdx.x / np1, k = threadIdx.x - g * np1;
@@ -536,12 +631,13 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   const double r0 = block_sum(ks.k0c, sScr), r1 = block_sum(ks.k1c, sScr), r2 = block_sum(ks.k2c, sScr);
   const double r3 = block_sum(ks.k0s, sScr), r4 = block_sum(ks.k1s, sScr), r5 = block_sum(ks.k2s, sScr);
   if (threadIdx.x == 0) {
-    glb_add(a.pred + 0, r0);
-    glb_add(a.pred + 1, r1);
-    glb_add(a.pred + 2, r2);
-    glb_add(a.pred + 3, r3);
-    glb_add(a.pred + 4, r4);
-    glb_add(a.pred + 5, r5);
+    double *mine = a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8;  // one of the copies (kernels.hpp PRED_SUM_COPIES)
+    glb_add(mine + 0, r0);
+    glb_add(mine + 1, r1);
+    glb_add(mine + 2, r2);
+    glb_add(mine + 3, r3);
+    glb_add(mine + 4, r4);
+    glb_add(mine + 5, r5);
   }
 }
 
@@ -557,6 +653,7 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc,
 }
 
 static_assert(PRED_MAX_MODES == 2, "k_step_one is instantiated for one and two kept modes");
+static_assert(PRIV_THREADS == STEP_PRIVATE_THREADS, "slot stride of k_step_one<PRIV> = its workgroup size");
 template <int DIST, int MODE, int POW2, int NM>
 hipError_t launch_step_one(const StepArgsDev &d, int t2m, const LaunchCfg &lc, hipStream_t st) {
   if (d.nt) {
@@ -571,6 +668,17 @@ hipError_t launch_step_one(const StepArgsDev &d, int t2m, const LaunchCfg &lc, h
 
 template <int DIST, int MODE, int POW2, bool CARRY = false>
 hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
+  if (full && d.pred && d.pred_nm == -2) {  // one pass per step, six sums in thread-private LDS slots
+    const int t2m = d.t2 ? d.t2_mode : 0;
+    if (d.nt) {
+      if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, 1, true>, d, lc, st);
+      if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, 1, true>, d, lc, st);
+      return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 1, true>, d, lc, st);
+    }
+    if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, 1, true>, d, lc, st);
+    if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, 1, true>, d, lc, st);
+    return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 1, true>, d, lc, st);
+  }
   if (full && d.pred && d.pred_nm < 0) {  // one pass per step, prediction as six sums (large grids)
     const int t2m = d.t2 ? d.t2_mode : 0;
     if (d.nt) {

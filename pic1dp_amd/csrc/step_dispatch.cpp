@@ -26,7 +26,7 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.tabA = a.tabA;
   d.tabB = a.tabB;
   d.pred = a.pred;
-  d.pred_nm = a.pred_kind == 2 ? -1 : a.pred_nm;  // -1: k_step_sums
+  d.pred_nm = a.pred_kind == 2 ? (a.pred_private ? -2 : -1) : a.pred_nm;  // -1: k_step_sums, -2: k_step_one<PRIV>
   d.t2_mode = a.t2_mode;
   d.eh_re = a.eh_re;
   d.eh_im = a.eh_im;

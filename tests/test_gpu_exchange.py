@@ -37,8 +37,7 @@ def test_exchange_ranks_share_the_gpu(amd, tmp_path, monkeypatch, nproc, mode, k
     insisted on at the small grid); the large grids: the paired solve's exchange vector beyond 64 KiB of LDS"""
     kw = dict(nparticle_max=600_000, nx=nx)
     steps = 12
-    if kind == 2:
-        monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
+    monkeypatch.setenv("PIC1DP_PRED_KIND", str(kind))
     ranks = run_ranks(tmp_path, nproc, kw, steps, mode, 29541 + nproc + 10 * kind + (nx > 128) * 20)
     # every rank holds the same field, bit for bit
     for r in ranks[1:]:

@@ -16,10 +16,12 @@ N = 200_001
 
 
 def engine(amd, monkeypatch, predict, kind=None, npe=1, **kw):
-    """kind 2: the large-grid kernel (k_step_sums: prediction as six sums, Eh from its kept mode) insisted on"""
+    """kind 1: the prediction as tiles (k_step_one) wherever they fit; kind 2: as six sums (k_step_one<PRIV> in
+    thread-private LDS slots where E0, Eh and the tables fit the LDS, else k_step_sums) -- the library's own choice
+    is the sums from nx = 512 up with one kept mode, the tiles below and with two kept modes"""
     monkeypatch.setenv("PIC1DP_PREDICT", "1" if predict else "0")
-    if kind == 2 and predict:
-        monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
+    if kind and predict:         # 1: the tiles wherever they fit; 2: the six sums (k_step_one<PRIV> / k_step_sums)
+        monkeypatch.setenv("PIC1DP_PRED_KIND", str(kind))
     else:
         monkeypatch.delenv("PIC1DP_PRED_KIND", raising=False)
     e = amd.Pic1dp(amd.make_input(**kw), npe=npe)

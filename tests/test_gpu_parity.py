@@ -723,8 +723,7 @@ def test_rccl_allreduce_path_single_rank(oracle_mod, amd, monkeypatch, kind, nx)
     the engine's stream -> field solve; in a one-pass step: pack -> ONE
     ncclAllReduce -> the paired solve, with the prediction as tiles or as six
     sums) that N > 1 uses"""
-    if kind == 2:
-        monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
+    monkeypatch.setenv("PIC1DP_PRED_KIND", str(kind))
     sim, eng = pair(oracle_mod, amd, nparticle_max=100000, nx=nx)
     assert eng.predict_kind() == kind
     uid = eng.comm_unique_id()
@@ -1046,7 +1045,7 @@ def test_library_reports_the_bytes_its_kernels_move(amd, monkeypatch):
     compulsory for its data flow, the carry of -f0'/f0 apart (bench.py prices its roofline on these instead of
     guessing from constants)"""
     def run(**kw):
-        eng = amd.Pic1dp(amd.make_input(nparticle_max=50_001, nx=64, **kw))
+        eng = amd.Pic1dp(amd.make_input(**dict(dict(nparticle_max=50_001, nx=64), **kw)))
         eng.particle_load()
         eng.interaction_collect_charge()
         eng.field_solve_electric()
@@ -1070,7 +1069,13 @@ def test_library_reports_the_bytes_its_kernels_move(amd, monkeypatch):
     ff = run(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0]).kernel_bytes(6)
     assert (ff["read"], ff["written"], ff["carry"]) == (24.0, 16.0, 0.0)          # no w in a full-f run
     monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
-    assert run().kernel_bytes(6)["name"].startswith("k_step_sums")
+    assert run().kernel_bytes(6)["name"].startswith("k_step_one<sums>")       # six sums in thread-private LDS slots
+    monkeypatch.setenv("PIC1DP_PRED_PRIVATE", "0")
+    assert run().kernel_bytes(6)["name"].startswith("k_step_sums")            # the large-grid kernel insisted on
+    monkeypatch.delenv("PIC1DP_PRED_PRIVATE")
+    monkeypatch.delenv("PIC1DP_PRED_KIND")
+    assert run(nx=1024).kernel_bytes(6)["name"].startswith("k_step_one<sums>")  # the library's choice from nx 512 up
+    assert run(nx=1024, nmode=2, modes=[1, 2]).kernel_bytes(6)["name"].startswith("k_step_one (")   # two kept modes: tiles
     eng = run()
     eng.interaction_push_particle(1)
     eng.particles_download()                           # materialised: the eager push kernel ran
