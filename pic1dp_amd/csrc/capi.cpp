@@ -97,7 +97,7 @@ struct pic1dp_ctx {
   double *d_rho_sp = nullptr, *d_charge = nullptr, *d_chargeden = nullptr, *d_E = nullptr;
   double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
   double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
-  // one pass per step (kernels.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
+  // one pass per step (kernels_step.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
   // prediction accumulators [nspecies][1 + 2 nm][nx], the combined half-step charge density
   double *d_tabA = nullptr, *d_tabB = nullptr, *d_pred = nullptr, *d_cd_h = nullptr, *d_mode_h = nullptr;
   int pair_plain = 0;              // PIC1DP_PAIR_PLAIN
@@ -170,7 +170,7 @@ struct pic1dp_ctx {
   FieldArgs fa{};
   // comm
   ncclComm_t comm = nullptr;
-  // one-hop charge exchange (kernels.hip exchange_charge): the own area, the peers'
+  // one-hop charge exchange (kernels_field.hip exchange_charge): the own area, the peers'
   // areas as mapped through hipIpc, and the running exchange number
   struct Xchg {
     void *local = nullptr;                       // flags + slots of this rank
@@ -1477,7 +1477,7 @@ static bool output_follows(const pic1dp_ctx *c) {
   return std::fmod(t + kSqrtEps, in.output_interval) < std::fmod(t + kSqrtEps - in.dt, in.output_interval);
 }
 
-// One pass per step (kernels.hip k_step_one) needs: the mode-filter solver (the kept modes must
+// One pass per step (kernels_step.hip k_step_one) needs: the mode-filter solver (the kept modes must
 // describe E), few kept modes, and LDS for E0, Eh, the mode tables and the four accumulators
 static bool predict_capable(const pic1dp_ctx *c) {
   return c->predict && c->pred_kind != 0 && c->d_pred && c->field_solver == 0 && step_recompute_ok(c);
@@ -2287,7 +2287,7 @@ int pic1dp_hip_comm_init(pic1dp_ctx *c, const unsigned char id[PIC1DP_COMM_ID_BY
 
 // ---------------------------------------------------------------------------
 // one-hop charge exchange over peer-mapped memory (alternative to the RCCL
-// all-reduce; kernels.hip exchange_charge)
+// all-reduce; kernels_field.hip exchange_charge)
 // ---------------------------------------------------------------------------
 int pic1dp_hip_comm_available(void) {
   std::string err;

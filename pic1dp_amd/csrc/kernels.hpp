@@ -1,4 +1,4 @@
-// kernels.hpp -- launch interface of the gfx950 kernels (kernels.hip).
+// kernels.hpp -- launch interface of the gfx950 kernels (kernels_step.hip, kernels_push.hip, kernels_field.hip, kernels_diag.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -134,18 +134,18 @@ struct StepArgs {
   SpeciesConst s;
   int iptcldist, deltaf, linear;
   int stream_nt;       // 1: non-temporal loads/stores (state larger than the Infinity Cache)
-  double *t2;          // [np + 2] carry of -f0'/f0 from the first kernel to the second, or null (kernels.hip CARRY)
-  // full kernel only: take the diagnostics of output_all in the same pass (kernels.hip DIAG); dist_out null = no
+  double *t2;          // [np + 2] carry of -f0'/f0 from the first kernel to the second, or null (kernels_step.hip CARRY)
+  // full kernel only: take the diagnostics of output_all in the same pass (kernels_step.hip DIAG); dist_out null = no
   DistGeom dg;
   double *dist_out, *dist_partial;
-  // full kernel only: also predict the charge of the NEXT step's first sub-step (kernels.hip k_step_one);
+  // full kernel only: also predict the charge of the NEXT step's first sub-step (kernels_step.hip k_step_one);
   // pred null = no.  tabA/tabB: [pred_nm][nx] mode tables with E = sum_m re_m*A_m + im_m*B_m;
   // pred: [1 + 2*pred_nm][nx] accumulators of this species (R0, RA_m, RB_m); t2_mode: 0 no carry of
   // -f0'/f0 through t2, 1 write it for the next step, 2 read this step's and write the next step's
   const double *tabA, *tabB;
   double *pred;
   int pred_nm, t2_mode;
-  // pred_kind 2 (kernels.hip k_step_sums, for grids whose prediction tiles outgrow the LDS; one kept mode): pred is
+  // pred_kind 2 (kernels_step.hip k_step_sums, for grids whose prediction tiles outgrow the LDS; one kept mode): pred is
   // [PRED_SUM_COPIES][8] -- six global sums K0c K1c K2c K0s K1s K2s shared by all species (Z folded in), in copies --, and Eh is not staged
   // but formed from the tables and its kept mode *eh_re, *eh_im (Eh = re A + im B, bit for bit what the solve wrote)
   int pred_kind;  // 1 tiles (k_step_one), 2 sums (k_step_sums)
@@ -212,7 +212,7 @@ struct FieldArgs {
   double Z[8], n0[8];
 };
 
-// one-hop charge exchange between the GPUs of a node (kernels.hip, exchange_charge)
+// one-hop charge exchange between the GPUs of a node (kernels_field.hip exchange_charge)
 constexpr int XCHG_MAX_RANKS = 16;
 struct XchgArgs {
   double *slots[XCHG_MAX_RANKS];               // every rank's slot area [2][nranks][nx] as mapped here

@@ -1,4 +1,4 @@
-"""One-hop charge exchange (pic1dp_hip_xchg_*, kernels.hip exchange_charge): N
+"""One-hop charge exchange (pic1dp_hip_xchg_*, kernels_field.hip exchange_charge): N
 processes share the box's one GPU and map each other's exchange areas through IPC
 handles -- the same code path as N GPUs over xGMI, minus the link.  Checks: the
 exchange runs, the summed charge / field are BIT-identical on all ranks (fixed
