@@ -300,8 +300,15 @@ __device__ __forceinline__ double pexp(double x) {
   x = fmax(x, -750.0);
   const double fn = rint(x * 0x1.71547652b82fep+6);            // n = round(x * 64/ln2)
   const int n = static_cast<int>(fn);
-  double r = fma(-fn, 0x1.62e42fefa0000p-7, x);               // x - n ln2/64, ln2/64 as hi (36 bits) + lo
-  r = fma(-fn, 0x1.cf79abc9e3b3ap-46, r);
+  double r;
+  if constexpr (HI_ONLY) {
+    // x - n ln2/64 with ln2/64 as ONE double: the product's error, |n| 2^-60, enters e^x relatively and the
+    // blend of the one-exp form with the weight 2 E/(1 + E)^2 <= 2 e^x: at most 2 |n| e^(-|n| ln2/64) 2^-60 < 6e-17
+    r = fma(-fn, 0x1.62e42fefa39efp-7, x);
+  } else {
+    r = fma(-fn, 0x1.62e42fefa0000p-7, x);                    // x - n ln2/64, ln2/64 as hi (36 bits) + lo
+    r = fma(-fn, 0x1.cf79abc9e3b3ap-46, r);
+  }
   double q = 0x1.1111111111111p-7;                            // 1/120
   q = fma(q, r, 0x1.5555555555555p-5);                        // 1/24
   q = fma(q, r, 0x1.5555555555555p-3);                        // 1/6
