@@ -545,5 +545,23 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
   return t;
 }
 
+// six per-thread values summed over the workgroup and added to dst[0..5] (one barrier; scr: 96 doubles nobody else
+// uses any more): wave reductions, [6][16] partials, then 16-lane groups of the first 96 threads
+__device__ __forceinline__ void block_sum6_add(const double (&v)[6], double *scr, double *dst) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double t = v[k];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) scr[k * 16 + wave] = t;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 96; t += blockDim.x) {
+    double u = (t & 15) < nwaves ? scr[t] : 0.0;
+    for (int off = 8; off > 0; off >>= 1) u += __shfl_down(u, off, 16);
+    if ((t & 15) == 0) glb_add(dst + (t >> 4), u);
+  }
+}
+
 }  // namespace
 }  // namespace pic1dp

@@ -160,7 +160,7 @@ constexpr int PRED_SUM_COPIES = 16;
 // dynamic LDS of k_step_sums: E0, A, B tiles (with guard cell), rho copies, reduction scratch
 inline size_t step_sums_lds_bytes(int nx, int rcopies) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
-  return sizeof(double) * (3 * ne + ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) + 16);
+  return sizeof(double) * (3 * ne + ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) + 96);  // [6][16] scratch
 }
 // dynamic LDS of k_step_one: E0, Eh tiles (with guard cell), the tables cell by cell (nx + 1 cells of 2 nm), rho
 // copies, the prediction accumulators cell by cell (nx + 2 cells of 1 + 2 nm)

@@ -458,13 +458,16 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   }
   __syncthreads();
   flush_rho(sR0, a.rho, a.g);
-  if constexpr (PRIV) {  // the six sums: every thread's slots, workgroup reduction, one global atomic each
-    double *sScr = sP + 6 * PRIV_THREADS;
-    double r[6];
-    for (int k = 0; k < 6; ++k) r[k] = block_sum(sP[k * PRIV_THREADS + threadIdx.x], sScr);
-    if (threadIdx.x == 0 && !a.g.debug_noflush) {
-      double *mine = a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8;
-      for (int k = 0; k < 6; ++k) glb_add(mine + k, r[k]);
+  if constexpr (PRIV) {  // the six sums: wave k adds up the slots of sum k (12 reads per lane, a wave reduction), one
+                         // global atomic each -- no barrier beyond the one above
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 6) {
+      const double *s = sP + wave * PRIV_THREADS + lane;
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < PRIV_THREADS / 64; ++j) t += s[64 * j];
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+      if (lane == 0 && !a.g.debug_noflush) glb_add(a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8 + wave, t);
     }
     return;
   }
@@ -565,7 +568,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   double *sA = sE0 + ne;
   double *sB = sA + ne;
   double *sR0 = sB + ne;
-  double *sScr = sR0 + ((nx * a.g.rcopies + 2) & ~1);  // [16] reduction scratch
+  double *sScr = sR0 + ((nx * a.g.rcopies + 2) & ~1);  // [6][16] reduction scratch
   for (int i = threadIdx.x; i < nx; i += blockDim.x) {
     sE0[i] = a.E0[i];
     sA[i] = a.tabA[i];
@@ -627,18 +630,9 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   }
   __syncthreads();
   flush_rho(sR0, a.rho, a.g);
-  // the six sums: workgroup reduction, one global atomic each
-  const double r0 = block_sum(ks.k0c, sScr), r1 = block_sum(ks.k1c, sScr), r2 = block_sum(ks.k2c, sScr);
-  const double r3 = block_sum(ks.k0s, sScr), r4 = block_sum(ks.k1s, sScr), r5 = block_sum(ks.k2s, sScr);
-  if (threadIdx.x == 0) {
-    double *mine = a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8;  // one of the copies (kernels.hpp PRED_SUM_COPIES)
-    glb_add(mine + 0, r0);
-    glb_add(mine + 1, r1);
-    glb_add(mine + 2, r2);
-    glb_add(mine + 3, r3);
-    glb_add(mine + 4, r4);
-    glb_add(mine + 5, r5);
-  }
+  // the six sums: workgroup reduction, one global atomic each into one of the copies (kernels.hpp PRED_SUM_COPIES)
+  const double mine[6] = {ks.k0c, ks.k1c, ks.k2c, ks.k0s, ks.k1s, ks.k2s};
+  block_sum6_add(mine, sScr, a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8);
 }
 
 template <typename K>

@@ -307,7 +307,7 @@ def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind)
 @pytest.mark.parametrize("kw,kind", [
     (dict(nx=2542), 1), (dict(nx=2543), 2),                                   # the last grid the tiles hold, the first for the sums
     (dict(nx=1694, nmode=2, modes=[1, 3]), 1), (dict(nx=1695, nmode=2, modes=[1, 3]), 0),
-    (dict(nx=5083), 2), (dict(nx=5084), 0)],                                  # the last grid for the sums, then two passes
+    (dict(nx=5063), 2), (dict(nx=5064), 0)],                                  # the last grid for the sums, then two passes
     ids=["tiles_last", "sums_first", "two_modes_last", "two_modes_beyond", "sums_last", "beyond"])
 def test_one_pass_at_the_lds_limits(amd, monkeypatch, kw, kind):
     """the grids at which the one-pass kernels' LDS tiles just fit and just do not (kernels.hpp step_one_lds_bytes,
