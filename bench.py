@@ -518,10 +518,11 @@ def main():
         barrier()
         return out
 
-    # the first ~30 steps after an idle period of the GPU (the loader runs on the host) run
-    # 3-13 % slower than the steady state (tools/ramp_probe.py): steps up to 30 are added in
-    # front of the caller's W and reported as warmup_effective
-    settle = max(0, 30 - a.warmup)
+    # the first ~60 ms of stepping after an idle period of the GPU (the loader runs on the host) run 1-10 % slower
+    # than the steady state (tools/ramp_probe.py, 10-step batches at 10^8 markers: 1.06 0.99 0.98 0.97 0.96 0.96 ...
+    # ms per step): about 0.1 s of steps (the same count on every rank: from the marker count, not from a clock) are
+    # added in front of the caller's W and reported as warmup_effective
+    settle = max(0, min(2000, max(30, int(0.1 / (per_gpu * 2.0 / 2.0e11)))) - a.warmup)
     device_sync()      # the first call initialises torch's device context (seconds): not between warm-up and timing
     job.run(settle)
     job.run(a.warmup)

@@ -20,7 +20,7 @@ cat "$OUT/bench_${CFG}_wholestep.json"
 
 echo "[2/4] kernel trace + stats" && date
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \
-  python3 "$R/bench.py" --config $CFG --steps 50 --warmup 40 --no-cpu-baseline --no-traffic-pass \
+  python3 "$R/bench.py" --config $CFG --steps 300 --warmup 40 --no-cpu-baseline --no-traffic-pass \
   > "$OUT/bench_${CFG}_wholestep_under_rocprof.json" 2> "$OUT/stats.err"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -n 1)" "$OUT/bench_${CFG}_wholestep_kernel_stats.csv"
 
