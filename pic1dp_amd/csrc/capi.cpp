@@ -659,7 +659,6 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     const int k = std::atoi(e);
     if (k == 1 || k == 2 || k == 4 || k == 8) c->grid.rcopies = k;
   }
-  c->grid.debug_noflush = std::getenv("PIC1DP_DEBUG_NOFLUSH") != nullptr;
   if (const char *e = std::getenv("PIC1DP_OSUB")) c->osub_req = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("PIC1DP_PAIR_PLAIN")) c->pair_plain = std::atoi(e) != 0;
   while (c->grid.rcopies > 1 && step_lds_bytes(nx, true, c->grid.rcopies) > 80 * 1024) c->grid.rcopies >>= 1;

@@ -518,7 +518,9 @@ __device__ __forceinline__ void zero_rho(double *sR, const GridConst &g) {
 }
 __device__ __forceinline__ void flush_rho(const double *sR, double *rho, const GridConst &g) {
   // one global atomic per cell per workgroup; start cell rotated by workgroup
-  if (g.debug_noflush) return;
+#ifdef PIC1DP_TUNE_NOFLUSH  // tuning build, measurement only: the LDS tiles are not flushed (wrong charge)
+  return;
+#endif
   const int nx = g.nx;
   rho += static_cast<size_t>(blockIdx.x & (g.gcopies - 1)) * g.gstride;
   const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);

@@ -44,7 +44,6 @@ struct GridConst {
   int gcopies, gstride;  // copies of the species accumulators in memory (power of two) and doubles between them:
                          // workgroup b flushes into copy b % gcopies (fewer atomics per address), the field
                          // kernels add the copies up
-  int debug_noflush;  // measurement only (PIC1DP_DEBUG_NOFLUSH=1): the LDS rho tiles are not flushed (wrong charge)
 };
 
 // Marker storage.  The four arrays of a species (x, v, w, p) are NOT four separate

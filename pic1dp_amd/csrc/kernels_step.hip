@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
 #pragma unroll
       for (int j = 0; j < PRIV_THREADS / 64; ++j) t += s[64 * j];
       for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-      if (lane == 0 && !a.g.debug_noflush) glb_add(a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8 + wave, t);
+      if (lane == 0) glb_add(a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8 + wave, t);
     }
     return;
   }
