@@ -1,7 +1,8 @@
 ! host_ranks.F90 -- the Fortran host as one of N processes WITHOUT MPI in the image (the reference is an MPI
 ! program: src/pic1dp.F90:43-52, `mpiexec -n 4`, run/Makefile:41; this image's mpif90 wrappers are unusable).
 ! Rank and size come from the environment (PIC1DP_RANK, PIC1DP_NRANKS), and the two things the reference does
-! with MPI outside the hot path travel through small files in a rendez-vous directory (PIC1DP_RENDEZVOUS):
+! with MPI outside the hot path travel through small files in a rendez-vous directory (PIC1DP_RENDEZVOUS -- fresh for
+! every run: a file an earlier run left there would be taken for this run's; ranks_finalize removes this run's):
 !   ranks_allgather_handles  <->  MPI_Allgather of the 64-byte exchange handles (INTEGRATION.md section 4)
 !   ranks_reduce_to_root     <->  MPI_Reduce(..., MPI_SUM, 0, ...) of the diagnostics (src/pic1dp_output.F90:333-356)
 ! The charge sum of the hot path (MPI_Allreduce, src/pic1dp_interaction.F90:130-135) does NOT go through files:
@@ -133,5 +134,14 @@ subroutine ranks_reduce_to_root(a, n)
     rc = c_unlink(trim(ranks_file('reduce', ranks_seq, q))//c_null_char)
   end do
 end subroutine ranks_reduce_to_root
+
+! the end of a run that went well: this rank's gather files go (the reduce files went as they were read)
+subroutine ranks_finalize()
+  integer :: q, rc
+  if (ranks_size == 1) return
+  do q = 1, ranks_seq
+    rc = c_unlink(trim(ranks_file('gather', q, ranks_rank))//c_null_char)
+  end do
+end subroutine ranks_finalize
 
 end module pic1dp_host_ranks

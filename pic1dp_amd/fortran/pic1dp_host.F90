@@ -110,4 +110,5 @@ if (verbosity >= 1) then
     '   electric field', ms_field
 end if
 call pic1dp_hip_check(pic1dp_hip_destroy(ctx), 'destroy')   ! particle_final + field_final
+call ranks_finalize()
 end program pic1dp_host
