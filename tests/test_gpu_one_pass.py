@@ -325,6 +325,34 @@ def test_one_pass_at_the_lds_limits(amd, monkeypatch, kw, kind):
         assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
 
 
+@pytest.mark.parametrize("nx,force,kind,kernel", [
+    (512, None, 2, "k_step_one<sums>"),       # the library's own choice from nx = 512 up ...
+    (511, None, 1, "k_step_one"),             # ... and the tiles below
+    (1096, None, 2, "k_step_one<sums>"),      # the last grid whose tiles and slots fit a CU twice
+    (1097, None, 1, "k_step_one"),            # one cell more: the tiles again by default,
+    (1097, 2, 2, "k_step_sums")],             # the register sums when the six sums are insisted on
+    ids=["private_first", "below", "private_last", "beyond_default", "beyond_forced_sums"])
+def test_private_sums_at_their_limits(amd, monkeypatch, nx, force, kind, kernel):
+    """k_step_one<PRIV> (six sums in thread-private LDS slots) between nx = 512 and the last grid at which E0, Eh, the
+    tables, the rho tile and the slots of TWO workgroups fit a CU's LDS (kernels.hpp step_one_private_lds_bytes): the
+    choice, the kernel that ran (as the library names it), and the run against the two-pass engine"""
+    kw = dict(nx=nx, nparticle_max=N)
+    a = engine(amd, monkeypatch, True, force, **kw)
+    assert a.predict_kind() == kind
+    b = engine(amd, monkeypatch, False, **kw)
+    a.kernel_stats_enable(True)
+    a.step(5)
+    b.step(5)
+    name = a.kernel_bytes(6)["name"]
+    assert name.startswith(kernel) and (kernel != "k_step_one" or not name.startswith("k_step_one<sums>")), name
+    assert a.kernel_stats(6)[1] == 5
+    assert np.max(np.abs(a.energy_history() / b.energy_history() - 1.0)) < 1e-11
+    assert relerr(a.get_field()["electric"], b.get_field()["electric"]) < 1e-11
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
+
+
 @pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
 def test_prediction_of_markers_that_cross_several_boxes(amd, monkeypatch, kind):
     """markers fast enough to cross more than a box length in half a step: the prediction wraps the CELL of
