@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """isa_loop_count.py -- static instruction mix of the marker loop of one kernel instantiation (cross-compiled,
-no GPU): python tools/isa_loop_count.py 'k_step_one<5, 0, 2, true, 0>'"""
+no GPU): python tools/isa_loop_count.py 'k_step_one<5, 0, 2, true, 0>'   (PIC1DP_ISA_OPS=1: the loop's opcode histogram too)"""
 import collections
 import os
 import re
@@ -50,3 +50,6 @@ for x in loop:
     g["VALU" if op.startswith("v_") else "LDS" if op.startswith("ds_") else "SALU" if op.startswith("s_") else
       "VMEM" if op.startswith(("global_", "buffer_", "flat_")) else "scratch" if op.startswith("scratch_") else "other"] += 1
 print(want, "kernel", len(ins), "loop", len(loop), dict(g))
+if os.environ.get("PIC1DP_ISA_OPS"):   # the opcode histogram of the loop, most frequent first
+    ops = collections.Counter(x.split()[0] for x in loop)
+    print("  ".join("%s %d" % kv for kv in ops.most_common(40)))
