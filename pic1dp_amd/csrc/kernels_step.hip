@@ -14,6 +14,9 @@
 #include "device_math.hpp"
 #include "step_args.hpp"
 
+#include <cstdio>
+#include <vector>
+
 #ifndef PIC1DP_STEP_DIST
 #error "compile with -DPIC1DP_STEP_DIST=0..5 (pic1dp_amd/build.py does)"
 #endif
@@ -21,6 +24,27 @@
 namespace pic1dp {
 
 namespace {
+
+// Tuning build -DPIC1DP_TUNE_STAMPS (tools/stamp_probe.sh; never the product): thread 0 of every workgroup of
+// k_step_one / k_step_sums records the 100 MHz wall clock at the phase boundaries -- 0 entry, 1 tiles staged, 2 its
+// own loop done, 3 the workgroup's loop done, 4 rho flushed, 5 end -- and 6 its hardware id; the launch numbered
+// PIC1DP_STAMP_AT is written to PIC1DP_STAMP_FILE by the launch after it.
+#ifdef PIC1DP_TUNE_STAMPS
+#define STAMP(a, k)                                                                          \
+  do {                                                                                       \
+    if (threadIdx.x == 0) (a).stamps[static_cast<size_t>(blockIdx.x) * 8 + (k)] = wall_clock64(); \
+  } while (0)
+#define STAMP_HWID(a)                                                                                             \
+  do {                                                                                                            \
+    if (threadIdx.x == 0)                                                                                         \
+      (a).stamps[static_cast<size_t>(blockIdx.x) * 8 + 6] =                                                       \
+          (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11))) << 32) | \
+          __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                                            \
+  } while (0)
+#else
+#define STAMP(a, k) ((void)0)
+#define STAMP_HWID(a) ((void)0)
+#endif
 
 // ---------------------------------------------------------------------------
 // Whole-time-step kernels (pic1dp_hip_step): the half-step state is never
@@ -370,6 +394,8 @@ __device__ __forceinline__ double pred_one_private(const One &n, double p, int i
 template <int DIST, int MODE, int POW2, bool NT, int T2, int NM, bool PRIV = false>
 __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  STAMP(a, 0);
+  STAMP_HWID(a);
   exp_table_init();
   const int nx = a.g.nx;
   constexpr int nm = NM, np1 = 1 + 2 * NM;
@@ -400,6 +426,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     sEh[nx] = a.Eh[0];
   }
   __syncthreads();
+  STAMP(a, 1);
   double *sR = my_rho_copy(sR0, a.g);
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
@@ -456,8 +483,11 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
       u = pred_one<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP, a);
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
   }
+  STAMP(a, 2);
   __syncthreads();
+  STAMP(a, 3);
   flush_rho(sR0, a.rho, a.g);
+  STAMP(a, 4);
   if constexpr (PRIV) {  // the six sums: wave k adds up the slots of sum k (12 reads per lane, a wave reduction), one
                          // global atomic each -- no barrier beyond the one above
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -469,6 +499,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
       for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
       if (lane == 0) glb_add(a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8 + wave, t);
     }
+    STAMP(a, 5);
     return;
   }
   // the guard cells nx, nx + 1 are cells 0, 1 (mod nx); then one global atomic per cell and slice
@@ -488,6 +519,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
       if (val != 0.0) glb_add(&a.pred[static_cast<size_t>(k) * nx + c], val);
     }
   }
+  STAMP(a, 5);
 }
 
 // ---------------------------------------------------------------------------
@@ -561,6 +593,8 @@ __device__ __forceinline__ double pred_one_sums(const One &n, double p, int ix, 
 template <int DIST, int MODE, int POW2, bool NT, int T2>
 __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  STAMP(a, 0);
+  STAMP_HWID(a);
   exp_table_init();
   const int nx = a.g.nx;
   const int ne = (nx + 2) & ~1;
@@ -581,6 +615,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
     sB[nx] = a.tabB[0];
   }
   __syncthreads();
+  STAMP(a, 1);
   const ModeField sEh{sA, sB, *a.eh_re, *a.eh_im};
   double *sR = my_rho_copy(sR0, a.g);
   constexpr bool HAS_W = (MODE != MODE_FULLF);
@@ -628,15 +663,69 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
     const double u = pred_one_sums<DIST, MODE, POW2>(n, p, ic, lc, sA, sB, ks, a);
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
   }
+  STAMP(a, 2);
   __syncthreads();
+  STAMP(a, 3);
   flush_rho(sR0, a.rho, a.g);
+  STAMP(a, 4);
   // the six sums: workgroup reduction, one global atomic each into one of the copies (kernels.hpp PRED_SUM_COPIES)
   const double mine[6] = {ks.k0c, ks.k1c, ks.k2c, ks.k0s, ks.k1s, ks.k2s};
   block_sum6_add(mine, sScr, a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8);
+  STAMP(a, 5);
 }
 
+#ifdef PIC1DP_TUNE_STAMPS
+constexpr size_t kStampGrid = 16384;
+struct StampState {
+  unsigned long long *dev = nullptr;
+  long launches = 0, at = -1;
+  int blocks = 0, threads = 0;
+};
+StampState &stamp_state() {
+  static StampState s;
+  return s;
+}
+// before launch number n + 1: the stamps of launch n = PIC1DP_STAMP_AT go to PIC1DP_STAMP_FILE
+hipError_t stamp_hook(StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
+  StampState &s = stamp_state();
+  if (!s.dev) {
+    hipError_t e = hipMalloc(&s.dev, sizeof(unsigned long long) * 8 * kStampGrid);
+    if (e != hipSuccess) return e;
+    if (const char *a = std::getenv("PIC1DP_STAMP_AT")) s.at = std::atol(a);
+  }
+  if (s.launches == s.at + 1 && s.at >= 0) {
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    std::vector<unsigned long long> h(static_cast<size_t>(8) * s.blocks);
+    e = hipMemcpy(h.data(), s.dev, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    if (const char *fn = std::getenv("PIC1DP_STAMP_FILE")) {
+      if (FILE *f = std::fopen(fn, "w")) {
+        std::fprintf(f, "# blocks %d threads %d\n", s.blocks, s.threads);
+        for (int b = 0; b < s.blocks; ++b) {
+          for (int k = 0; k < 7; ++k) std::fprintf(f, "%llu ", h[static_cast<size_t>(b) * 8 + k]);
+          std::fprintf(f, "\n");
+        }
+        std::fclose(f);
+      }
+    }
+  }
+  s.launches++;
+  s.blocks = lc.blocks;
+  s.threads = lc.threads;
+  d.stamps = s.dev;
+  return static_cast<size_t>(lc.blocks) <= kStampGrid ? hipSuccess : hipErrorInvalidValue;
+}
+#endif
+
 template <typename K>
-hipError_t launch_step_kernel(K kern, const StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
+hipError_t launch_step_kernel(K kern, const StepArgsDev &d0, const LaunchCfg &lc, hipStream_t st) {
+#ifdef PIC1DP_TUNE_STAMPS
+  StepArgsDev d = d0;
+  if (hipError_t e = stamp_hook(d, lc, st); e != hipSuccess) return e;
+#else
+  const StepArgsDev &d = d0;
+#endif
   if (lc.lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS (idempotent, cheap)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PARTICLE_LDS_CAP);

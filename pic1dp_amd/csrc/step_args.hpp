@@ -26,6 +26,9 @@ struct StepArgsDev {
   int pred_nm, t2_mode;
   const double *eh_re, *eh_im;  // k_step_sums: the kept mode of Eh
   double snx, pred_k;           // k_step_one's prediction: nx / lx, and dt/2 Z/m
+#ifdef PIC1DP_TUNE_STAMPS  // tuning build (tools/stamp_probe.sh): [gridDim][8] wall-clock stamps of the phases of a workgroup
+  unsigned long long *stamps;
+#endif
 };
 
 // DIST: 0 Maxwellian, 1 two-stream1, 2 two-stream2, 3 bump-on-tail (-f0'/f0 in the reference's operation order),

@@ -270,6 +270,34 @@ def test_bench_self_launch_starts_rank_processes(amd):
     assert "NODEVICE" in r.stderr
 
 
+def test_bench_launcher_ends_the_job_when_a_rank_dies_early(monkeypatch, capsys):
+    """rank 1 exits with an error while rank 0 would sit in a collective for minutes.  The launcher watches
+    all ranks while it passes rank 0's output through: after the grace period it terminates rank 0 (exact PID) and
+    returns rank 1's code -- it does not wait for rank 0's end of file first."""
+    import importlib.util
+    import sys
+    import time
+    spec = importlib.util.spec_from_file_location("bench_launcher_only", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("PIC1DP_BENCH_GRACE_S", "1")
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    rank_prog = ("import os, sys, time\n"
+                 "r = int(os.environ['RANK'])\n"
+                 "print('rank', r, 'of', os.environ['WORLD_SIZE'], flush=True)\n"
+                 "if r == 1: sys.exit(7)\n"
+                 "time.sleep(300)\n")
+    t0 = time.monotonic()
+    code = bench.launch_ranks(2, cmd=[sys.executable, "-c", rank_prog])
+    took = time.monotonic() - t0
+    err = capsys.readouterr().err
+    assert took < 30.0, "the launcher waited for the hanging rank (%.0f s)" % took
+    assert code != 0
+    assert "rank 1 exited with code 7" in err
+    assert "rank 0 exited with code" in err            # terminated, not left behind
+    assert "rank 0 of 2" in err                        # its non-JSON output went to stderr meanwhile
+
+
 def test_bench_launcher_parent_never_loads_the_hip_library():
     """the module imports without pic1dp_amd (bench.py binds it inside main(), in a rank process only)"""
     import importlib.util

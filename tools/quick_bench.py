@@ -29,16 +29,23 @@ for mode in ((0,) if only0 else (0, 1)):
     eng.set_step_mode(mode)
     eng.step(int(os.environ.get("PIC1DP_QB_WARMUP", "3")))
     eng.sync()
+    # the step time WITHOUT the per-kernel HIP events (two hipEventRecord per marker launch cost ~4 us each on the
+    # stream: 8 us of a 140 us step, profiles/r04/experiments/event_overhead.log); then the same steps with them
+    t0 = time.perf_counter()
+    eng.step(steps)
+    eng.sync()
+    dt = time.perf_counter() - t0
     eng.kernel_stats_enable(True)
     eng.timers_reset()
     t0 = time.perf_counter()
     eng.step(steps)
     eng.sync()
-    dt = time.perf_counter() - t0
+    dt_ev = time.perf_counter() - t0
     ks = [eng.kernel_stats(k) for k in (0, 1, 2, 3, 4, 6)]
     names = ["fused", "push", "deposit", "step_half", "step_full", "step_one"]
     parts = ["%s %.4f ms" % (nm, ms / cnt) for nm, (ms, cnt) in zip(names, ks) if cnt]
-    print("mode %d: %.4e updates/s  %.4f ms/step  | %s" % (mode, n * 2 * steps / dt, dt / steps * 1e3, ", ".join(parts)), flush=True)
+    print("mode %d: %.4e updates/s  %.4f ms/step  | %s | with the events in the stream %.4f ms/step"
+          % (mode, n * 2 * steps / dt, dt / steps * 1e3, ", ".join(parts), dt_ev / steps * 1e3), flush=True)
     eng.kernel_stats_enable(False)
 
 if only0:
