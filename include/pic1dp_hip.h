@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PIC1DP_ABI_VERSION 3
+#define PIC1DP_ABI_VERSION 4
 #define PIC1DP_MAX_SPECIES 8
 #define PIC1DP_MAX_MODES 4096 /* up to the full spectrum nx/2 of the largest grid */
 #define PIC1DP_MAX_INIT_MODES 16
@@ -265,8 +265,8 @@ int pic1dp_hip_step(pic1dp_ctx *ctx, int32_t nsteps);
  *     coefficients of the kept field modes: 56-72 B per marker per step; the
  *     half-step charge then equals a marker-by-marker deposit up to rounding;
  *     PIC1DP_PREDICT=0 in the environment keeps the two passes, 88 B).  The
- *     prediction is held as LDS tiles (two kept modes, or one on grids below
- *     nx = 512; nx up to ~2400) or, with one kept mode (nx up to ~5000), as six
+ *     prediction is held as LDS tiles (two kept modes; nx up to ~1700) or, with
+ *     one kept mode (nx up to ~5000), as six
  *     sums over the markers -- then, through the call sites, the collect_charge after push(1)
  *     leaves in field_chargeden the kept mode's content of the half-step charge
  *     density only (all that solve_field looks at; nothing in the reference driver
@@ -316,17 +316,25 @@ int pic1dp_hip_output_due(pic1dp_ctx *ctx, int32_t itermination, int32_t *flag);
  * HALF-STEP CHARGE DENSITY -- the one place where the state a host can look at differs
  * from what the reference would hold: between the collect_charge after push(1) and the
  * next collect_charge, when that half-step charge was predicted as six sums
- * (pic1dp_hip_predict_kind = 2: one kept mode on grids from nx = 512 up), field_chargeden
+ * (pic1dp_hip_predict_kind = 2: one kept mode), field_chargeden
  * holds its kept mode's content only.  Asking for chargeden here rebuilds the whole
  * vector on a one-rank context: the half-step state is pushed into memory after all and
- * deposited (that step then runs as two ordinary sub-steps; results unchanged to
- * rounding).  On several ranks the rebuild would need the charge sum -- a collective an
- * inspection on one rank must not start -- so there chargeden keeps the kept mode's
- * content between the sub-steps; a host that needs the full half-step vector on several
- * ranks calls pic1dp_hip_set_step_mode(ctx, 1) or sets PIC1DP_PREDICT=0.  Pass
+ * deposited (that step then runs as two ordinary sub-steps -- a noted push(2) is run at
+ * once as well; results unchanged to rounding).  On several ranks the rebuild would need
+ * the charge sum -- a collective an inspection on one rank must not start -- so there
+ * chargeden keeps the kept mode's content between the sub-steps; a host that needs the
+ * full half-step vector on several ranks calls pic1dp_hip_set_step_mode(ctx, 1) or sets
+ * PIC1DP_PREDICT=0.  Whether the vector handed out is the reference's or the kept mode's
+ * content is never left to guessing: pic1dp_hip_chargeden_state says which.  Pass
  * chargeden = NULL to leave it alone. */
 int pic1dp_hip_get_field(pic1dp_ctx *ctx, double *electric, double *chargeden,
                          double *mode_re, double *mode_im);
+/* *kept_mode_only = 1: field_chargeden (as pic1dp_hip_get_field hands it out now) holds
+ * only the kept mode's content of the half-step charge density -- the rebuild described
+ * above was not possible (several ranks; or the markers have been moved on since by
+ * calls outside the push / collect_charge / solve_field sequence); 0: it is the vector
+ * the reference holds (src/pic1dp_interaction.F90:138-150). */
+int pic1dp_hip_chargeden_state(pic1dp_ctx *ctx, int32_t *kept_mode_only);
 /* overwrite field_electric (testing the push against a prescribed field) */
 int pic1dp_hip_set_electric(pic1dp_ctx *ctx, const double *electric);
 /* overwrite field_chargeden (testing the solve; field_test of
@@ -451,7 +459,9 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
  * first sub-step k_step_half (3), second sub-step k_step_full (4); which = 5: number
  * of separate diagnostics passes (k_ptcldist) launched so far, *ms = 0; which = 6: the
  * one-pass-per-step kernel k_step_one (second sub-step + prediction of the next first
- * sub-step's charge) */
+ * sub-step's charge); which = 7: number of k_step_one / k_step_sums launches so far whose
+ * prologue solved the field of the previous step (one launch per time step inside
+ * pic1dp_hip_step: no field_solve_electric launch in between), *ms = 0 */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

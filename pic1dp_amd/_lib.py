@@ -15,7 +15,7 @@ MAX_MODES = 4096
 MAX_INIT_MODES = 16
 COMM_ID_BYTES = 128
 XCHG_HANDLE_BYTES = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_OPT = 32
 
 ERR_NAMES = {1: "ARG", 2: "HIP", 3: "NODEVICE", 4: "STATE", 5: "COMM", 6: "RNG", 7: "NOMEM"}
@@ -106,6 +106,7 @@ SIGNATURES = {
     "pic1dp_hip_check_termination": [_P, C.POINTER(C.c_int32)],
     "pic1dp_hip_output_due": [_P, C.c_int32, C.POINTER(C.c_int32)],
     "pic1dp_hip_get_field": [_P, _P, _P, _P, _P],
+    "pic1dp_hip_chargeden_state": [_P, C.POINTER(C.c_int32)],
     "pic1dp_hip_set_electric": [_P, _P],
     "pic1dp_hip_set_chargeden": [_P, _P],
     "pic1dp_hip_field_energy": [_P, _D],

@@ -95,6 +95,16 @@ struct pic1dp_ctx {
   bool charge_pending = false;  // charge_local ran, waiting for charge_reduced
   // field
   double *d_rho_sp = nullptr, *d_charge = nullptr, *d_chargeden = nullptr, *d_E = nullptr;
+  // The species accumulators and the six sums of the prediction exist three times (kernels.hpp FusedSolve): d_rho_sp /
+  // Species::rho / fa.rho_sp / d_pred always name the set the marker kernels deposit into NOW (acc_idx); all sets are
+  // zero whenever no fused launch sequence is under way
+  double *d_rho_all = nullptr, *d_pred_all = nullptr;
+  size_t rho_set_doubles = 0, pred_set_doubles = 0;
+  int acc_idx = 0;
+  int fuse_solve = 1;           // PIC1DP_FUSE_SOLVE=0: the field solve always in a launch of its own
+  bool fused_pending = false;   // step(): the last marker launch left the solve of its step to the next launch's prologue
+  int fused_dirty = -1;         // accumulator set the last fused launch read (still holding that step's deposits), or -1
+  FusedSolve fuse_args{};       // what the next marker launch's prologue has to solve (on = 1), consumed by step_particles
   double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
   double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
   // one pass per step (kernels_step.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
@@ -164,6 +174,7 @@ struct pic1dp_ctx {
   std::vector<int> diag_blocks;            // [nspecies] workgroups of that pass
   int fuse_output = 0;                     // take the diagnostics inside k_step_full on steps output_all follows
   int64_t diag_passes = 0;                 // separate k_ptcldist passes launched so far
+  int64_t fused_solves = 0;                // marker launches whose prologue solved the previous step's field
   int32_t itime = 0;
   double time = 0.0;
   GridConst grid{};
@@ -585,8 +596,13 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
                           bool pred = false);
 static bool predict_capable(const pic1dp_ctx *c);
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full);
+static LaunchCfg pred_launch(const pic1dp_ctx *c, int64_t np, bool priv, int64_t *resident);
 static size_t step_lds_bytes(int nx, bool full, int rcopies);
 static bool output_follows(const pic1dp_ctx *c);
+static bool output_follows_at(const pic1dp_ctx *c, int32_t itime0, double time0);
+static void optimize_due_at(const pic1dp_ctx *c, double time0, bool due[3]);
+static int finish_pending_solve(pic1dp_ctx *c);
+static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred);
 static void field_written(pic1dp_ctx *c, bool by_solve);
 static bool pred_usable(const pic1dp_ctx *c);
 static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer);
@@ -685,8 +701,11 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   }
   c->grid.gstride = ns * nx;
   const size_t rho_doubles = static_cast<size_t>(c->grid.gcopies) * ns * nx;
-  HIP_TRY_C(hipMalloc(&c->d_rho_sp, sizeof(double) * rho_doubles));
-  HIP_TRY_C(hipMemsetAsync(c->d_rho_sp, 0, sizeof(double) * rho_doubles, c->st));
+  c->rho_set_doubles = rho_doubles;
+  HIP_TRY_C(hipMalloc(&c->d_rho_all, sizeof(double) * 3 * rho_doubles));
+  HIP_TRY_C(hipMemsetAsync(c->d_rho_all, 0, sizeof(double) * 3 * rho_doubles, c->st));
+  c->d_rho_sp = c->d_rho_all;
+  if (const char *e = std::getenv("PIC1DP_FUSE_SOLVE")) c->fuse_solve = std::atoi(e) != 0;
   for (int s = 0; s < ns; ++s) {
     Species &S = c->sp[s];
     S.nalloc = nalloc;
@@ -758,11 +777,13 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     // (the six sums travel in the head of an nx-vector on the call-site path: nx >= 8)
     else if (nm == 1 && nx >= 8 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP)
       c->pred_kind = 2;
-    // One kept mode on a grid of some size: the six sums in thread-private LDS slots (k_step_one<PRIV>) beat the
-    // tiles, whose six atomics per marker at random cells pay ~3x in bank conflicts: -2 % at 1e8 markers / nx 1024,
-    // -1 % at 1.25e7 / 1024, level at nx 256 and 192 where the field launch of the sums is 2-3 us longer
-    // (profiles/r03/experiments/ab_private_sums.log) -- so from nx = 512 up.
-    if (c->pred_kind == 1 && nm == 1 && nx >= 512 && private_fits) c->pred_kind = 2;
+    // One kept mode: the six sums in thread-private LDS slots (k_step_one<PRIV>) beat the tiles, whose six atomics per
+    // marker at random cells pay ~3x in bank conflicts: -2 % at 1e8 markers / nx 1024 (profiles/r03/experiments/
+    // ab_private_sums.log), and on the small grids too once the step is timed without per-kernel events in the stream:
+    // 6.4e6 / nx 192 83.8 -> 76.6 us per step, 1e7 / nx 256 123.7 -> 116.5 (profiles/r04/experiments/ab_fused_solve.log)
+    // -- wherever the slots of two workgroups fit (nx >= 8: the sums travel in the head of an nx-vector on the
+    // call-site path).
+    if (c->pred_kind == 1 && nm == 1 && nx >= 8 && private_fits) c->pred_kind = 2;
     if (const char *e = std::getenv("PIC1DP_PRED_KIND")) {
       const int k = std::atoi(e);
       if (k == 2 && nm == 1 && nx >= 8 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP) c->pred_kind = 2;
@@ -784,14 +805,16 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
       const size_t pred_doubles = c->pred_kind == 2 ? 8 * PRED_SUM_COPIES : static_cast<size_t>(ns) * (1 + 2 * nm) * nx;
       HIP_TRY_C(hipMalloc(&c->d_tabA, sizeof(double) * nm * nx));
       HIP_TRY_C(hipMalloc(&c->d_tabB, sizeof(double) * nm * nx));
-      HIP_TRY_C(hipMalloc(&c->d_pred, sizeof(double) * pred_doubles));
+      c->pred_set_doubles = pred_doubles;
+      HIP_TRY_C(hipMalloc(&c->d_pred_all, sizeof(double) * 3 * pred_doubles));
+      c->d_pred = c->d_pred_all;
       HIP_TRY_C(hipMalloc(&c->d_cd_h, sizeof(double) * nx));
       HIP_TRY_C(hipMalloc(&c->d_Ehn, sizeof(double) * nx));
       HIP_TRY_C(hipMalloc(&c->d_pack, sizeof(double) * pack_doubles(nx, nm, c->pred_kind)));
       HIP_TRY_C(hipMalloc(&c->d_mode_h, sizeof(double) * 2 * nm));
       HIP_TRY_C(hipMemcpy(c->d_tabA, ta.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
       HIP_TRY_C(hipMemcpy(c->d_tabB, tb.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
-      HIP_TRY_C(hipMemset(c->d_pred, 0, sizeof(double) * pred_doubles));
+      HIP_TRY_C(hipMemset(c->d_pred_all, 0, sizeof(double) * 3 * pred_doubles));
     }
     HIP_TRY_C(hipMemcpy(c->d_fre, fre.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
     HIP_TRY_C(hipMemcpy(c->d_fim, fim.data(), sizeof(double) * nm * nx, hipMemcpyHostToDevice));
@@ -849,8 +872,8 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     (void)hipFree(S.slab[1]);
     (void)hipFree(S.t2);
   }
-  double *bufs[] = {c->d_rho_sp, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
-                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred, c->d_cd_h, c->d_mode_h, c->d_Ehn, c->d_pack};
+  double *bufs[] = {c->d_rho_all, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
+                    c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred_all, c->d_cd_h, c->d_mode_h, c->d_Ehn, c->d_pack};
   for (double *b : bufs) (void)hipFree(b);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);
@@ -1255,14 +1278,16 @@ static int allreduce_doubles(pic1dp_ctx *c, double *d, size_t n);
 
 // ---- marker optimisation (host side, rare; see optimize.hpp) -------------------
 // which events are due for the step that is being taken: merge, remove, split
-static void optimize_due(const pic1dp_ctx *c, bool due[3]) {
+// time0: the time at the start of the step being taken
+static void optimize_due_at(const pic1dp_ctx *c, double time0, bool due[3]) {
   const pic1dp_input &in = c->in;
-  const double t = c->time + in.dt;  // src/pic1dp_particle.F90:742,756,770
+  const double t = time0 + in.dt;  // src/pic1dp_particle.F90:742,756,770
   due[0] = c->imerge > 0 && c->imerge <= in.nmerge && t >= in.tmerge[c->imerge - 1];
   due[1] = c->iremove > 0 && c->iremove <= in.nremove && t >= in.tremove[c->iremove - 1];
   due[2] = c->isplit > 0 && c->isplit <= in.nsplit && t >= in.tsplit[c->isplit - 1];
   if (in.deltaf == 0) due[0] = due[1] = due[2] = false;  // :734
 }
+static void optimize_due(const pic1dp_ctx *c, bool due[3]) { optimize_due_at(c, c->time, due); }
 
 static bool optimize_due_any(const pic1dp_ctx *c) {
   bool due[3];
@@ -1468,13 +1493,14 @@ static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
 // the particle kernel(s) of one sub-step of the whole-step path: E0 = field at
 // the start of the step, Eh = field after the first sub-step (full only)
 // does output_all follow the step that is being taken?  (src/pic1dp.F90:98-107 evaluated one step ahead)
-static bool output_follows(const pic1dp_ctx *c) {
+static bool output_follows_at(const pic1dp_ctx *c, int32_t itime0, double time0) {  // (counters at the start of the step)
   const pic1dp_input &in = c->in;
   if (!(in.output_interval > 0.0)) return false;
-  const double t = c->time + in.dt;
-  if (c->itime + 1 >= in.ntime_max || t + kSqrtEps >= in.time_max) return true;
+  const double t = time0 + in.dt;
+  if (itime0 + 1 >= in.ntime_max || t + kSqrtEps >= in.time_max) return true;
   return std::fmod(t + kSqrtEps, in.output_interval) < std::fmod(t + kSqrtEps - in.dt, in.output_interval);
 }
+static bool output_follows(const pic1dp_ctx *c) { return output_follows_at(c, c->itime, c->time); }
 
 // One pass per step (kernels_step.hip k_step_one) needs: the mode-filter solver (the kept modes must
 // describe E), few kept modes, and LDS for E0, Eh, the mode tables and the four accumulators
@@ -1483,6 +1509,65 @@ static bool predict_capable(const pic1dp_ctx *c) {
 }
 static size_t pred_doubles(const pic1dp_ctx *c) {
   return c->pred_kind == 2 ? 8 * PRED_SUM_COPIES : static_cast<size_t>(c->in.nspecies) * (1 + 2 * c->in.nmode) * c->in.nx;
+}
+
+// the accumulator set the marker kernels deposit into from now on (d_rho_all / d_pred_all hold three)
+static void use_accumulators(pic1dp_ctx *c, int idx) {
+  c->acc_idx = idx;
+  c->d_rho_sp = c->d_rho_all + static_cast<size_t>(idx) * c->rho_set_doubles;
+  for (int s = 0; s < c->in.nspecies; ++s) c->sp[s].rho = c->d_rho_sp + static_cast<size_t>(s) * c->in.nx;
+  c->fa.rho_sp = c->d_rho_sp;
+  if (c->d_pred_all) c->d_pred = c->d_pred_all + static_cast<size_t>(idx) * c->pred_set_doubles;
+}
+
+// One launch per time step (kernels.hpp FusedSolve): may the solve of a step be left to the prologue of the next
+// step's marker launch?  One rank (no charge sum between the launches), the six-sum prediction of one kept mode, the
+// mode-filter solver, and partial chains of an npe-rank order that fit the prologue's scratch.
+// And a grid of at most the resident workgroups: EVERY workgroup runs the solve in its prologue, side by side in
+// one round; in an oversubscribed grid each round pays it again (1e8 markers / nx 1024, four rounds: 0.962 -> 0.990 ms
+// per step, profiles/r04/experiments/ab_fused_solve.log).  What the fusion is worth where it applies: one dependency
+// gap and the field launch's start-up, 1-2 us of a step (the solve itself is a chain of dependent round trips either way).
+static bool fuse_capable(const pic1dp_ctx *c) {
+  const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
+  if (!(c->fuse_solve && !multi && c->pred_kind == 2 && c->in.nmode == 1 && c->field_solver == 0 && c->fa.npe <= 32 &&
+        predict_capable(c)))
+    return false;
+  const bool priv = c->pred_private && c->threads_req <= 0;
+  for (int s = 0; s < c->in.nspecies; ++s) {
+    if (c->sp[s].np <= 0) continue;
+    int64_t resident = 0;
+    const LaunchCfg lc = pred_launch(c, c->sp[s].np, priv, &resident);
+    return lc.blocks <= resident;  // (the first species launched carries the solve)
+  }
+  return false;
+}
+
+// launch shape of the one-pass kernels (k_step_one, k_step_one<PRIV>, k_step_sums) for np markers; *resident: the
+// workgroups that fill the CUs (the grid is that, or a multiple: oversubscribed())
+static LaunchCfg pred_launch(const pic1dp_ctx *c, int64_t np, bool priv, int64_t *resident) {
+  LaunchCfg lc{};
+  lc.lds = priv ? step_one_private_lds_bytes(c->in.nx, c->grid.rcopies)
+                : (c->pred_kind == 2 ? step_sums_lds_bytes(c->in.nx, c->grid.rcopies)
+                                     : step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode));
+  bool two = 2 * (lc.lds + kStaticLds) <= kCuLds;  // both workgroups resident: each also holds the static exp table
+  int th2 = 768;   // (= STEP_PRIVATE_THREADS: the private sums' slot stride is a compile-time constant)
+  int th1 = 1024;
+  if (c->pred_kind == 2 && !priv) {
+    // k_step_sums keeps its registers: four waves per SIMD with the exp-bearing distributions (one
+    // workgroup of 1024 per CU), eight with the others, which saturate the memory system with far fewer
+    // (tools/ab_sums_shapes.sh: 1e8 markers, Maxwellian, nx 4096: 512 x 1 0.925 ms, 1024 x 1 0.965 ms)
+    if (c->in.deltaf && (c->in.iptcldist == 2 || c->in.iptcldist == 3))
+      two = false;
+    else
+      th1 = 512;
+  }
+  lc.threads = c->threads_req > 0 ? c->threads_req : (two ? th2 : th1);
+  const int bpc = c->bpc_req > 0 ? c->bpc_req : (two ? 2 : 1);
+  const int64_t need = ((np >> 1) + lc.threads - 1) / lc.threads;
+  const int64_t res = static_cast<int64_t>(c->num_cu) * bpc;
+  if (resident) *resident = res;
+  lc.blocks = static_cast<int>(std::max<int64_t>(1, std::min(oversubscribed(c, np, res, bpc >= 2), need)));
+  return lc;
 }
 
 // full = true: the caller has bumped state_version for this step; the state the kernel READS is version - 1
@@ -1548,6 +1633,11 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       if (!full) S.t2_version = c->state_version;
     }
     LaunchCfg lc = step_launch(c, S.np, full);
+    if (pred && c->fuse_args.on) {  // this launch's prologue solves the previous step's field (first species launched)
+      a.fused = c->fuse_args;
+      c->fuse_args.on = 0;
+      c->fused_solves++;
+    }
     if (pred) {  // k_step_one: the full step + the prediction of the next first sub-step's charge
       a.tabA = c->d_tabA;
       a.tabB = c->d_tabB;
@@ -1575,26 +1665,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
         a.t2_mode = S.t2_version == read_version ? 2 : 1;
         S.t2_version = c->state_version;
       }
-      lc.lds = priv ? step_one_private_lds_bytes(c->in.nx, c->grid.rcopies)
-                    : (c->pred_kind == 2 ? step_sums_lds_bytes(c->in.nx, c->grid.rcopies)
-                                         : step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode));
-      bool two = 2 * (lc.lds + kStaticLds) <= kCuLds;  // both workgroups resident: each also holds the static exp table
-      int th2 = 768;   // (= STEP_PRIVATE_THREADS: the private sums' slot stride is a compile-time constant)
-      int th1 = 1024;
-      if (c->pred_kind == 2 && !priv) {
-        // k_step_sums keeps its registers: four waves per SIMD with the exp-bearing distributions (one
-        // workgroup of 1024 per CU), eight with the others, which saturate the memory system with far fewer
-        // (tools/ab_sums_shapes.sh: 1e8 markers, Maxwellian, nx 4096: 512 x 1 0.925 ms, 1024 x 1 0.965 ms)
-        if (c->in.deltaf && (c->in.iptcldist == 2 || c->in.iptcldist == 3))
-          two = false;
-        else
-          th1 = 512;
-      }
-      lc.threads = c->threads_req > 0 ? c->threads_req : (two ? th2 : th1);
-      const int bpc = c->bpc_req > 0 ? c->bpc_req : (two ? 2 : 1);
-      const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
-      lc.blocks = static_cast<int>(
-          std::max<int64_t>(1, std::min(oversubscribed(c, S.np, static_cast<int64_t>(c->num_cu) * bpc, bpc >= 2), need)));
+      lc = pred_launch(c, S.np, priv, nullptr);
     }
     if (diag) {  // one workgroup of 1024 threads per CU: grid tiles + histograms in its LDS
       const size_t ntot = dist_len(c->in);
@@ -1621,6 +1692,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       std::snprintf(kb.name, sizeof kb.name, "%s%s", pred ? (c->pred_kind == 2 ? (priv ? "k_step_one<sums>" : "k_step_sums") : "k_step_one")
                                                           : (full ? (diag ? "k_step_full<DIAG>" : "k_step_full") : "k_step_half"),
                     S.sc.one_exp && c->in.deltaf ? " (one-exp -f0'/f0)" : "");
+      if (a.fused.on) std::strncat(kb.name, " + field solve", sizeof kb.name - std::strlen(kb.name) - 1);
     }
     Span tm(c, PIC1DP_IWT_PUSH_PARTICLE, c->timers_on);
     Span ks(c, tag, c->stats_on);
@@ -1628,6 +1700,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     if (int rc = ks.end()) return rc;
     if (int rc = tm.end()) return rc;
   }
+  if (c->fuse_args.on) return fail(PIC1DP_ERR_STATE, "internal: a fused field solve found no marker launch to run in");
   if (pred) c->pred_version = c->state_version;
   return 0;
 }
@@ -1704,9 +1777,50 @@ static int predict_half_field(pic1dp_ctx *c) {
 }
 
 // sub-step of the whole-step path: particle kernel(s), charge, field into Eout
-static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool diag = false, bool pred = false) {
+// fused_in: the previous step's marker launch left its solve (field of the state the markers are in, Eh of this step)
+// to this launch's prologue; fuse_out: this step's solve is left to the next launch likewise (fused_pending)
+static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool diag = false, bool pred = false,
+                      bool fused_in = false, bool fuse_out = false) {
   if (full) c->state_version++;
+  if (fused_in) {
+    FusedSolve &fs = c->fuse_args;
+    fs = FusedSolve{};
+    fs.on = 1;
+    fs.f = c->fa;  // rho_sp: the set the previous launch deposited into
+    if (c->hist_count < kHistCap) fs.f.history = c->d_hist + c->hist_count++;
+    fs.pt = c->pred_tab;
+    fs.pred_in = c->d_pred;
+    fs.E_h = c->d_Eh;
+    fs.mode_h = c->d_mode_h;
+    const int read = c->acc_idx, dirty = c->fused_dirty;
+    fs.zero_rho = c->d_rho_all + static_cast<size_t>(dirty >= 0 ? dirty : read) * c->rho_set_doubles;
+    fs.zero_rho_n = dirty >= 0 ? static_cast<int64_t>(c->rho_set_doubles) : 0;
+    fs.zero_pred = dirty >= 0 ? c->d_pred_all + static_cast<size_t>(dirty) * c->pred_set_doubles
+                              : c->d_pred_all + static_cast<size_t>((read + 2) % 3) * c->pred_set_doubles;  // (zero already)
+    use_accumulators(c, (read + 1) % 3);  // zero: nobody has deposited into it since it was last zeroed
+    c->fused_dirty = read;
+    c->fused_pending = false;
+    // what the dedicated launch would have recorded: E and its kept mode are the new state's, Eh is this step's
+    field_written(c, true);
+    c->pred_version = 0;
+    c->eh_modes = 2;
+  }
   if (int rc = step_particles(c, full, c->d_E, c->d_Eh, diag, pred)) return rc;
+  if (fuse_out && pred && c->pred_version == c->state_version) {
+    c->fused_pending = true;
+    return 0;
+  }
+  return solve_phase(c, Eout, record, pred);
+}
+
+// the solve of a step whose marker launch left it pending, in a launch of its own after all
+static int finish_pending_solve(pic1dp_ctx *c) {
+  c->fused_pending = false;
+  return solve_phase(c, c->d_E, true, true);
+}
+
+// charge sum over ranks and field solve(s) behind the marker kernel(s) of a sub-step of the whole-step path
+static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred) {
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   const bool fused_xchg = xchg_active(c) && c->field_solver == 0;  // exchange inside the solve's launch
   // RCCL path of a one-pass step: everything the two charge sums of the step need in one all-reduce
@@ -1728,6 +1842,13 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool 
   if (record && c->hist_count < kHistCap) f.history = c->d_hist + c->hist_count++;
   // one-pass step on one rank or with the exchange: both fields (the new state's, and the next step's
   // half-step field from the prediction) in ONE launch
+  if (c->fused_dirty >= 0) {  // the set the last fused launch read: no launch follows that would zero it
+    HIP_TRY(hipMemsetAsync(c->d_rho_all + static_cast<size_t>(c->fused_dirty) * c->rho_set_doubles, 0,
+                           sizeof(double) * c->rho_set_doubles, c->st));
+    HIP_TRY(hipMemsetAsync(c->d_pred_all + static_cast<size_t>(c->fused_dirty) * c->pred_set_doubles, 0,
+                           sizeof(double) * c->pred_set_doubles, c->st));
+    c->fused_dirty = -1;
+  }
   const bool pair = pred && c->pred_version == c->state_version && (!multi || fused_xchg || will_pack) &&
                     c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (pair) {
@@ -1769,22 +1890,39 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
       // Eh of this step: predicted by the previous step's kernel (one pass per step), or from a
       // first-sub-step pass over the markers
       const bool pc = predict_capable(c);
-      const bool have_eh = pc && c->eh_version == c->state_version && c->eh_field_version == c->field_version;
-      if (have_eh) {
-        std::swap(c->d_Eh, c->d_Ehn);  // d_Eh: the half-step field of the step being taken
-        c->eh_modes = 2;               // its kept modes: d_mode_h
-      } else if (int rc = step_phase(c, false, c->d_Eh, false)) {
-        return rc;
-      } else {
-        c->eh_modes = c->field_solver == 0 ? 1 : 0;  // that solve left them in fa.mode_re / mode_im
-      }
       // the host can only call output_all after the last step of this call
       const bool diag = c->fuse_output && it == nsteps - 1 && output_follows(c);
       const bool pred = pc && !diag;
-      if (int rc = step_phase(c, true, c->d_E, true, diag, pred)) return rc;
-      if (pred && c->pred_version == c->state_version)  // not already turned into Eh by the paired solve
+      // the previous step left its solve to this step's marker launch (one launch per step, kernels.hpp FusedSolve)
+      const bool fused_in = c->fused_pending && pred && fuse_capable(c);
+      if (c->fused_pending && !fused_in)
+        if (int rc = finish_pending_solve(c)) return rc;
+      if (!fused_in) {
+        const bool have_eh = pc && c->eh_version == c->state_version && c->eh_field_version == c->field_version;
+        if (have_eh) {
+          std::swap(c->d_Eh, c->d_Ehn);  // d_Eh: the half-step field of the step being taken
+          c->eh_modes = 2;               // its kept modes: d_mode_h
+        } else if (int rc = step_phase(c, false, c->d_Eh, false)) {
+          return rc;
+        } else {
+          c->eh_modes = c->field_solver == 0 ? 1 : 0;  // that solve left them in fa.mode_re / mode_im
+        }
+      }
+      // may the NEXT step's launch take this step's solve?  Only if that step will be an ordinary predicted one (the
+      // step after an output, an optimisation step or the last step of the call need the field in memory first)
+      bool fuse_out = false;
+      if (pred && it + 1 < nsteps && fuse_capable(c)) {
+        const bool next_diag = c->fuse_output && it + 1 == nsteps - 1 && output_follows_at(c, c->itime + 1, c->time + c->in.dt);
+        bool due[3];
+        optimize_due_at(c, c->time + c->in.dt, due);
+        fuse_out = !next_diag && !(due[0] || due[1] || due[2]);
+      }
+      if (int rc = step_phase(c, true, c->d_E, true, diag, pred, fused_in, fuse_out)) return rc;
+      if (pred && !c->fused_pending && c->pred_version == c->state_version)  // not already turned into Eh by the paired solve
         if (int rc = predict_half_field(c)) return rc;
     } else {
+      if (c->fused_pending)
+        if (int rc = finish_pending_solve(c)) return rc;
       if (int rc = substep_impl(c, 1, false)) return rc;
       HIP_TRY(hipMemcpyAsync(c->d_Eh, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
       if (int rc = substep_impl(c, 2, true)) return rc;
@@ -1792,6 +1930,8 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
     c->itime += 1;                  // src/pic1dp.F90:92
     c->time = c->time + c->in.dt;   // :93
   }
+  if (c->fused_pending)  // (the last step of a call never leaves its solve pending; a safety net)
+    if (int rc = finish_pending_solve(c)) return rc;
   return 0;
 }
 
@@ -1871,12 +2011,28 @@ int pic1dp_hip_output_due(pic1dp_ctx *c, int32_t itermination, int32_t *flag) {
 // mode's content (include/pic1dp_hip.h says so).  The field solved from either is the same to rounding: the
 // solve only looks at the kept mode.
 static int rebuild_half_step_chargeden(pic1dp_ctx *c) {
-  c->cd_kept_mode_only = false;
-  if (c->lz != LZ_HALF || c->lay.nranks > 1 || c->comm != nullptr) return 0;
+  // the flag is cleared only when the vector has actually been rebuilt: on several ranks, or when the
+  // markers have left the half-step state through calls outside the sequence, chargeden keeps the kept mode's
+  // content and pic1dp_hip_chargeden_state says so
+  if (c->lay.nranks > 1 || c->comm != nullptr) return 0;
+  if (c->lz != LZ_HALF && c->lz != LZ_PUSH2) return 0;
+  const bool push2_noted = c->lz == LZ_PUSH2;
   if (int rc = enqueue_push(c, 1, false, c->d_E0)) return rc;
   c->lz = LZ_CLEAN;  // memory now holds the half-step state (x not yet wrapped): the deposit wraps and stores it
   if (int rc = enqueue_deposit(c)) return rc;
   HIP_TRY(launch_chargeden(c->fa, true, c->st));
+  c->cd_kept_mode_only = false;
+  // a push(2) that had been noted: memory as the eager calls would have left it (the field it sees, d_E, is the one
+  // solve_field wrote after the half step)
+  if (push2_noted)
+    if (int rc = enqueue_push(c, 2, false)) return rc;
+  return 0;
+}
+
+int pic1dp_hip_chargeden_state(pic1dp_ctx *c, int32_t *kept_mode_only) {
+  CHECK_CTX(c);
+  if (!kept_mode_only) return fail(PIC1DP_ERR_ARG, "null output");
+  *kept_mode_only = c->cd_kept_mode_only ? 1 : 0;
   return 0;
 }
 
@@ -2438,10 +2594,10 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 6) return fail(PIC1DP_ERR_ARG, "which must be 0..6");
-  if (which == 5) {  // separate diagnostics passes (k_ptcldist): a count, no time
+  if (which < 0 || which > 7) return fail(PIC1DP_ERR_ARG, "which must be 0..7");
+  if (which == 5 || which == 7) {  // separate diagnostics passes (k_ptcldist) / field solves inside marker launches: counts
     if (ms) *ms = 0.0;
-    if (launches) *launches = c->diag_passes;
+    if (launches) *launches = which == 5 ? c->diag_passes : c->fused_solves;
     return 0;
   }
   if (int rc = ev_resolve(c)) return rc;

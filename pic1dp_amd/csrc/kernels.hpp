@@ -120,6 +120,49 @@ struct LaunchCfg {
   size_t lds;    // dynamic LDS bytes
 };
 
+struct FieldArgs {
+  double *rho_sp;        // [rho_copies][nspecies][nx] raw per-species deposits (zeroed after use)
+  int rho_copies, rho_stride;  // copies the particle kernels flush into, doubles between them (GridConst::gcopies)
+  double *charge;        // [nx] charge2 / charge1 (local sum, all-reduced in place)
+  double *chargeden;     // [nx]
+  double *E;             // [nx]
+  double *mode_re, *mode_im;   // [nmode]
+  const double *fre, *fim;     // [nmode][nx] cos / -sin tables
+  const double *grad_inv;      // [nmode]
+  double *history;       // energy slot to write, or nullptr
+  int nx, nmode, nspecies, deltaf;
+  int npe;               // reference ranks reproduced: > 1 takes the forward sums in the npe-rank order (MPI-AIJ row
+                         // blocks, kernels_field.hip rank_block), 1 in the one-rank ascending order
+  int tab_lds;           // 1: stage the tables in LDS (they fit)
+  double lx, dnx, sc_re, sc_im;
+  double Z[8], n0[8];
+};
+
+// what the host knows of the one kept mode's tables (pred_kind 2): their sums (full-f offset) and their Gram
+// matrix (kept-mode reconstruction of chargeden for the call-site path)
+struct PredTab {
+  double sum_fre, sum_fim, g11, g22, g12;
+};
+
+// A whole-step launch whose PROLOGUE solves the field of the previous step itself (kernels_step.hip FUSED; one rank, one
+// kept mode, prediction as six sums): every workgroup forms charge2 / chargeden from the accumulators the previous
+// launch deposited into, runs the forward sums in the reference's order (the same device functions as the field
+// kernels: device_field.hpp), and writes E0 and Eh of this step straight into its LDS tiles -- one launch per time
+// step instead of two; workgroup 0 also writes what the field kernel would have left in memory.  The accumulators
+// rotate through three buffers: read (deposited by the previous launch), deposit (this launch), zeroed by workgroup 0
+// (read by the previous launch: nobody touches it any more).
+struct FusedSolve {
+  int on;                 // 0: the launch stages E0 / Eh from memory
+  FieldArgs f;            // rho_sp: the accumulators to READ (left as they are); charge, chargeden, E, mode_re / mode_im,
+                          // history: outputs of workgroup 0
+  PredTab pt;
+  const double *pred_in;  // [PRED_SUM_COPIES][8] the previous launch's six sums (read, left as they are)
+  double *E_h, *mode_h;   // workgroup 0: this step's half-step field and its kept mode (re, im)
+  double *zero_rho;       // workgroup 0 zeroes zero_rho[0 .. zero_rho_n) and zero_pred[0 .. 8 PRED_SUM_COPIES)
+  int64_t zero_rho_n;
+  double *zero_pred;
+};
+
 // whole-time-step path: state updated in place, half-step state recomputed
 struct StepArgs {
   double *x, *v, *w;   // particle_x/v/w, updated in place by the full kernel
@@ -151,6 +194,7 @@ struct StepArgs {
   int pred_private;  // pred_kind 2 on a grid whose E0, Eh and table tiles fit the LDS: k_step_one<PRIV>, the six sums in
                      // thread-private LDS slots (Eh staged from memory like k_step_one's)
   const double *eh_re, *eh_im;
+  FusedSolve fused;  // pred_kind 2 only: the prologue solves the previous step's field (E0, Eh, eh_re / eh_im unused)
 };
 constexpr int PRED_MAX_MODES = 2;
 // pred_kind 2: the six sums (padded to 8) are kept in this many copies -- workgroup b of the marker kernel adds into
@@ -193,23 +237,6 @@ hipError_t launch_push(const PushArgs &a, bool fused_deposit, const LaunchCfg &l
 hipError_t launch_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst &g,
                           const LaunchCfg &lc, hipStream_t st);
 
-struct FieldArgs {
-  double *rho_sp;        // [rho_copies][nspecies][nx] raw per-species deposits (zeroed after use)
-  int rho_copies, rho_stride;  // copies the particle kernels flush into, doubles between them (GridConst::gcopies)
-  double *charge;        // [nx] charge2 / charge1 (local sum, all-reduced in place)
-  double *chargeden;     // [nx]
-  double *E;             // [nx]
-  double *mode_re, *mode_im;   // [nmode]
-  const double *fre, *fim;     // [nmode][nx] cos / -sin tables
-  const double *grad_inv;      // [nmode]
-  double *history;       // energy slot to write, or nullptr
-  int nx, nmode, nspecies, deltaf;
-  int npe;               // reference ranks reproduced: > 1 takes the forward sums in the npe-rank order (MPI-AIJ row
-                         // blocks, kernels_field.hip rank_block), 1 in the one-rank ascending order
-  int tab_lds;           // 1: stage the tables in LDS (they fit)
-  double lx, dnx, sc_re, sc_im;
-  double Z[8], n0[8];
-};
 
 // one-hop charge exchange between the GPUs of a node (kernels_field.hip exchange_charge)
 constexpr int XCHG_MAX_RANKS = 16;
@@ -228,11 +255,6 @@ constexpr int XCHG_MAX_VEC = 6;
 // both fields of a one-pass step in one launch: the new state's field from its deposited charge, then the
 // NEXT step's half-step field from k_step_one's prediction (x1: the ONE exchange of a multi-rank step -- charge2
 // and the Z-weighted prediction slices travel together --, or null)
-// what the host knows of the one kept mode's tables (pred_kind 2): their sums (full-f offset) and their Gram
-// matrix (kept-mode reconstruction of chargeden for the call-site path)
-struct PredTab {
-  double sum_fre, sum_fim, g11, g22, g12;
-};
 struct PairArgs {
   double *pred;     // kind 1: [nspecies][1 + 2 nmode][nx]; kind 2: [PRED_SUM_COPIES][8] the six sums; consumed (re-zeroed)
   double *E_h;      // [nx] half-step field of the next step

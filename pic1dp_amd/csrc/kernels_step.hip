@@ -11,6 +11,7 @@
 // -DPIC1DP_STEP_DIST (0 Maxwellian, 1 two-stream1, 2 two-stream2, 3 bump-on-tail, 4 / 5 the one-exp forms of 2 / 3),
 // in parallel; step_dispatch.cpp picks the instance.
 #include "device_diag.hpp"
+#include "device_field.hpp"
 #include "device_math.hpp"
 #include "step_args.hpp"
 
@@ -320,6 +321,119 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
   return t2;
 }
 
+// ---------------------------------------------------------------------------
+// FUSED: the prologue of a one-pass launch solves the field of the PREVIOUS step itself (kernels.hpp FusedSolve).
+// A time step then is ONE launch: the separate field launch (8-12 us of dependent round trips on one CU while 255
+// idle) and the dependency gap in front of it (~3 us) go; what remains is the solve's own latency -- charge ->
+// products -> the serial forward sums (the reference's order: 1 us at nx 192, 5.8 us at nx 1024 in the one-rank
+// order) -> inverse --, run by EVERY workgroup for itself, side by side, with the very device functions of the
+// field kernels (device_field.hpp: the same products in the same order, hence the same bits as
+// k_field_solve_pair_sums1 gives for the same accumulators).  No workgroup waits for another, nothing is exchanged:
+// the accumulators are complete when the launch starts, and every workgroup reads all of them (nx doubles, L2 hits).
+// sE0: the tile E0 goes to -- and, until the sums have run, the products of the cos table; sX: products of the -sin
+// table, then (TILE_EH) the tile of Eh; sSc: [88] scratch.  Workgroup 0 writes to memory what the field kernel
+// would have: charge, chargeden, E, the kept mode, Eh and its kept mode, the field energy; and zeroes the
+// accumulators the previous launch read.  Ends without a barrier: the caller's follows.
+// ---------------------------------------------------------------------------
+constexpr int FUSED_CHAIN_W = 8;  // register batch of the serial sums inside a kernel held to 80 VGPRs
+template <bool TILE_EH>
+__device__ __forceinline__ void fused_solve(const FusedSolve &fs, double *sE0, double *sX, double *sSc, double &re_h,
+                                            double &im_h) {
+  const FieldArgs &f = fs.f;
+  const int nx = f.nx;
+  double *sMode = sSc, *sScr = sSc + 8, *sPart = sSc + 24;
+  const bool lead = blockIdx.x == 0;
+  double *sPc = sE0, *sPs = sX;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
+    double c2 = 0.0;
+    for (int sp = 0; sp < f.nspecies; ++sp) {  // src/pic1dp_interaction.F90:126-127
+      const double *r = f.rho_sp + static_cast<size_t>(sp) * nx + ix;
+      double c1 = *r;
+      for (int g = 1; g < f.rho_copies; ++g) c1 = c1 + r[static_cast<size_t>(g) * f.rho_stride];
+      c2 = c2 + c1 * f.Z[sp];
+    }
+    const double cd = chargeden_from(f, c2);  // :138-148
+    if (lead) {
+      f.charge[ix] = c2;
+      f.chargeden[ix] = cd;
+    }
+    sPc[ix] = f.fre[ix] * cd;
+    sPs[ix] = f.fim[ix] * cd;
+  }
+  if (lead) {  // the accumulators the previous launch read: nobody looks at them any more
+    for (int64_t i = threadIdx.x; i < fs.zero_rho_n; i += blockDim.x) fs.zero_rho[i] = 0.0;
+    if (threadIdx.x < 8 * PRED_SUM_COPIES) fs.zero_pred[threadIdx.x] = 0.0;
+  }
+  __syncthreads();
+  const double ginv = f.grad_inv[0];
+  {  // the forward sums (:231-240); beside them the last wave adds up the copies of the six sums, in copy order
+    const double acc = lean_forward_sums<FUSED_CHAIN_W>(f, sPc, sPs, sPart, [&]() {
+      const int k = static_cast<int>(threadIdx.x) - (static_cast<int>(blockDim.x) - 64);
+      if (k >= 0 && k < 6) {
+        double a = 0.0;
+        static_assert(PRED_SUM_COPIES % 8 == 0, "eight copies in flight at a time");
+        for (int c0 = 0; c0 < PRED_SUM_COPIES; c0 += 8) {
+          double t[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) t[c] = fs.pred_in[(c0 + c) * 8 + k];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) a = (c0 + c == 0) ? t[0] : a + t[c];
+        }
+        sMode[2 + k] = a;
+      }
+    });
+    if (threadIdx.x == 0) {
+      const double im = acc * f.sc_im * ginv;
+      sMode[1] = im;
+      if (lead) f.mode_im[0] = im;
+    } else if (threadIdx.x == 1) {
+      const double re = acc * f.sc_re * ginv;
+      sMode[0] = re;
+      if (lead) f.mode_re[0] = re;
+    }
+  }
+  __syncthreads();
+  const double re = sMode[0], im = sMode[1];
+  double ac, as;
+  pred_forward_sums(f, fs.pt, sMode + 2, re, im, ac, as);
+  im_h = ac * f.sc_im * ginv;  // :234, :239, :243-247
+  re_h = as * f.sc_re * ginv;
+  if (lead && threadIdx.x == 0) {
+    fs.mode_h[0] = re_h;
+    fs.mode_h[1] = im_h;
+  }
+  double e2 = 0.0;
+  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {  // both inverse transforms, :251-257
+    const double tr = f.fre[ix], ti = f.fim[ix];
+    double a = 0.0;
+    a = a + tr * re;
+    a = a + ti * im;
+    const double e = a * 2.0;
+    double b = 0.0;
+    b = b + tr * re_h;
+    b = b + ti * im_h;
+    const double eh = b * 2.0;
+    sE0[ix] = e;
+    if constexpr (TILE_EH) sX[ix] = eh;
+    if (ix == 0) {  // the guard cell behind the last one
+      sE0[nx] = e;
+      if constexpr (TILE_EH) sX[nx] = eh;
+    }
+    e2 += e * e;
+    if (lead) {
+      f.E[ix] = e;
+      fs.E_h[ix] = eh;
+    }
+  }
+  if (lead && f.history) {  // int E^2 dx, src/pic1dp_output.F90:120-124
+    const double tot = block_sum(e2, sScr);
+    if (threadIdx.x == 0) {
+      const double nrm = sqrt(tot);
+      *f.history = nrm * nrm * f.lx / f.dnx;
+    }
+  }
+}
+
 // PRIV: the prediction of ONE kept mode as six sums instead of three tiles (the algebra of k_step_sums below: the
 // solve only ever projects the predicted charge on the kept mode's tables, and the projection of a CIC deposit of q
 // at x' is q times the gather of the table at x'), accumulated in THREAD-PRIVATE LDS slots.  k_step_one is LDS-bound
@@ -391,8 +505,9 @@ __device__ __forceinline__ double pred_one_private(const One &n, double p, int i
 // T2: 0 no carry of -f0'/f0; 1 this step evaluates it, the next step's value is stored; 2 this
 // step's value is loaded (stored by the previous k_step_one), the next step's stored
 // NM: kept modes of the prediction tiles (1, 2); PRIV (NM = 1): six sums in thread-private slots instead
-template <int DIST, int MODE, int POW2, bool NT, int T2, int NM, bool PRIV = false>
+template <int DIST, int MODE, int POW2, bool NT, int T2, int NM, bool PRIV = false, bool FUSED = false>
 __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
+  static_assert(!FUSED || PRIV, "the fused solve serves the six-sum prediction");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   STAMP(a, 0);
   STAMP_HWID(a);
@@ -406,9 +521,11 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   double *sR0 = sAB + static_cast<size_t>(nx + 1) * 2 * nm;
   double *sP = sR0 + ((nx * a.g.rcopies + 2) & ~1);              // [nx + 2][1 + 2 nm]: R0 RA_m RB_m per cell
                                                                  // PRIV: [6][blockDim] private sums, then [16] scratch
-  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-    sE0[i] = a.E0[i];
-    sEh[i] = a.Eh[i];
+  if constexpr (!FUSED) {
+    for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+      sE0[i] = a.E0[i];
+      sEh[i] = a.Eh[i];
+    }
   }
   for (int i = threadIdx.x; i < nm * (nx + 1); i += blockDim.x) {
     const int m = i / (nx + 1), c = i - m * (nx + 1), cs = c < nx ? c : 0;  // cell nx: the guard, = cell 0
@@ -416,14 +533,19 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     sAB[c * 2 * nm + 2 * m + 1] = a.tabB[m * nx + cs];
   }
   zero_rho(sR0, a.g);
+  if constexpr (FUSED) {  // E0 and Eh of this step from the previous launch's deposits and six sums (scratch: the
+                          // head of the slots, zeroed behind it)
+    double re_h, im_h;
+    fused_solve<true>(a.fused, sE0, sEh, sP, re_h, im_h);
+    __syncthreads();
+  } else if (threadIdx.x == 0) {
+    sE0[nx] = a.E0[0];
+    sEh[nx] = a.Eh[0];
+  }
   if constexpr (PRIV) {
     for (int k = 0; k < 6; ++k) sP[k * PRIV_THREADS + threadIdx.x] = 0.0;
   } else {
     for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
-  }
-  if (threadIdx.x == 0) {
-    sE0[nx] = a.E0[0];
-    sEh[nx] = a.Eh[0];
   }
   __syncthreads();
   STAMP(a, 1);
@@ -590,7 +712,7 @@ __device__ __forceinline__ double pred_one_sums(const One &n, double p, int ix, 
 #else
 #define PIC1DP_SUMS_ATTR
 #endif
-template <int DIST, int MODE, int POW2, bool NT, int T2>
+template <int DIST, int MODE, int POW2, bool NT, int T2, bool FUSED = false>
 __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepArgsDev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   STAMP(a, 0);
@@ -604,19 +726,27 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   double *sR0 = sB + ne;
   double *sScr = sR0 + ((nx * a.g.rcopies + 2) & ~1);  // [6][16] reduction scratch
   for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-    sE0[i] = a.E0[i];
+    if constexpr (!FUSED) sE0[i] = a.E0[i];
     sA[i] = a.tabA[i];
     sB[i] = a.tabB[i];
   }
-  zero_rho(sR0, a.g);
   if (threadIdx.x == 0) {
-    sE0[nx] = a.E0[0];
+    if constexpr (!FUSED) sE0[nx] = a.E0[0];
     sA[nx] = a.tabA[0];
     sB[nx] = a.tabB[0];
   }
+  double re_h, im_h;
+  if constexpr (FUSED) {  // E0 and the kept mode of Eh from the previous launch's deposits and six sums; the rho tile
+                          // holds the second row of products meanwhile
+    fused_solve<false>(a.fused, sE0, sR0, sScr, re_h, im_h);  // (its sums have left the rho tile behind its last barrier)
+  } else {
+    re_h = *a.eh_re;
+    im_h = *a.eh_im;
+  }
+  zero_rho(sR0, a.g);
   __syncthreads();
   STAMP(a, 1);
-  const ModeField sEh{sA, sB, *a.eh_re, *a.eh_im};
+  const ModeField sEh{sA, sB, re_h, im_h};
   double *sR = my_rho_copy(sR0, a.g);
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
@@ -753,6 +883,16 @@ template <int DIST, int MODE, int POW2, bool CARRY = false>
 hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc, hipStream_t st) {
   if (full && d.pred && d.pred_nm == -2) {  // one pass per step, six sums in thread-private LDS slots
     const int t2m = d.t2 ? d.t2_mode : 0;
+    if (d.fused.on) {  // ... and the previous step's field solved in the prologue
+      if (d.nt) {
+        if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, 1, true, true>, d, lc, st);
+        if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, 1, true, true>, d, lc, st);
+        return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 1, true, true>, d, lc, st);
+      }
+      if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, 1, true, true>, d, lc, st);
+      if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, 1, true, true>, d, lc, st);
+      return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 1, true, true>, d, lc, st);
+    }
     if (d.nt) {
       if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, 1, true>, d, lc, st);
       if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, 1, true>, d, lc, st);
@@ -764,6 +904,16 @@ hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc,
   }
   if (full && d.pred && d.pred_nm < 0) {  // one pass per step, prediction as six sums (large grids)
     const int t2m = d.t2 ? d.t2_mode : 0;
+    if (d.fused.on) {
+      if (d.nt) {
+        if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 2, true>, d, lc, st);
+        if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1, true>, d, lc, st);
+        return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 0, true>, d, lc, st);
+      }
+      if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 2, true>, d, lc, st);
+      if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 1, true>, d, lc, st);
+      return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 0, true>, d, lc, st);
+    }
     if (d.nt) {
       if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 2>, d, lc, st);
       if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1>, d, lc, st);

@@ -157,6 +157,14 @@ class Pic1dp:
         1: two fused sub-steps through the RK ping-pong sets"""
         check(self.L.pic1dp_hip_set_step_mode(self._ctx, mode))
 
+    def chargeden_kept_mode_only(self):
+        """True: field_chargeden holds only the kept mode's content of the half-step charge density (between the
+        sub-steps of a step whose half-step charge was predicted as six sums, where the library could not rebuild the
+        reference's vector: several ranks); False: it is the reference's vector"""
+        k = C.c_int32()
+        check(self.L.pic1dp_hip_chargeden_state(self._ctx, C.byref(k)))
+        return bool(k.value)
+
     def predict_kind(self):
         """how step mode 0 predicts the next first sub-step's charge: 0 not (two passes per step),
         1 prediction tiles (k_step_one), 2 six sums (k_step_sums, large grids)"""

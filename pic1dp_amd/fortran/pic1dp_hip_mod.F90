@@ -10,7 +10,7 @@ module pic1dp_hip
 use iso_c_binding
 implicit none
 
-integer(c_int), parameter :: PIC1DP_ABI_VERSION = 3
+integer(c_int), parameter :: PIC1DP_ABI_VERSION = 4
 integer(c_int), parameter :: PIC1DP_MAX_SPECIES = 8
 integer(c_int), parameter :: PIC1DP_MAX_MODES = 4096
 integer(c_int), parameter :: PIC1DP_MAX_INIT_MODES = 16
@@ -262,6 +262,12 @@ interface
     real(c_double), intent(inout) :: mode_im(*)
     integer(c_int) :: ierr
   end function pic1dp_hip_get_field
+  function pic1dp_hip_chargeden_state(ctx, kept_mode_only) bind(C, name="pic1dp_hip_chargeden_state") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), intent(out) :: kept_mode_only
+    integer(c_int) :: ierr
+  end function pic1dp_hip_chargeden_state
   function pic1dp_hip_set_electric(ctx, electric) bind(C, name="pic1dp_hip_set_electric") result(ierr)
     import
     type(c_ptr), value :: ctx

@@ -46,7 +46,7 @@ CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
                  "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "attribution", "strong_1e8_total")
 
 
-@pytest.mark.parametrize("config,nx,kernel,carry", [("c3", 256, "k_step_one", None), ("c3", 1024, "k_step_one<sums>", 0.0),
+@pytest.mark.parametrize("config,nx,kernel,carry", [("c3", 256, "k_step_one<sums>", 0.0), ("c3", 1024, "k_step_one<sums>", 0.0),
                                                     ("c5", 4096, "k_step_sums", 0.0)])
 def test_bench_contract_line_small(config, nx, kernel, carry):
     """the one JSON line of a default-form run (N = 1), without the traffic passes: contract keys, the roofline

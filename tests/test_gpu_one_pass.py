@@ -188,6 +188,39 @@ def test_chargeden_between_the_sub_steps_is_rebuilt_on_inspection(amd, monkeypat
     assert a.kernel_stats(6)[1] >= 1 and a.kernel_stats(3)[1] >= 2
 
 
+def test_chargeden_asked_for_between_push2_and_collect_charge(amd, monkeypatch):
+    """push(2) has been NOTED (nothing launched) when the host asks for field_chargeden -- still the kept
+    mode's content of the half-step charge density.  The library rebuilds the reference's vector (half push into
+    memory, deposit) and then runs the noted push(2) at once, so that memory is what eager calls would hold; the flag
+    that says 'kept mode only' is cleared because the vector WAS rebuilt, and pic1dp_hip_chargeden_state reports it."""
+    kw = dict(nparticle_max=N, nx=96, init_nmode=2, init_mode=[1, 3], init_mode_cos=[0.0, 0.0], init_mode_sin=[1e-3, 5e-4])
+    a = engine(amd, monkeypatch, True, 2, **kw)
+    monkeypatch.setenv("PIC1DP_LAZY_CALLS", "0")
+    b = engine(amd, monkeypatch, False, **kw)
+    monkeypatch.delenv("PIC1DP_LAZY_CALLS")
+    for it in range(4):
+        for irk in (1, 2):
+            for e in (a, b):
+                e.interaction_push_particle(irk)
+                if irk == 2 and it == 2:           # between push(2) and its collect_charge
+                    if e is a:
+                        assert a.chargeden_kept_mode_only()         # served from the six sums after push(1)
+                    cd = e.get_field()["chargeden"]
+                    if e is a:
+                        assert not a.chargeden_kept_mode_only()     # rebuilt
+                        cd_a = cd
+                    else:
+                        spec = np.abs(np.fft.rfft(cd))
+                        assert spec[3] > 0.05 * spec[1]             # mode 3 is in the full vector only
+                        assert relerr(cd_a, cd) < 1e-11
+                e.interaction_collect_charge()
+                e.field_solve_electric()
+            assert relerr(a.get_field(chargeden=False)["electric"], b.get_field()["electric"]) < 1e-10, (it, irk)
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-10 * max(1.0, np.max(np.abs(gb[k]))), k
+
+
 @pytest.mark.parametrize("kw", [dict(nx=96), dict(nx=1000), dict(nx=2050, deltaf=0),
                                 dict(nx=64, nspecies=2, iptcldist=0, species_charge=[-1.0, 1.0], species_mass=[1.0, 25.0],
                                      species_temperature=[1.0, 0.5], species_temperature2=[1.0, 1.0],
@@ -326,14 +359,17 @@ def test_one_pass_at_the_lds_limits(amd, monkeypatch, kw, kind):
 
 
 @pytest.mark.parametrize("nx,force,kind,kernel", [
-    (512, None, 2, "k_step_one<sums>"),       # the library's own choice from nx = 512 up ...
-    (511, None, 1, "k_step_one"),             # ... and the tiles below
+    (8, None, 2, "k_step_one<sums>"),         # the library's own choice for one kept mode from nx = 8 up (round 4) ...
+    (7, None, 1, "k_step_one"),               # ... the tiles below (the sums travel in the head of an nx-vector)
+    (192, None, 2, "k_step_one<sums>"),       # the reference's default grid
+    (192, 1, 1, "k_step_one"),                # the tiles when insisted on
     (1096, None, 2, "k_step_one<sums>"),      # the last grid whose tiles and slots fit a CU twice
     (1097, None, 1, "k_step_one"),            # one cell more: the tiles again by default,
     (1097, 2, 2, "k_step_sums")],             # the register sums when the six sums are insisted on
-    ids=["private_first", "below", "private_last", "beyond_default", "beyond_forced_sums"])
+    ids=["private_first", "below", "default_grid", "default_grid_forced_tiles", "private_last", "beyond_default",
+         "beyond_forced_sums"])
 def test_private_sums_at_their_limits(amd, monkeypatch, nx, force, kind, kernel):
-    """k_step_one<PRIV> (six sums in thread-private LDS slots) between nx = 512 and the last grid at which E0, Eh, the
+    """k_step_one<PRIV> (six sums in thread-private LDS slots) between nx = 8 and the last grid at which E0, Eh, the
     tables, the rho tile and the slots of TWO workgroups fit a CU's LDS (kernels.hpp step_one_private_lds_bytes): the
     choice, the kernel that ran (as the library names it), and the run against the two-pass engine"""
     kw = dict(nx=nx, nparticle_max=N)
@@ -375,3 +411,118 @@ def test_prediction_of_markers_that_cross_several_boxes(amd, monkeypatch, kind):
     assert relerr(a.get_field_half(), b.get_field_half()) < 1e-11
     assert a.kernel_stats(6)[1] == 5
 
+
+
+# ---------------------------------------------------------------------------
+# One launch per time step: the marker kernel's prologue solves the field of the previous step (kernels_step.hip
+# FUSED, kernels.hpp FusedSolve) with the device functions of the field kernels.  PIC1DP_FUSE_SOLVE=0 keeps the solve
+# in a launch of its own.
+# ---------------------------------------------------------------------------
+def fused_pair(amd, monkeypatch, npe=1, env=None, **kw):
+    """two engines on the same input: the solve inside the marker launches, and in launches of its own"""
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "1")
+    a = engine(amd, monkeypatch, True, 2, npe=npe, **kw)
+    monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "0")
+    b = engine(amd, monkeypatch, True, 2, npe=npe, **kw)
+    monkeypatch.delenv("PIC1DP_FUSE_SOLVE")
+    return a, b
+
+
+FUSED_CASES = [
+    ("bump_private_slots", dict(), 1, {}),
+    ("bump_register_sums", dict(), 1, {"PIC1DP_PRED_PRIVATE": "0"}),
+    ("bump_four_rank_order", dict(), 4, {}),
+    ("bump_reference_order_dlnf0_carry", dict(), 1, {"PIC1DP_DLNF0": "ref"}),
+    ("two_stream2_nonpow2", dict(iptcldist=2, species_density=[1.0], species_v0=[3.0], species_temperature=[0.9],
+                                 species_mass=[1.2]), 1, {}),
+    ("maxwellian_linear", dict(iptcldist=0, species_density=[1.0], species_v0=[0.0], linear=1), 1, {}),
+    ("maxwellian_full_f", dict(iptcldist=0, species_density=[1.0], species_v0=[0.0], deltaf=0), 2, {}),
+    ("two_species", dict(nspecies=2, species_charge=[-1.0, 1.0], species_mass=[1.0, 4.0], species_temperature=[1.0, 1.0],
+                         species_temperature2=[1.0, 1.0], species_density=[0.9, 0.9], species_v0=[5.0, 5.0],
+                         species_nparticle_init=[96, 96]), 1, {}),
+]
+
+
+@pytest.mark.parametrize("name,kw,npe,env", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+def test_fused_solve_bit_identical_to_the_field_kernel(amd, monkeypatch, name, kw, npe, env):
+    """With at most one wave of markers per rank block the charge sums have ONE order (a wave's lanes, then program
+    order), so both engines see the same bits in their accumulators at every step -- and must then agree bit for bit
+    in everything the solve writes: E, charge density, the kept mode, the predicted half-step field, the field energy
+    of every step, and the markers that were pushed with those fields."""
+    kw = dict(kw, nparticle_max=96, nx=32)
+    a, b = fused_pair(amd, monkeypatch, npe=npe, env=env, **kw)
+    nsteps = 25
+    a.step(nsteps)
+    b.step(nsteps)
+    assert a.kernel_stats(7)[1] == nsteps - 1 and b.kernel_stats(7)[1] == 0      # (the first step of a run takes two passes)
+    fa, fb = a.get_field(), b.get_field()
+    for k in ("electric", "chargeden", "mode_re", "mode_im"):
+        assert np.array_equal(fa[k], fb[k]), k
+    assert np.array_equal(a.get_field_half(), b.get_field_half())
+    assert np.array_equal(a.energy_history(), b.energy_history())
+    for isp in range(kw.get("nspecies", 1)):
+        ga, gb = a.particles_download(isp), b.particles_download(isp)
+        for k in "xvw":
+            assert np.array_equal(ga[k], gb[k]), (isp, k)
+    # and nothing is left behind in the accumulators: the next deposit starts from zero in both
+    a.interaction_collect_charge()
+    b.interaction_collect_charge()
+    assert np.array_equal(a.get_field()["chargeden"], b.get_field()["chargeden"])
+
+
+@pytest.mark.parametrize("nx,env", [(1024, {}), (96, {}), (2500, {}), (1024, {"PIC1DP_PRED_PRIVATE": "0"})],
+                         ids=["nx1024_private_slots", "nx96_private_slots", "nx2500_register_sums", "nx1024_register_sums"])
+def test_fused_solve_many_markers(oracle_mod, amd, monkeypatch, nx, env):
+    """at a realistic marker count (the order of the charge atomics differs between runs): every step's field energy
+    against the oracle, 1e-10, and against the engine that solves in launches of its own, 1e-11; calls of one step
+    never fuse (their field has to be in memory when they return), calls of several fuse all but the last"""
+    kw = dict(nparticle_max=N, nx=nx)
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    a, b = fused_pair(amd, monkeypatch, env=env, **kw)
+    eo = []
+    for _ in range(60):
+        sim.step(1)
+        eo.append(sim.field_energy())
+    for e in (a, b):
+        e.step(1)
+        e.step(1)
+        e.step(30)
+        e.step(1)
+        e.step(27)
+    assert a.kernel_stats(7)[1] == 29 + 26 and b.kernel_stats(7)[1] == 0
+    ea, eb = a.energy_history(), b.energy_history()
+    assert len(ea) == 60 and np.max(np.abs(ea / np.array(eo) - 1.0)) < 1e-10
+    assert np.max(np.abs(ea / eb - 1.0)) < 1e-11
+    assert relerr(a.get_field_half(), b.get_field_half()) < 1e-11
+    fa, fb = a.get_field(), b.get_field()
+    for k in ("electric", "chargeden", "mode_re", "mode_im"):
+        assert relerr(fa[k], fb[k]) < 1e-11, k
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
+
+
+def test_fused_solve_with_output_steps(oracle_mod, amd, monkeypatch):
+    """the reference's driver loop with output fusion: the step before an output_all takes its diagnostics inside
+    k_step_full<DIAG> and needs its fields in memory -- the step before it must not leave its solve pending"""
+    kw = dict(nparticle_max=N, nx=1024, output_interval=0.35)
+    a, b = fused_pair(amd, monkeypatch, **kw)
+    outs = {id(a): [], id(b): []}
+    for e in (a, b):
+        e.set_output_fusion(True)
+        t = 0
+        for chunk in (7, 7, 1, 7, 14, 3):
+            e.step(chunk)
+            t += chunk
+            outs[id(e)].append((e.output_scalars(), e.ptcldist()))
+    assert a.kernel_stats(7)[1] > 20 and b.kernel_stats(7)[1] == 0
+    assert np.max(np.abs(a.energy_history() / b.energy_history() - 1.0)) < 1e-11
+    for (sa, da), (sb, db) in zip(outs[id(a)], outs[id(b)]):
+        assert relerr(sa, sb) < 1e-11
+        for k in da:
+            assert relerr(da[k], db[k]) < 1e-9, k

@@ -969,8 +969,11 @@ def test_lazy_call_sites_equal_eager_calls(amd, monkeypatch, name, kw, linear):
                 e.particle_optimize(irk)
                 e.interaction_collect_charge()
                 e.field_solve_electric()
-            assert relerr(b.get_field()["electric"], a.get_field()["electric"]) < 1e-10
-            b.set_electric(a.get_field()["electric"])
+            # (field_chargeden is left alone: between the sub-steps of a step whose half-step charge was predicted as six
+            # sums ASKING for it makes the library push and deposit the half-step state after all, see pic1dp_hip_get_field)
+            Ea = a.get_field(chargeden=False)["electric"]
+            assert relerr(b.get_field()["electric"], Ea) < 1e-10
+            b.set_electric(Ea)
         ga, gb = a.particles_download(), b.particles_download()
         for k in "xvw":
             assert np.array_equal(ga[k], gb[k]), (k, it)
@@ -1074,7 +1077,10 @@ def test_library_reports_the_bytes_its_kernels_move(amd, monkeypatch):
     assert run().kernel_bytes(6)["name"].startswith("k_step_sums")            # the large-grid kernel insisted on
     monkeypatch.delenv("PIC1DP_PRED_PRIVATE")
     monkeypatch.delenv("PIC1DP_PRED_KIND")
-    assert run(nx=1024).kernel_bytes(6)["name"].startswith("k_step_one<sums>")  # the library's choice from nx 512 up
+    assert run(nx=1024).kernel_bytes(6)["name"].startswith("k_step_one<sums>")  # the library's choice for one kept mode
+    monkeypatch.setenv("PIC1DP_PRED_KIND", "1")
+    assert run().kernel_bytes(6)["name"].startswith("k_step_one (")             # the tiles insisted on
+    monkeypatch.delenv("PIC1DP_PRED_KIND")
     assert run(nx=1024, nmode=2, modes=[1, 2]).kernel_bytes(6)["name"].startswith("k_step_one (")   # two kept modes: tiles
     eng = run()
     eng.interaction_push_particle(1)
