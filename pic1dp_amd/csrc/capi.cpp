@@ -101,9 +101,6 @@ struct pic1dp_ctx {
   double *d_rho_all = nullptr, *d_pred_all = nullptr;
   size_t rho_set_doubles = 0, pred_set_doubles = 0;
   int acc_idx = 0;
-  unsigned long long *d_sched = nullptr;  // counters of the one-pass kernels' dynamic chunk schedule (kernels.hpp ChunkSchedule)
-  unsigned long long sched_seq = 0;       // launches that have drawn from them
-  double dyn_frac = 0.0;                  // share of a launch's chunks that is drawn instead of dealt (PIC1DP_DYN_FRAC)
   int fuse_solve = 1;           // PIC1DP_FUSE_SOLVE=0: the field solve always in a launch of its own
   bool fused_pending = false;   // step(): the last marker launch left the solve of its step to the next launch's prologue
   int fused_dirty = -1;         // accumulator set the last fused launch read (still holding that step's deposits), or -1
@@ -709,9 +706,6 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMemsetAsync(c->d_rho_all, 0, sizeof(double) * 3 * rho_doubles, c->st));
   c->d_rho_sp = c->d_rho_all;
   if (const char *e = std::getenv("PIC1DP_FUSE_SOLVE")) c->fuse_solve = std::atoi(e) != 0;
-  if (const char *e = std::getenv("PIC1DP_DYN_FRAC")) c->dyn_frac = std::min(0.9, std::max(0.0, std::atof(e)));
-  HIP_TRY_C(hipMalloc(&c->d_sched, sizeof(unsigned long long) * 16 * SCHED_MAX_COUNTERS));
-  HIP_TRY_C(hipMemsetAsync(c->d_sched, 0, sizeof(unsigned long long) * 16 * SCHED_MAX_COUNTERS, c->st));
   for (int s = 0; s < ns; ++s) {
     Species &S = c->sp[s];
     S.nalloc = nalloc;
@@ -873,7 +867,6 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     if (c->xc.opened[q]) (void)hipIpcCloseMemHandle(c->xc.peer[q]);
   if (c->xc.local) (void)hipFree(c->xc.local);
   if (c->xc.err) (void)hipHostFree(c->xc.err);
-  (void)hipFree(c->d_sched);
   for (auto &S : c->sp) {
     (void)hipFree(S.slab[0]);
     (void)hipFree(S.slab[1]);
@@ -1673,19 +1666,6 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
         S.t2_version = c->state_version;
       }
       lc = pred_launch(c, S.np, priv, nullptr);
-      {  // which wave takes which 64 pairs (kernels.hpp ChunkSchedule): dealt round-robin, the last share drawn
-        const int64_t nchunks = ((S.np >> 1) + 63) / 64, waves = static_cast<int64_t>(lc.blocks) * (lc.threads / 64);
-        a.sched = ChunkSchedule{};
-        a.sched.nstatic = nchunks;
-        if (c->dyn_frac > 0.0 && nchunks >= 4 * waves) {  // (a launch of a few trips per wave has nothing to balance with)
-          a.sched.nstatic = static_cast<int64_t>(static_cast<double>(nchunks) * (1.0 - c->dyn_frac));
-          a.sched.ndynamic = nchunks - a.sched.nstatic;
-          a.sched.ncounters = std::min(SCHED_MAX_COUNTERS, lc.blocks);
-          a.sched.len = (a.sched.ndynamic + a.sched.ncounters - 1) / a.sched.ncounters;
-          a.sched.counters = c->d_sched;
-          a.sched.base = (++c->sched_seq) << 32;
-        }
-      }
     }
     if (diag) {  // one workgroup of 1024 threads per CU: grid tiles + histograms in its LDS
       const size_t ntot = dist_len(c->in);

@@ -163,23 +163,6 @@ struct FusedSolve {
   double *zero_pred;
 };
 
-// How the one-pass kernels split the markers among their waves.  A chunk = 64 consecutive marker pairs = one wave's
-// loads of one trip.  The first `nstatic` chunks go round-robin as a grid-stride loop would hand them out (wave g of W
-// takes g, g + W, ...): no coordination, but the kernel then ends with its slowest CU, and CUs -- whole XCDs -- differ
-// by +-5 % (profiles/r04/experiments/stamps_before.log: the CUs idle 4-7 % of the kernel at its end).  The remaining
-// chunks are DRAWN: `ncounters` counters (128 B apart), counter q owning chunks [nstatic + q len, + len); a wave
-// draws from the counter of its workgroup (blockIdx % ncounters: neighbouring counters belong to different XCDs)
-// with one device-scope fetch-add per chunk, and when that is exhausted looks at the next few.  Counters are never
-// reset: a launch raises them to its `base` (launch number << 32) on first touch.
-struct ChunkSchedule {
-  unsigned long long *counters;  // null / ncounters 0: everything static
-  unsigned long long base;
-  int64_t nstatic, len, ndynamic;
-  int ncounters;
-};
-constexpr int SCHED_MAX_COUNTERS = 64;
-constexpr int SCHED_NEIGHBOURS = 3;  // counters a wave looks at beyond its own
-
 // whole-time-step path: state updated in place, half-step state recomputed
 struct StepArgs {
   double *x, *v, *w;   // particle_x/v/w, updated in place by the full kernel
@@ -212,7 +195,6 @@ struct StepArgs {
                      // thread-private LDS slots (Eh staged from memory like k_step_one's)
   const double *eh_re, *eh_im;
   FusedSolve fused;  // pred_kind 2 only: the prologue solves the previous step's field (E0, Eh, eh_re / eh_im unused)
-  ChunkSchedule sched;  // one-pass kernels
 };
 constexpr int PRED_MAX_MODES = 2;
 // pred_kind 2: the six sums (padded to 8) are kept in this many copies -- workgroup b of the marker kernel adds into

@@ -502,86 +502,6 @@ __device__ __forceinline__ double pred_one_private(const One &n, double p, int i
   return t2;
 }
 
-// ---------------------------------------------------------------------------
-// Which chunk (64 marker pairs) a wave takes next (kernels.hpp ChunkSchedule): round-robin while the static part
-// lasts, then drawn from shared counters -- the waves of CUs that run ahead take more.  Everything here is
-// wave-uniform (scalar registers; lane 0 performs the memory operations).  -1: nothing left for this wave.
-// ---------------------------------------------------------------------------
-struct WaveSched {
-  int64_t next_static, waves;
-  int home, visited;
-  bool drawing, in_flight;
-  unsigned long long drawn;  // lane 0: what the fetch-add in flight on counter `home` returns
-};
-__device__ __forceinline__ unsigned long long wave_bcast(unsigned long long v) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
-  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
-  return (static_cast<unsigned long long>(hi) << 32) | lo;
-}
-__device__ __forceinline__ int64_t sched_len(const ChunkSchedule &cs, int q) {
-  const int64_t left = cs.ndynamic - static_cast<int64_t>(q) * cs.len;
-  return left < cs.len ? (left > 0 ? left : 0) : cs.len;
-}
-// one draw from counter w.home, not waited for: the next sched_next looks at what it returned.  A counter is raised to
-// the launch's base by every wave before its first draw from it (a max: whoever comes first does the raising)
-__device__ __forceinline__ void sched_draw(WaveSched &w, const ChunkSchedule &cs, bool first) {
-  if ((threadIdx.x & 63) == 0) {
-    unsigned long long *p = cs.counters + 16 * w.home;
-    if (first) __hip_atomic_fetch_max(p, cs.base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    w.drawn = __hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  w.in_flight = true;
-}
-__device__ __forceinline__ WaveSched sched_begin(const ChunkSchedule &cs) {
-  WaveSched w;
-  const int wpw = blockDim.x >> 6;
-  w.waves = static_cast<int64_t>(gridDim.x) * wpw;
-  w.next_static = static_cast<int64_t>(blockIdx.x) * wpw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  w.home = cs.ncounters > 0 ? static_cast<int>(blockIdx.x % cs.ncounters) : 0;
-  w.visited = 0;
-  w.drawing = w.in_flight = false;
-  w.drawn = 0;
-  return w;
-}
-__device__ __forceinline__ int64_t sched_next(WaveSched &w, const ChunkSchedule &cs) {
-  if (!w.drawing) {
-    const int64_t c = w.next_static;
-    w.next_static += w.waves;
-    if (c < cs.nstatic) {
-      // the last dealt chunk: the first draw travels while it is being worked on
-      if (w.next_static >= cs.nstatic && cs.ncounters > 0 && sched_len(cs, w.home) > 0) sched_draw(w, cs, true);
-      return c;
-    }
-    w.drawing = true;
-  }
-  if (cs.ncounters <= 0) return -1;
-  const bool lane0 = (threadIdx.x & 63) == 0;
-  while (w.visited <= SCHED_NEIGHBOURS && w.visited < cs.ncounters) {
-    const int64_t len = sched_len(cs, w.home);
-    if (w.in_flight) {
-      w.in_flight = false;
-      const int64_t idx = static_cast<int64_t>(wave_bcast(w.drawn) - cs.base);
-      if (idx < len) {
-        sched_draw(w, cs, false);  // the next one, while this chunk is being worked on
-        return cs.nstatic + static_cast<int64_t>(w.home) * cs.len + idx;
-      }
-    } else if (len > 0) {
-      // a counter this wave has not drawn from yet: a look first -- an exhausted counter then costs a load, not an
-      // atomic that queues behind those of the waves still drawing from it
-      unsigned long long v = 0;
-      if (lane0) v = __hip_atomic_load(cs.counters + 16 * w.home, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v = wave_bcast(v);
-      if (v < cs.base || static_cast<int64_t>(v - cs.base) < len) {
-        sched_draw(w, cs, true);
-        continue;
-      }
-    }
-    w.home = w.home + 1 == cs.ncounters ? 0 : w.home + 1;
-    w.visited++;
-  }
-  return -1;
-}
-
 // T2: 0 no carry of -f0'/f0; 1 this step evaluates it, the next step's value is stored; 2 this
 // step's value is loaded (stored by the previous k_step_one), the next step's stored
 // NM: kept modes of the prediction tiles (1, 2); PRIV (NM = 1): six sums in thread-private slots instead
@@ -635,15 +555,13 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   constexpr bool CARRY_IN = (T2 == 2) && HAS_W;
   constexpr bool CARRY_OUT = (T2 != 0) && HAS_W;
   const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   double2 *x2 = reinterpret_cast<double2 *>(a.x);
   double2 *v2 = reinterpret_cast<double2 *>(a.v);
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   double2 *t2 = reinterpret_cast<double2 *>(a.t2);
-  WaveSched ws = sched_begin(a.sched);
-  for (int64_t ch = sched_next(ws, a.sched); ch >= 0; ch = sched_next(ws, a.sched)) {
-    const int64_t j = ch * 64 + (threadIdx.x & 63);
-    if (j >= npair) continue;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
     const int64_t o = tidx2(j);
     const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);
@@ -836,15 +754,13 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   constexpr bool CARRY_OUT = (T2 != 0) && HAS_W;
   PredSums ks;
   const int64_t npair = a.np >> 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   double2 *x2 = reinterpret_cast<double2 *>(a.x);
   double2 *v2 = reinterpret_cast<double2 *>(a.v);
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   double2 *t2 = reinterpret_cast<double2 *>(a.t2);
-  WaveSched ws = sched_begin(a.sched);
-  for (int64_t ch = sched_next(ws, a.sched); ch >= 0; ch = sched_next(ws, a.sched)) {
-    const int64_t j = ch * 64 + (threadIdx.x & 63);
-    if (j >= npair) continue;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
     const int64_t o = tidx2(j);
     const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);

@@ -27,7 +27,6 @@ struct StepArgsDev {
   const double *eh_re, *eh_im;  // k_step_sums: the kept mode of Eh
   double snx, pred_k;           // k_step_one's prediction: nx / lx, and dt/2 Z/m
   FusedSolve fused;             // kernels.hpp: the prologue solves the previous step's field
-  ChunkSchedule sched;          // kernels.hpp: which wave takes which 64 marker pairs (k_step_one, k_step_sums)
 #ifdef PIC1DP_TUNE_STAMPS  // tuning build (tools/stamp_probe.sh): [gridDim][8] wall-clock stamps of the phases of a workgroup
   unsigned long long *stamps;
 #endif
