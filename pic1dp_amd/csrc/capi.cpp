@@ -101,7 +101,7 @@ struct pic1dp_ctx {
   double *d_rho_all = nullptr, *d_pred_all = nullptr;
   size_t rho_set_doubles = 0, pred_set_doubles = 0;
   int acc_idx = 0;
-  int fuse_solve = 1;           // PIC1DP_FUSE_SOLVE=0: the field solve always in a launch of its own
+  int fuse_solve = 1;           // PIC1DP_FUSE_SOLVE=0: the field solve always in a launch of its own; 2: fused whatever the grid
   bool fused_pending = false;   // step(): the last marker launch left the solve of its step to the next launch's prologue
   int fused_dirty = -1;         // accumulator set the last fused launch read (still holding that step's deposits), or -1
   FusedSolve fuse_args{};       // what the next marker launch's prologue has to solve (on = 1), consumed by step_particles
@@ -705,7 +705,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMalloc(&c->d_rho_all, sizeof(double) * 3 * rho_doubles));
   HIP_TRY_C(hipMemsetAsync(c->d_rho_all, 0, sizeof(double) * 3 * rho_doubles, c->st));
   c->d_rho_sp = c->d_rho_all;
-  if (const char *e = std::getenv("PIC1DP_FUSE_SOLVE")) c->fuse_solve = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PIC1DP_FUSE_SOLVE")) c->fuse_solve = std::max(0, std::min(2, std::atoi(e)));
   for (int s = 0; s < ns; ++s) {
     Species &S = c->sp[s];
     S.nalloc = nalloc;
@@ -1532,6 +1532,12 @@ static bool fuse_capable(const pic1dp_ctx *c) {
   if (!(c->fuse_solve && !multi && c->pred_kind == 2 && c->in.nmode == 1 && c->field_solver == 0 && c->fa.npe <= 32 &&
         predict_capable(c)))
     return false;
+  // ... and serial forward sums that are short.  The solve costs inside a marker launch what it costs in its own: a
+  // row of dependent round trips and the chain in the reference's order (12 cycles a term at the marker kernel's
+  // clock).  With a chain of 1024 terms the launch it saves is level or slightly behind (1.25e7 markers / nx 1024:
+  // 0.1471 against 0.1460 ms per step); with 192 terms it is 1 % ahead at 6.4e6 markers and 11 % at 2e5
+  // (profiles/r04/experiments/ab_fused_solve.log, ab_small_knobs.log).  PIC1DP_FUSE_SOLVE=2 fuses whatever the length.
+  if (c->fuse_solve != 2 && c->in.nx / std::max(1, c->fa.npe) > 512) return false;
   const bool priv = c->pred_private && c->threads_req <= 0;
   for (int s = 0; s < c->in.nspecies; ++s) {
     if (c->sp[s].np <= 0) continue;
