@@ -772,7 +772,12 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     // one pass per step: with prediction tiles where they fit the LDS (k_step_one), as six sums for larger
     // grids with one kept mode (k_step_sums); PIC1DP_PRED_KIND=1|2 insists on one of them (tests)
     const bool private_fits = 2 * (step_one_private_lds_bytes(nx, c->grid.rcopies) + kStaticLds) <= kCuLds;
-    if (nm <= PRED_MAX_MODES && step_one_lds_bytes(nx, c->grid.rcopies, nm) <= PARTICLE_LDS_CAP)
+    // The prediction tiles cost 2 + 4 nm LDS atomics at random cells per marker.  Measured against the two passes
+    // (profiles/r04/experiments/ab_kept_modes.log, 1e8 markers / nx 1024, ms per step): two kept modes 1.23 against 1.46,
+    // three 1.49 against 1.45, four 2.05 (nx 512) against 1.46 -- so the tiles are the default up to two kept modes,
+    // and for three and four only when PIC1DP_PRED_KIND=1 asks for the one pass by name (k_step_one is built for them).
+    constexpr int kPredDefaultModes = 2;
+    if (nm <= kPredDefaultModes && step_one_lds_bytes(nx, c->grid.rcopies, nm) <= PARTICLE_LDS_CAP)
       c->pred_kind = 1;
     // (the six sums travel in the head of an nx-vector on the call-site path: nx >= 8)
     else if (nm == 1 && nx >= 8 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP)
@@ -1665,7 +1670,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       // traffic cost: measured (profiles/r03/experiments/ab_one_exp.log), PIC1DP_CARRY=1 / 0 insists either way.
       const bool exp_bearing = c->in.deltaf && (c->in.iptcldist == 2 || c->in.iptcldist == 3);
       const bool carry_one = c->carry < 0 ? (S.sc.one_exp ? kCarryOneExpDefault : true) : c->carry > 0;
-      if (exp_bearing && carry_one) {
+      if (exp_bearing && carry_one && (c->pred_kind == 2 || c->in.nmode <= 2)) {  // (the tiles of 3, 4 modes: built without the carry)
         if (!S.t2) HIP_TRY(hipMalloc(&S.t2, sizeof(double) * static_cast<size_t>(S.nalloc + 2)));
         a.t2 = S.t2;
         a.t2_mode = S.t2_version == read_version ? 2 : 1;

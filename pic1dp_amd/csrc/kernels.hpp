@@ -196,7 +196,7 @@ struct StepArgs {
   const double *eh_re, *eh_im;
   FusedSolve fused;  // pred_kind 2 only: the prologue solves the previous step's field (E0, Eh, eh_re / eh_im unused)
 };
-constexpr int PRED_MAX_MODES = 2;
+constexpr int PRED_MAX_MODES = 4;  // kept modes k_step_one's prediction tiles are instantiated for (1 .. 4)
 // pred_kind 2: the six sums (padded to 8) are kept in this many copies -- workgroup b of the marker kernel adds into
 // copy b % PRED_SUM_COPIES, the field kernels add the copies up: six addresses shared by all workgroups serialise
 constexpr int PRED_SUM_COPIES = 16;
@@ -251,7 +251,7 @@ struct XchgArgs {
   int vstride;                                 // doubles per (parity, rank) slot: XCHG_MAX_VEC * nx
 };
 // vectors of nx doubles one exchange can carry: charge2 + the 1 + 2 * PRED_MAX_MODES prediction slices
-constexpr int XCHG_MAX_VEC = 6;
+constexpr int XCHG_MAX_VEC = 2 + 2 * PRED_MAX_MODES;
 // both fields of a one-pass step in one launch: the new state's field from its deposited charge, then the
 // NEXT step's half-step field from k_step_one's prediction (x1: the ONE exchange of a multi-rank step -- charge2
 // and the Z-weighted prediction slices travel together --, or null)

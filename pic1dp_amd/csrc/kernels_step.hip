@@ -504,7 +504,7 @@ __device__ __forceinline__ double pred_one_private(const One &n, double p, int i
 
 // T2: 0 no carry of -f0'/f0; 1 this step evaluates it, the next step's value is stored; 2 this
 // step's value is loaded (stored by the previous k_step_one), the next step's stored
-// NM: kept modes of the prediction tiles (1, 2); PRIV (NM = 1): six sums in thread-private slots instead
+// NM: kept modes of the prediction tiles (1 .. 4); PRIV (NM = 1): six sums in thread-private slots instead
 template <int DIST, int MODE, int POW2, bool NT, int T2, int NM, bool PRIV = false, bool FUSED = false>
 __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
   static_assert(!FUSED || PRIV, "the fused solve serves the six-sum prediction");
@@ -865,10 +865,15 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d0, const LaunchCfg &lc
   return hipGetLastError();
 }
 
-static_assert(PRED_MAX_MODES == 2, "k_step_one is instantiated for one and two kept modes");
+static_assert(PRED_MAX_MODES == 4, "k_step_one is instantiated for one to four kept modes");
 static_assert(PRIV_THREADS == STEP_PRIVATE_THREADS, "slot stride of k_step_one<PRIV> = its workgroup size");
 template <int DIST, int MODE, int POW2, int NM>
 hipError_t launch_step_one(const StepArgsDev &d, int t2m, const LaunchCfg &lc, hipStream_t st) {
+  if constexpr (NM > 2) {  // three and four kept modes (on request: two passes measure faster): without the carry
+    if (t2m != 0) return hipErrorInvalidValue;
+    return d.nt ? launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, NM>, d, lc, st)
+                : launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, NM>, d, lc, st);
+  }
   if (d.nt) {
     if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, NM>, d, lc, st);
     if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, NM>, d, lc, st);
@@ -927,6 +932,8 @@ hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc,
     const int t2m = d.t2 ? d.t2_mode : 0;
     if (d.pred_nm == 1) return launch_step_one<DIST, MODE, POW2, 1>(d, t2m, lc, st);
     if (d.pred_nm == 2) return launch_step_one<DIST, MODE, POW2, 2>(d, t2m, lc, st);
+    if (d.pred_nm == 3) return launch_step_one<DIST, MODE, POW2, 3>(d, t2m, lc, st);
+    if (d.pred_nm == 4) return launch_step_one<DIST, MODE, POW2, 4>(d, t2m, lc, st);
     return hipErrorInvalidValue;  // PRED_MAX_MODES
   }
   if (full && d.dist_out)  // with the diagnostics of output_all

@@ -306,7 +306,10 @@ def test_prediction_is_dropped_when_it_no_longer_applies(amd, monkeypatch, kind)
 
 @pytest.mark.parametrize("kw,predicted", [
     (dict(nmode=2, modes=[1, 3], init_nmode=2, init_mode=[1, 3], init_mode_cos=[0.0, 2e-6], init_mode_sin=[1e-5, 0.0]), True),
-    (dict(nmode=3, modes=[1, 2, 5]), False),                    # more kept modes than the tiles hold: two passes
+    (dict(nmode=3, modes=[1, 2, 5], init_nmode=3, init_mode=[1, 2, 5], init_mode_cos=[0.0, 2e-6, 1e-6],
+          init_mode_sin=[1e-5, 0.0, 3e-6]), True),              # three and four kept modes: tiles too (round 4)
+    (dict(nmode=4, modes=[1, 2, 3, 7], init_nmode=2, init_mode=[1, 7], init_mode_cos=[0.0, 2e-6], init_mode_sin=[1e-5, 0.0]), True),
+    (dict(nmode=5, modes=[1, 2, 3, 4, 5]), False),              # more kept modes than the tiles are built for: two passes
     (dict(nspecies=2, iptcldist=0, species_charge=[-1.0, 1.0], species_mass=[1.0, 25.0], species_temperature=[1.0, 0.5],
           species_temperature2=[1.0, 1.0], species_density=[1.0, 1.0], species_v0=[0.0, 0.0], lx=4 * np.pi), True),
     (dict(nx=4096), True),                                      # eight tiles of 32 KiB do not fit the LDS: six sums
@@ -316,12 +319,13 @@ def test_prediction_is_dropped_when_it_no_longer_applies(amd, monkeypatch, kind)
           species_temperature2=[1.0, 1.0], species_density=[1.0, 1.0], species_v0=[0.0, 0.0], lx=4 * np.pi), True),
     (dict(nx=33), True),                                        # odd grid: guard cell and tile padding
     (dict(nparticle_max=N + 1, species_nparticle_init=[N - 7]), True)],
-    ids=["two_modes", "three_modes_fall_back", "two_species", "nx4096_sums", "nx4096_two_modes_fall_back", "nx4096_full_f", "nx4096_two_species", "odd_nx", "even_count_tail_slots"])
+    ids=["two_modes", "three_modes", "four_modes", "five_modes_fall_back", "two_species", "nx4096_sums", "nx4096_two_modes_fall_back", "nx4096_full_f", "nx4096_two_species", "odd_nx", "even_count_tail_slots"])
 @pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
 def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind):
     kw = dict(dict(nparticle_max=N, nx=96), **kw)
-    if kind == 2 and kw.get("nmode", 1) == 2 and kw["nx"] < 4096:
-        pytest.skip("two kept modes: the tiles' case")
+    if kind == 2 and kw.get("nmode", 1) in (2, 3, 4) and kw["nx"] < 4096:
+        pytest.skip("two to four kept modes: the tiles' case")
+    # (three and four kept modes: one pass when PIC1DP_PRED_KIND=1 asks for it -- `kind` does here; by default two passes)
     a = engine(amd, monkeypatch, True, kind, **kw)
     assert a.predict_kind() == (0 if not predicted else 2 if (kind == 2 or kw["nx"] == 4096) else 1)
     b = engine(amd, monkeypatch, False, **kw)
@@ -340,13 +344,15 @@ def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind)
 @pytest.mark.parametrize("kw,kind", [
     (dict(nx=2542), 1), (dict(nx=2543), 2),                                   # the last grid the tiles hold, the first for the sums
     (dict(nx=1694, nmode=2, modes=[1, 3]), 1), (dict(nx=1695, nmode=2, modes=[1, 3]), 0),
+    (dict(nx=1016, nmode=4, modes=[1, 2, 3, 5]), 1), (dict(nx=1017, nmode=4, modes=[1, 2, 3, 5]), 0),
     (dict(nx=5063), 2), (dict(nx=5064), 0)],                                  # the last grid for the sums, then two passes
-    ids=["tiles_last", "sums_first", "two_modes_last", "two_modes_beyond", "sums_last", "beyond"])
+    ids=["tiles_last", "sums_first", "two_modes_last", "two_modes_beyond", "four_modes_last", "four_modes_beyond", "sums_last",
+         "beyond"])
 def test_one_pass_at_the_lds_limits(amd, monkeypatch, kw, kind):
     """the grids at which the one-pass kernels' LDS tiles just fit and just do not (kernels.hpp step_one_lds_bytes,
     step_sums_lds_bytes against PARTICLE_LDS_CAP): the choice, and the run against the two-pass engine"""
     kw = dict(kw, nparticle_max=N)
-    a = engine(amd, monkeypatch, True, **kw)
+    a = engine(amd, monkeypatch, True, 1 if kw.get("nmode", 1) > 2 else None, **kw)   # (3, 4 kept modes: on request)
     assert a.predict_kind() == kind
     b = engine(amd, monkeypatch, False, **kw)
     a.step(5)
@@ -526,3 +532,42 @@ def test_fused_solve_with_output_steps(oracle_mod, amd, monkeypatch):
         assert relerr(sa, sb) < 1e-11
         for k in da:
             assert relerr(da[k], db[k]) < 1e-9, k
+
+
+@pytest.mark.parametrize("modes", [[1, 2, 3], [1, 2, 3, 5]], ids=["three_modes", "four_modes"])
+@pytest.mark.parametrize("mname,mkw", MODES, ids=[m[0] for m in MODES])
+def test_one_pass_three_and_four_kept_modes_against_oracle(oracle_mod, amd, monkeypatch, modes, mname, mkw):
+    """the reference allows any input_nmode (src/pic1dp_input.F90:75-80); with three and four kept
+    modes the step can still be ONE pass over the markers (prediction tiles R0, RA_m, RB_m per kept mode,
+    src/pic1dp_field.F90:231-257; PIC1DP_PRED_KIND=1 -- the two passes stay the default there, they measure faster:
+    profiles/r04/experiments/ab_kept_modes.log) -- against the oracle directly: field energy at every one of 80 steps within 1e-10,
+    every kept mode's amplitude and the markers at the end"""
+    nm = len(modes)
+    kw = dict(nparticle_max=N, nx=128, nmode=nm, modes=modes, init_nmode=nm, init_mode=modes,
+              init_mode_cos=[0.0, 2e-6, 1e-6, 5e-7][:nm], init_mode_sin=[1e-5, 3e-6, 0.0, 2e-6][:nm], **mkw)
+    if mkw.get("deltaf") == 0:
+        kw.update(iptcldist=0, species_density=[1.0], species_v0=[0.0])
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    eng = engine(amd, monkeypatch, True, **kw)
+    assert eng.predict_kind() == 0           # the library's own choice: two passes measure faster from three kept modes on
+    eng = engine(amd, monkeypatch, True, 1, **kw)
+    assert eng.predict_kind() == 1           # ... the one pass on request
+    eng.kernel_stats_enable(True)
+    nsteps = 80
+    eo = []
+    for _ in range(nsteps):
+        sim.step(1)
+        eo.append(sim.field_energy())
+    eng.step(nsteps)
+    assert np.max(np.abs(eng.energy_history() / np.array(eo) - 1.0)) < 1e-10
+    assert eng.kernel_stats(3)[1] == 1 and eng.kernel_stats(6)[1] == nsteps and eng.kernel_stats(4)[1] == 0
+    f = eng.get_field()
+    so = sim.get_field()
+    assert relerr(f["electric"], so[0]) < 1e-10
+    g = eng.particles_download()
+    assert np.max(np.abs(g["x"] - sim.gather("x"))) < 1e-9 and np.max(np.abs(g["v"] - sim.gather("v"))) < 1e-9
+    if kw.get("deltaf", 1):
+        assert np.max(np.abs(g["w"] - sim.gather("w"))) < 1e-9 * max(1.0, np.max(np.abs(sim.gather("w"))))
