@@ -28,12 +28,13 @@ STEP_DISTS = (0, 1, 2, 3, 4, 5)
 PRODUCT_UNITS = [("kernels_step.hip", ["-DPIC1DP_STEP_DIST=%d" % d], "kernels_step_d%d" % d) for d in STEP_DISTS] + [
     ("kernels_push.hip", [], "kernels_push"), ("kernels_field.hip", [], "kernels_field"),
     ("kernels_diag.hip", [], "kernels_diag"), ("step_dispatch.cpp", [], "step_dispatch"),
-    ("capi.cpp", [], "capi"), ("loader.cpp", [], "loader"), ("multirand.cpp", [], "multirand"),
+    ("capi.cpp", [], "capi"), ("capi_comm.cpp", [], "capi_comm"), ("capi_diag.cpp", [], "capi_diag"),
+    ("capi_optimize.cpp", [], "capi_optimize"), ("loader.cpp", [], "loader"), ("multirand.cpp", [], "multirand"),
     ("optimize.cpp", [], "optimize"), ("species.cpp", [], "species"), ("hostcheck.cpp", [], "hostcheck")]
 PROBE_UNITS = [("probe.hip", [], "probe")]
 PROBE_SHARED = ["species", "hostcheck"]      # objects of the product the probe library links as well
 HEADERS = ["kernels.hpp", "device_math.hpp", "device_field.hpp", "device_diag.hpp", "step_args.hpp", "check_values.hpp", "loader.hpp",
-           "multirand.hpp", "optimize.hpp", "rccl_dyn.hpp",
+           "multirand.hpp", "optimize.hpp", "rccl_dyn.hpp", "ctx.hpp",
            os.path.join("..", "..", "include", "pic1dp_hip.h"), os.path.join("..", "..", "include", "pic1dp_probe.h")]
 
 # -ffp-contract=off : products and sums round separately, like the reference's

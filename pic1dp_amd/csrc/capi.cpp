@@ -1,30 +1,12 @@
-// capi.cpp -- context, sequencing and the C ABI of include/pic1dp_hip.h.
+// capi.cpp -- context, transfers, the hot path's sequencing and the state machine of the lazy call sites behind the
+// C ABI of include/pic1dp_hip.h (the other units: ctx.hpp).
 //
 // One context = one process = one GPU = one HIP stream.  Every compute entry
 // point only enqueues kernels (and at most one RCCL all-reduce) on that stream;
 // nothing in the time loop synchronises with the host.
-#include <hip/hip_runtime.h>
+#include "ctx.hpp"
 
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <thread>
-#include <utility>
-#include <vector>
-
-#include "../../include/pic1dp_hip.h"
-#include "kernels.hpp"
-#include "loader.hpp"
-#include "multirand.hpp"
-#include "optimize.hpp"
-#include "rccl_dyn.hpp"
-
-using namespace pic1dp;
-
-namespace {
+namespace pic1dp_host {
 
 thread_local std::string g_err;
 
@@ -38,223 +20,9 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
-#define HIP_TRY(expr)                                                                     \
-  do {                                                                                    \
-    hipError_t e_ = (expr);                                                               \
-    if (e_ != hipSuccess)                                                                 \
-      return fail(PIC1DP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                  __FILE__, __LINE__);                                                    \
-  } while (0)
-
-#define CHECK_CTX(c) \
-  if (!(c)) return fail(PIC1DP_ERR_ARG, "null context")
-
-constexpr double kPi = 3.14159265358979323846264;        // PETSC_PI
-constexpr double kSqrtEps = 1.490116119384766e-08;       // PETSC_SQRT_MACHINE_EPSILON
-constexpr int kTagFused = 100, kTagPush = 101, kTagDeposit = 102, kTagStepHalf = 103, kTagStepFull = 104, kTagStepOne = 106,
-              kNumTags = 128;
-constexpr int64_t kHistCap = 1 << 20;
-constexpr bool kCarryOneExpDefault = false;  // k_step_one with the one-exp form of -f0'/f0: carry it (72 B) or evaluate it again (56 B)
-constexpr int kEnergyBlocks = 1024;
-constexpr size_t kCuLds = 160 * 1024, kStaticLds = 1024;  // LDS of a CU; static LDS of a marker kernel (the exp table)
-// states of the lazy call sites (pic1dp_ctx::lz)
-enum { LZ_CLEAN = 0, LZ_PUSH1, LZ_HALF, LZ_PUSH2 };
-
-struct Species {
-  int64_t nalloc = 0, np = 0;
-  PSet set[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  double *p = nullptr;
-  double *t2 = nullptr;   // carry of -f0'/f0 between the whole-step kernels
-  uint64_t t2_version = 0;  // state_version whose step-start velocities the values in t2 belong to (0: none)
-  double *slab[2] = {nullptr, nullptr};  // tiled storage of set 0 (+ p) and of the RK ping-pong set (kernels.hpp)
-  double *rho = nullptr;  // slice of rho_sp
-  SpeciesConst sc{};
-};
-
-struct EvPair {
-  hipEvent_t a, b;
-  int tag;
-};
-
-}  // namespace
-
-struct pic1dp_ctx {
-  pic1dp_input in{};
-  pic1dp_layout lay{};
-  int device = 0, num_cu = 256;
-  hipStream_t st = nullptr;
-  int cur = 0;  // which particle set is particle_x/v/w right now
-  std::vector<Species> sp;
-  int blk0 = 0, nblk = 1;  // owned reference blocks [blk0, blk0+nblk)
-  std::vector<int64_t> blk_alloc;                 // [nblk] allocated slots of each owned block
-  std::vector<std::vector<int64_t>> blk_np;       // [nspecies][nblk] valid markers
-  std::vector<Multirand> blk_rng;                 // [nblk] generators as particle_load left them
-  bool rng_ready = false;
-  int imerge = 0, iremove = 0, isplit = 0;        // particle_imerge / _iremove / _isplit
-  bool loaded = false;
-  bool charge_pending = false;  // charge_local ran, waiting for charge_reduced
-  // field
-  double *d_rho_sp = nullptr, *d_charge = nullptr, *d_chargeden = nullptr, *d_E = nullptr;
-  // The species accumulators and the six sums of the prediction exist three times (kernels.hpp FusedSolve): d_rho_sp /
-  // Species::rho / fa.rho_sp / d_pred always name the set the marker kernels deposit into NOW (acc_idx); all sets are
-  // zero whenever no fused launch sequence is under way
-  double *d_rho_all = nullptr, *d_pred_all = nullptr;
-  size_t rho_set_doubles = 0, pred_set_doubles = 0;
-  int acc_idx = 0;
-  int fuse_solve = 1;           // PIC1DP_FUSE_SOLVE=0: the field solve always in a launch of its own; 2: fused whatever the grid
-  bool fused_pending = false;   // step(): the last marker launch left the solve of its step to the next launch's prologue
-  int fused_dirty = -1;         // accumulator set the last fused launch read (still holding that step's deposits), or -1
-  FusedSolve fuse_args{};       // what the next marker launch's prologue has to solve (on = 1), consumed by step_particles
-  double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
-  double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
-  // one pass per step (kernels_step.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
-  // prediction accumulators [nspecies][1 + 2 nm][nx], the combined half-step charge density
-  double *d_tabA = nullptr, *d_tabB = nullptr, *d_pred = nullptr, *d_cd_h = nullptr, *d_mode_h = nullptr;
-  int pair_plain = 0;              // PIC1DP_PAIR_PLAIN
-  int osub_req = 0;                // PIC1DP_OSUB: grid size of the marker kernels in units of the resident one (0: auto)
-  int pred_kind = 0;               // 0 no one-pass step here, 1 prediction tiles (k_step_one), 2 six sums (k_step_sums)
-  int pred_private = 0;            // pred_kind 2 and E0, Eh, the table tiles and the private sums of two workgroups fit a
-                                   // CU's LDS: the sums are taken by k_step_one<PRIV> (thread-private LDS slots)
-  PredTab pred_tab{};              // kind 2: sums / Gram matrix of the kept mode's tables (host, libm)
-  int eh_modes = 0;                // kind 2: where the kept mode of the Eh about to be used lies: 0 nowhere, 1 fa.mode_*, 2 d_mode_h
-  bool charge_pending_pred = false;  // kind 2: charge_local handed out the six sums, not a charge vector
-  double *d_Ehn = nullptr;         // half-step field predicted for the NEXT step (d_Eh stays the last step's)
-  double *d_pack = nullptr;        // [2 + 2 nmode][nx] one all-reduce per one-pass step (RCCL path)
-  int predict = 1;                 // PIC1DP_PREDICT=0: always two passes per step
-  uint64_t pred_version = 0;       // state_version the accumulators in d_pred belong to (0: none)
-  uint64_t eh_version = 0;         // state_version d_Eh has been predicted for (step() path)
-  uint64_t field_version = 1, eh_field_version = 0, modes_field_version = 0;  // who wrote d_E last
-  double *d_stage = nullptr;  // contiguous staging buffer between host arrays and the tiled marker arrays
-  double *d_Eh = nullptr;  // field after the first sub-step of the last whole-step call
-  // The reference's three call sites at whole-step cost (see "lazy call sites"
-  // below): a push is only noted; the collect_charge that follows runs the
-  // whole-step kernel instead of push + deposit.
-  int lazy_calls = 1;            // PIC1DP_LAZY_CALLS=0: every call launches its own kernel at once
-  // collect_charge leaves its last step to the solve_field that follows (one launch less per sub-step):
-  // 0 field_chargeden is current; 1 d_charge holds the summed charge1, its scaling is pending; 2 (one rank) the
-  // species accumulators hold the deposits, species sum and scaling pending; 3 (one rank, mode-filter solve, few
-  // modes) k_step_one's prediction accumulators hold the charge, combination with the kept modes, species sum and
-  // scaling pending; 4 (one rank, mode-filter solve) the six sums of the prediction are pending: the kept mode's
-  // content of chargeden follows from them.  materialize_cd() before anything else looks at charge, chargeden or the
-  // accumulators.
-  int cd_lazy = 0;
-  // field_chargeden holds only the kept mode's content of the half-step charge density (collect_charge after a
-  // noted push(1) served from the six sums, pred_kind 2): all solve_field looks at, but not what the reference
-  // holds there.  get_field rebuilds the full vector on one rank (rebuild_half_step_chargeden); cleared by
-  // everything that writes field_chargeden.
-  bool cd_kept_mode_only = false;
-  int lz = 0;                    // LZ_CLEAN / LZ_PUSH1 / LZ_HALF / LZ_PUSH2
-  double *d_E0 = nullptr;        // field the noted push(1) saw
-  double *d_rho_dummy = nullptr; // accumulator of a wrap-only deposit
-  int carry = -1;          // whole-step kernels carry -f0'/f0 between them: -1 where measured to pay, 0 never
-                           // (PIC1DP_CARRY=0), 1 wherever -f0'/f0 bears an exp, 2 also two-stream2 between k_step_half / _full
-  int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
-  int field_solver = 0;    // 0 the reference's mode-filter DFT solve, 1 finite-difference tridiagonal (opt-in)
-  // marker state (bytes) above which k_step_half / k_step_full stream non-temporally
-  // The two kernels leave the caches to each other, so the pairs were compared inside
-  // one process on the same arrays (tools/ab_nt.py, nx = 1024, half + full in ms):
-  //   markers   plain/plain   nt/nt    half nt, full plain   half plain, full nt
-  //   6.4e6       0.102*      0.114         0.105                 0.106
-  //   1e7         0.159       0.169         0.158*                0.158*
-  //   2e7         0.372       0.332         0.326                 0.319*
-  //   3e7         0.539       0.497         0.492                 0.483*
-  //   5e7         0.886       0.829*        0.835                 0.828*
-  //   1e8         1.745       1.657*        1.676                 1.678
-  // => both plain below 288 MiB of marker state, the full kernel non-temporal above
-  //    it, the half kernel only above 2 GiB
-  double nt_threshold_half = 2048.0 * 1048576.0, nt_threshold_full = 288.0 * 1048576.0;
-  int64_t hist_count = 0;
-  // marker diagnostics of output_all: one fused pass per species (histograms +
-  // kinetic sums), kept until the markers change
-  uint64_t state_version = 1;              // bumped by everything that writes marker arrays
-  std::vector<uint64_t> diag_version;      // [nspecies] version the cached results belong to
-  std::vector<double> diag_sums;           // [nspecies][3]
-  double *d_diag_part = nullptr;           // [nspecies][3 * diag_max_blocks] per-workgroup partial sums of the pass
-  std::vector<char> diag_pending;          // [nspecies] a pass ran, its partial sums are still on the device
-  std::vector<int> diag_blocks;            // [nspecies] workgroups of that pass
-  int fuse_output = 0;                     // take the diagnostics inside k_step_full on steps output_all follows
-  int64_t diag_passes = 0;                 // separate k_ptcldist passes launched so far
-  int64_t fused_solves = 0;                // marker launches whose prologue solved the previous step's field
-  int32_t itime = 0;
-  double time = 0.0;
-  GridConst grid{};
-  FieldArgs fa{};
-  // comm
-  ncclComm_t comm = nullptr;
-  // one-hop charge exchange (kernels_field.hip exchange_charge): the own area, the peers'
-  // areas as mapped through hipIpc, and the running exchange number
-  struct Xchg {
-    void *local = nullptr;                       // flags + slots of this rank
-    void *peer[XCHG_MAX_RANKS] = {nullptr};      // every rank's area as mapped here (own: local)
-    bool opened[XCHG_MAX_RANKS] = {false};       // peer[q] came from hipIpcOpenMemHandle
-    unsigned long long *err = nullptr;           // pinned host word the kernel reports a time-out in
-    unsigned long long epoch = 0;
-    long long timeout_ticks = 0;
-    bool connected = false;
-    int memkind = 0;                             // 1 fine-grained, 2 uncached, 3 plain hipMalloc
-  } xc;
-  int allreduce_kind = 0;  // 0 auto (RCCL when a communicator exists), 1 RCCL, 2 one-hop exchange
-  // launch
-  int threads_req = 0, bpc_req = 0;
-  // timing
-  bool timers_on = false, stats_on = false;
-  std::vector<EvPair> evpool;
-  size_t ev_used = 0;
-  double acc_ms[kNumTags] = {0};
-  int64_t acc_n[kNumTags] = {0};
-  // what the marker kernel launched last under a tag moves per marker (pic1dp_hip_kernel_bytes)
-  struct KernelBytes {
-    double rd = 0.0, wr = 0.0, carry = 0.0;
-    char name[64] = {0};
-  } kbytes[kNumTags];
-};
+}  // namespace pic1dp_host
 
 namespace {
-
-int ev_resolve(pic1dp_ctx *c) {
-  if (c->ev_used == 0) return 0;
-  HIP_TRY(hipStreamSynchronize(c->st));
-  for (size_t i = 0; i < c->ev_used; ++i) {
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, c->evpool[i].a, c->evpool[i].b));
-    c->acc_ms[c->evpool[i].tag] += ms;
-    c->acc_n[c->evpool[i].tag] += 1;
-  }
-  c->ev_used = 0;
-  return 0;
-}
-
-// bracket helper: records a start event on construction (if enabled) and the
-// stop event in end(); pairs are resolved to milliseconds lazily (ev_resolve)
-struct Span {
-  pic1dp_ctx *c;
-  long idx = -1;
-  int rc = 0;
-  Span(pic1dp_ctx *c_, int tag, bool on) : c(c_) {
-    if (!on) return;
-    if (c->ev_used == c->evpool.size() && c->evpool.size() >= (1u << 16)) {
-      // a long run that reads its timers only at the end: fold what has been recorded into
-      // the accumulators (one stream synchronisation per 65 536 spans) and reuse the pool
-      if ((rc = ev_resolve(c)) != 0) return;
-    }
-    if (c->ev_used == c->evpool.size()) {
-      EvPair p{};
-      if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
-        rc = fail(PIC1DP_ERR_HIP, "hipEventCreate failed");
-        return;
-      }
-      c->evpool.push_back(p);
-    }
-    idx = static_cast<long>(c->ev_used++);
-    c->evpool[idx].tag = tag;
-    if (hipEventRecord(c->evpool[idx].a, c->st) != hipSuccess) rc = fail(PIC1DP_ERR_HIP, "hipEventRecord failed");
-  }
-  int end() {
-    if (idx >= 0 && hipEventRecord(c->evpool[idx].b, c->st) != hipSuccess)
-      return fail(PIC1DP_ERR_HIP, "hipEventRecord failed");
-    return rc;
-  }
-};
 
 LaunchCfg particle_launch(const pic1dp_ctx *c, int64_t np, bool with_E, bool with_rho) {
   const int nx = c->in.nx;
@@ -319,59 +87,6 @@ int validate(const pic1dp_input &in, const pic1dp_layout &lay) {
   return 0;
 }
 
-// the all-reduce of src/pic1dp_interaction.F90:132 on the stream
-int allreduce_charge(pic1dp_ctx *c) {
-  if (c->lay.nranks == 1 && !c->comm) return 0;
-  if (!c->comm)
-    return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: call pic1dp_hip_comm_init, connect the one-hop exchange (xchg_create / xchg_connect / set_allreduce), or use charge_local/charge_reduced");
-  Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
-  ncclResult_t r = rccl().AllReduce(c->d_charge, c->d_charge, static_cast<size_t>(c->in.nx), ncclDouble,
-                                    ncclSum, c->comm, c->st);
-  if (r != ncclSuccess) return fail(PIC1DP_ERR_COMM, "ncclAllReduce: %s", rccl().GetErrorString(r));
-  return sp.end();
-}
-
-constexpr size_t kXchgFlagBytes = 4096;  // flags[2][XCHG_MAX_RANKS] u64, padded
-
-bool xchg_active(const pic1dp_ctx *c) { return c->allreduce_kind == 2 && c->xc.connected; }
-
-XchgArgs next_xchg_args(pic1dp_ctx *c) {
-  XchgArgs x{};
-  for (int q = 0; q < c->lay.nranks; ++q) {
-    char *b = reinterpret_cast<char *>(c->xc.peer[q]);
-    x.flags[q] = reinterpret_cast<unsigned long long *>(b);
-    x.slots[q] = reinterpret_cast<double *>(b + kXchgFlagBytes);
-  }
-  x.err = c->xc.err;
-  x.epoch = ++c->xc.epoch;
-  x.timeout_ticks = c->xc.timeout_ticks;
-  x.rank = c->lay.rank;
-  x.nranks = c->lay.nranks;
-  x.vstride = XCHG_MAX_VEC * c->in.nx;
-  return x;
-}
-
-// a time-out reported by an exchange kernel (checked wherever the host synchronises)
-int xchg_check(pic1dp_ctx *c) {
-  if (!c->xc.err) return 0;
-  const unsigned long long e = *reinterpret_cast<volatile unsigned long long *>(c->xc.err);
-  if (e == 0) return 0;
-  return fail(PIC1DP_ERR_COMM, "charge exchange %llu: rank %d waited in vain for the charge of rank %d (peer stopped or out of step)",
-              e >> 8, c->lay.rank, static_cast<int>(e & 0xff) - 1);
-}
-
-// charge2 -> charge1 over ranks, whichever way is configured: the exchange kernel, or
-// k_charge_local + RCCL all-reduce (src/pic1dp_interaction.F90:126-135)
-int reduce_charge(pic1dp_ctx *c) {
-  if (xchg_active(c)) {
-    Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
-    HIP_TRY(launch_charge_exchange(c->fa, next_xchg_args(c), c->st));
-    return sp.end();
-  }
-  HIP_TRY(launch_charge_local(c->fa, c->st));
-  return allreduce_charge(c);
-}
-
 PushArgs make_push_args(pic1dp_ctx *c, int isp, int irk, const double *E) {
   Species &S = c->sp[isp];
   PushArgs a{};
@@ -390,20 +105,6 @@ PushArgs make_push_args(pic1dp_ctx *c, int isp, int irk, const double *E) {
   a.linear = c->in.linear;
   a.irk = irk;
   return a;
-}
-
-// second particle set of the RK ping-pong (sub-step kernels only): a slab of the same
-// geometry as the first (its p tiles stay unused)
-int ensure_second_set(pic1dp_ctx *c) {
-  for (Species &S : c->sp) {
-    if (S.slab[1]) continue;
-    HIP_TRY(hipMalloc(&S.slab[1], sizeof(double) * static_cast<size_t>(slab_doubles(S.nalloc + 2))));
-    const int64_t as = slab_array_stride(S.nalloc + 2);
-    S.set[1].x = S.slab[1];
-    S.set[1].v = c->in.linear == 1 ? S.set[0].v : S.slab[1] + as;      // v is never pushed in a linear run
-    S.set[1].w = c->in.deltaf == 0 ? S.set[0].w : S.slab[1] + 2 * as;  // w is not evolved in a full-f run
-  }
-  return 0;
 }
 
 int enqueue_push(pic1dp_ctx *c, int irk, bool fused, const double *E = nullptr) {
@@ -452,6 +153,24 @@ int enqueue_deposit(pic1dp_ctx *c) {
 }
 
 }  // namespace
+
+namespace pic1dp_host {
+
+// second particle set of the RK ping-pong (sub-step kernels only): a slab of the same
+// geometry as the first (its p tiles stay unused)
+int ensure_second_set(pic1dp_ctx *c) {
+  for (Species &S : c->sp) {
+    if (S.slab[1]) continue;
+    HIP_TRY(hipMalloc(&S.slab[1], sizeof(double) * static_cast<size_t>(slab_doubles(S.nalloc + 2))));
+    const int64_t as = slab_array_stride(S.nalloc + 2);
+    S.set[1].x = S.slab[1];
+    S.set[1].v = c->in.linear == 1 ? S.set[0].v : S.slab[1] + as;      // v is never pushed in a linear run
+    S.set[1].w = c->in.deltaf == 0 ? S.set[0].w : S.slab[1] + 2 * as;  // w is not evolved in a full-f run
+  }
+  return 0;
+}
+
+}  // namespace pic1dp_host
 
 // ===========================================================================
 // C ABI
@@ -600,15 +319,11 @@ static LaunchCfg pred_launch(const pic1dp_ctx *c, int64_t np, bool priv, int64_t
 static size_t step_lds_bytes(int nx, bool full, int rcopies);
 static bool output_follows(const pic1dp_ctx *c);
 static bool output_follows_at(const pic1dp_ctx *c, int32_t itime0, double time0);
-static void optimize_due_at(const pic1dp_ctx *c, double time0, bool due[3]);
 static int finish_pending_solve(pic1dp_ctx *c);
 static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred);
 static void field_written(pic1dp_ctx *c, bool by_solve);
 static bool pred_usable(const pic1dp_ctx *c);
 static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer);
-static int diag_buffers(pic1dp_ctx *c);
-static int diag_max_blocks(const pic1dp_ctx *c);
-static size_t dist_len(const pic1dp_input &in);
 
 int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1dp_ctx **out) {
   if (!in || !layout || !out) return fail(PIC1DP_ERR_ARG, "null argument");
@@ -864,14 +579,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   if (c->st) (void)hipStreamSynchronize(c->st);
-  if (c->comm) {
-    rccl().CommDestroy(c->comm);
-    c->comm = nullptr;
-  }
-  for (int q = 0; q < XCHG_MAX_RANKS; ++q)
-    if (c->xc.opened[q]) (void)hipIpcCloseMemHandle(c->xc.peer[q]);
-  if (c->xc.local) (void)hipFree(c->xc.local);
-  if (c->xc.err) (void)hipHostFree(c->xc.err);
+  comm_release(c);
   for (auto &S : c->sp) {
     (void)hipFree(S.slab[0]);
     (void)hipFree(S.slab[1]);
@@ -900,7 +608,8 @@ static int ensure_stage(pic1dp_ctx *c) {
 
 // host[0, cnt) -> markers [off, off + cnt) of the array starting at arr; returns
 // with the host buffer free for reuse
-static int put_range(pic1dp_ctx *c, double *arr, int64_t off, const double *host, int64_t cnt) {
+}  // extern "C"
+int pic1dp_host::put_range(pic1dp_ctx *c, double *arr, int64_t off, const double *host, int64_t cnt) {
   if (cnt <= 0) return 0;
   if (int rc = ensure_stage(c)) return rc;
   for (int64_t done = 0; done < cnt; done += kStageDoubles) {
@@ -911,9 +620,11 @@ static int put_range(pic1dp_ctx *c, double *arr, int64_t off, const double *host
   HIP_TRY(hipStreamSynchronize(c->st));
   return 0;
 }
+extern "C" {
 
 // markers [off, off + cnt) of the array starting at arr -> host[0, cnt)
-static int get_range(pic1dp_ctx *c, const double *arr, int64_t off, double *host, int64_t cnt) {
+}  // extern "C"
+int pic1dp_host::get_range(pic1dp_ctx *c, const double *arr, int64_t off, double *host, int64_t cnt) {
   if (cnt <= 0) return 0;
   if (int rc = ensure_stage(c)) return rc;
   for (int64_t done = 0; done < cnt; done += kStageDoubles) {
@@ -924,6 +635,7 @@ static int get_range(pic1dp_ctx *c, const double *arr, int64_t off, double *host
   }
   return 0;
 }
+extern "C" {
 
 int pic1dp_hip_local_sizes(pic1dp_ctx *c, int32_t isp, int64_t *nalloc, int64_t *np) {
   CHECK_CTX(c);
@@ -933,8 +645,6 @@ int pic1dp_hip_local_sizes(pic1dp_ctx *c, int32_t isp, int64_t *nalloc, int64_t 
   return 0;
 }
 
-static int materialize(pic1dp_ctx *c);  // lazy call sites, see below
-static int materialize_cd(pic1dp_ctx *c);
 
 int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   CHECK_CTX(c);
@@ -1087,7 +797,8 @@ int pic1dp_hip_particles_download_bak(pic1dp_ctx *c, int32_t isp, double *xb, do
 // ---------------------------------------------------------------------------
 // checks only: for the call sites that take part in the lazy scheme themselves
 // field_chargeden (and d_charge, and zeroed accumulators) as collect_charge would have left them at once
-static int materialize_cd(pic1dp_ctx *c) {
+}  // extern "C"
+int pic1dp_host::materialize_cd(pic1dp_ctx *c) {
   const int pending = c->cd_lazy;
   c->cd_lazy = 0;
   if (pending == 0) return 0;
@@ -1099,6 +810,7 @@ static int materialize_cd(pic1dp_ctx *c) {
   HIP_TRY(launch_chargeden(c->fa, pending == 2, c->st));
   return 0;
 }
+extern "C" {
 
 static int require_loaded_keep_lazy(pic1dp_ctx *c) {
   if (!c->loaded) return fail(PIC1DP_ERR_STATE, "no particles: call particle_load or particles_upload first");
@@ -1110,10 +822,12 @@ static int require_loaded_keep_lazy(pic1dp_ctx *c) {
 
 // every other entry point that reads or writes markers or charge accumulators:
 // memory first becomes what the eager calls would have left
-static int require_loaded(pic1dp_ctx *c) {
+}  // extern "C"
+int pic1dp_host::require_loaded(pic1dp_ctx *c) {
   if (int rc = require_loaded_keep_lazy(c)) return rc;
   return materialize(c);
 }
+extern "C" {
 
 // ---------------------------------------------------------------------------
 // Lazy call sites.  The reference driver calls push(irk), collect_charge,
@@ -1131,7 +845,6 @@ static int require_loaded(pic1dp_ctx *c) {
 // path itself are the whole-step path's (tests: test_lazy_call_sites_*).
 // ---------------------------------------------------------------------------
 static bool step_recompute_ok(const pic1dp_ctx *c);
-static bool optimize_due_any(const pic1dp_ctx *c);
 
 static bool lazy_ok(const pic1dp_ctx *c) {
   return c->lazy_calls && step_recompute_ok(c) && !optimize_due_any(c);
@@ -1149,7 +862,8 @@ static int enqueue_wrap_only(pic1dp_ctx *c) {
   return 0;
 }
 
-static int materialize(pic1dp_ctx *c) {
+}  // extern "C"
+int pic1dp_host::materialize(pic1dp_ctx *c) {
   const int lz = c->lz;
   c->lz = LZ_CLEAN;
   if (lz == LZ_CLEAN) return 0;
@@ -1160,6 +874,7 @@ static int materialize(pic1dp_ctx *c) {
   if (lz == LZ_PUSH2) return enqueue_push(c, 2, false);
   return 0;
 }
+extern "C" {
 
 // the deposit of collect_charge / charge_local into the species accumulators:
 // the whole-step kernel of a noted push, or the plain wrap + deposit
@@ -1277,133 +992,6 @@ int pic1dp_hip_push(pic1dp_ctx *c, int32_t irk) {
   }
   if (int rc = materialize(c)) return rc;
   return enqueue_push(c, irk, false);
-}
-
-static int allreduce_doubles(pic1dp_ctx *c, double *d, size_t n);
-
-// ---- marker optimisation (host side, rare; see optimize.hpp) -------------------
-// which events are due for the step that is being taken: merge, remove, split
-// time0: the time at the start of the step being taken
-static void optimize_due_at(const pic1dp_ctx *c, double time0, bool due[3]) {
-  const pic1dp_input &in = c->in;
-  const double t = time0 + in.dt;  // src/pic1dp_particle.F90:742,756,770
-  due[0] = c->imerge > 0 && c->imerge <= in.nmerge && t >= in.tmerge[c->imerge - 1];
-  due[1] = c->iremove > 0 && c->iremove <= in.nremove && t >= in.tremove[c->iremove - 1];
-  due[2] = c->isplit > 0 && c->isplit <= in.nsplit && t >= in.tsplit[c->isplit - 1];
-  if (in.deltaf == 0) due[0] = due[1] = due[2] = false;  // :734
-}
-static void optimize_due(const pic1dp_ctx *c, bool due[3]) { optimize_due_at(c, c->time, due); }
-
-static bool optimize_due_any(const pic1dp_ctx *c) {
-  bool due[3];
-  optimize_due(c, due);
-  return due[0] || due[1] || due[2];
-}
-
-int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optimized) {
-  CHECK_CTX(c);
-  if (flag_optimized) *flag_optimized = 0;
-  if (irk != 1 && irk != 2) return fail(PIC1DP_ERR_ARG, "irk must be 1 or 2");
-  bool due[3];
-  optimize_due(c, due);
-  if (irk != 2 || !(due[0] || due[1] || due[2])) return 0;
-  if (int rc = require_loaded(c)) return rc;
-  if (c->cur != 0) return fail(PIC1DP_ERR_STATE, "particle_optimize must follow the push of sub-step 2");
-  if ((due[1] || due[2]) && !c->rng_ready)
-    return fail(PIC1DP_ERR_STATE,
-                "particle_remove / particle_split continue the loader's random stream: load the markers with "
-                "pic1dp_hip_particle_load");
-  const pic1dp_input &in = c->in;
-  const int ns = in.nspecies, nb = c->nblk, nv = in.nv;
-  for (int s = 0; s < ns; ++s) {
-    int64_t sum = 0;
-    for (int b = 0; b < nb; ++b) sum += c->blk_np[s][b];
-    if (sum != c->sp[s].np) return fail(PIC1DP_ERR_STATE, "marker counts per block unknown (uploaded over several blocks)");
-  }
-  Span tm(c, PIC1DP_IWT_PARTICLE_OPTIMIZE, c->timers_on);
-  c->state_version++;
-  HIP_TRY(hipStreamSynchronize(c->st));
-  // host copy of every owned block, full allocation (valid markers + tail slots)
-  struct Block {
-    std::vector<double> a[4];  // x v p w
-  };
-  std::vector<std::vector<Block>> host(ns, std::vector<Block>(nb));
-  for (int s = 0; s < ns; ++s) {
-    Species &S = c->sp[s];
-    const double *dev[4] = {S.set[0].x, S.set[0].v, S.p, S.set[0].w};
-    int64_t voff = 0, toff = S.np;
-    for (int b = 0; b < nb; ++b) {
-      const int64_t na = c->blk_alloc[b], np = c->blk_np[s][b];
-      for (int k = 0; k < 4; ++k) {
-        host[s][b].a[k].resize(static_cast<size_t>(na));
-        if (int rc = get_range(c, dev[k], voff, host[s][b].a[k].data(), np)) return rc;
-        if (int rc = get_range(c, dev[k], toff, host[s][b].a[k].data() + np, na - np)) return rc;
-      }
-      voff += np;
-      toff += na - np;
-    }
-  }
-  const double *times[3] = {in.tmerge, in.tremove, in.tsplit};
-  const double *thresholds[3] = {in.thshmerge, in.thshremove, in.thshsplit};
-  int *counters[3] = {&c->imerge, &c->iremove, &c->isplit};
-  (void)times;
-  std::vector<double> hist(static_cast<size_t>(ns) * nv), local(nv);
-  for (int kind = 0; kind < 3; ++kind) {
-    if (!due[kind]) continue;
-    // particle_compute_dist_pertb_abs_v: block by block, summed in block order,
-    // then over processes (MPI_Allreduce, :392)
-    for (int s = 0; s < ns; ++s) {
-      double *h = &hist[static_cast<size_t>(s) * nv];
-      for (int b = 0; b < nb; ++b) {
-        std::fill(local.begin(), local.end(), 0.0);
-        opt_histogram(in, c->blk_np[s][b], host[s][b].a[1].data(), host[s][b].a[3].data(), local.data());
-        for (int i = 0; i < nv; ++i) h[i] = b == 0 ? local[i] : h[i] + local[i];
-      }
-    }
-    if (c->lay.nranks > 1 || c->comm) {
-      double *d = c->d_scratch;
-      if (static_cast<size_t>(ns) * nv > static_cast<size_t>(kEnergyBlocks) * 3)
-        return fail(PIC1DP_ERR_ARG, "nv too large for the reduction scratch");
-      HIP_TRY(hipMemcpy(d, hist.data(), sizeof(double) * ns * nv, hipMemcpyHostToDevice));
-      if (int rc = allreduce_doubles(c, d, static_cast<size_t>(ns) * nv)) return rc;
-      HIP_TRY(hipStreamSynchronize(c->st));
-      HIP_TRY(hipMemcpy(hist.data(), d, sizeof(double) * ns * nv, hipMemcpyDeviceToHost));
-    }
-    const double th = thresholds[kind][*counters[kind] - 1];
-    for (int b = 0; b < nb; ++b)
-      for (int s = 0; s < ns; ++s) {
-        Block &B = host[s][b];
-        const double *h = &hist[static_cast<size_t>(s) * nv];
-        int64_t &np = c->blk_np[s][b];
-        if (kind == 0)
-          opt_merge(in, th, h, np, B.a[0].data(), B.a[1].data(), B.a[2].data(), B.a[3].data());
-        else if (kind == 1)
-          opt_remove(in, th, h, c->blk_rng[b], np, B.a[0].data(), B.a[1].data(), B.a[2].data(), B.a[3].data());
-        else
-          opt_split(in, th, h, c->blk_rng[b], c->blk_alloc[b], np, B.a[0].data(), B.a[1].data(), B.a[2].data(),
-                    B.a[3].data());
-      }
-    *counters[kind] += 1;
-  }
-  // back to the device: valid markers of all blocks packed first, tails behind
-  for (int s = 0; s < ns; ++s) {
-    Species &S = c->sp[s];
-    S.np = 0;
-    for (int b = 0; b < nb; ++b) S.np += c->blk_np[s][b];
-    double *dev[4] = {S.set[0].x, S.set[0].v, S.p, S.set[0].w};
-    int64_t voff = 0, toff = S.np;
-    for (int b = 0; b < nb; ++b) {
-      const int64_t na = c->blk_alloc[b], np = c->blk_np[s][b];
-      for (int k = 0; k < 4; ++k) {
-        if (int rc = put_range(c, dev[k], voff, host[s][b].a[k].data(), np)) return rc;
-        if (int rc = put_range(c, dev[k], toff, host[s][b].a[k].data() + np, na - np)) return rc;
-      }
-      voff += np;
-      toff += na - np;
-    }
-  }
-  if (flag_optimized) *flag_optimized = 1;
-  return tm.end();
 }
 
 static int substep_impl(pic1dp_ctx *c, int irk, bool record) {
@@ -2116,89 +1704,6 @@ int pic1dp_hip_energy_history_reset(pic1dp_ctx *c) {
   return 0;
 }
 
-// One fused pass over a species' markers for output_all: histograms of
-// output_ptcldist into d_dist[isp] and the kinetic sums of output_field; results
-// stay valid until the markers change (state_version).
-static size_t dist_len(const pic1dp_input &in) {
-  return 3 * static_cast<size_t>(in.nx_opd) * in.nv_opd + 3 * static_cast<size_t>(in.nv_opd);
-}
-
-static int diag_max_blocks(const pic1dp_ctx *c) { return 2 * c->num_cu; }
-
-// buffers of the marker diagnostics: [nspecies] cached histograms + one for the all-reduced
-// copy handed out, per-workgroup partial sums per species
-static int diag_buffers(pic1dp_ctx *c) {
-  const pic1dp_input &in = c->in;
-  const int ns = in.nspecies;
-  if (in.nx_opd < 1 || in.nv_opd < 2) return fail(PIC1DP_ERR_ARG, "nx_opd >= 1 and nv_opd >= 2 required");
-  if (c->diag_version.empty()) {
-    c->diag_version.assign(ns, 0);
-    c->diag_sums.assign(3 * static_cast<size_t>(ns), 0.0);
-    c->diag_pending.assign(ns, 0);
-    c->diag_blocks.assign(ns, 0);
-  }
-  if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * dist_len(in) * (ns + 1)));
-  if (!c->d_diag_part) HIP_TRY(hipMalloc(&c->d_diag_part, sizeof(double) * 3 * diag_max_blocks(c) * ns));
-  return 0;
-}
-
-static int ensure_diag(pic1dp_ctx *c, int isp) {
-  const pic1dp_input &in = c->in;
-  if (int rc = diag_buffers(c)) return rc;
-  const size_t ntot = dist_len(in);
-  Species &S = c->sp[isp];
-  double *part_dev = c->d_diag_part + static_cast<size_t>(3) * diag_max_blocks(c) * isp;
-  if (c->diag_version[isp] != c->state_version) {  // no pass has seen these markers yet: run one
-    const PSet &A = S.set[c->cur];
-    double *hist = c->d_dist + ntot * isp;
-    HIP_TRY(hipMemsetAsync(hist, 0, sizeof(double) * ntot, c->st));
-    c->diag_blocks[isp] = 0;
-    if (S.np > 0) {
-      c->diag_blocks[isp] = ptcldist_blocks(S.np, in.nx_opd, in.nv_opd, c->num_cu);
-      HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, in.lx, in.v_max, in.nx_opd, in.nv_opd, in.deltaf == 1, hist,
-                              part_dev, c->num_cu, c->st));
-      c->diag_passes++;
-    }
-    c->diag_pending[isp] = 1;
-    c->diag_version[isp] = c->state_version;
-  }
-  if (!c->diag_pending[isp]) return 0;
-  // collect: partial kinetic sums of the pass (k_ptcldist, or k_step_full's DIAG variant), workgroup order
-  double *sums = &c->diag_sums[3 * static_cast<size_t>(isp)];
-  sums[0] = sums[1] = sums[2] = 0.0;
-  std::vector<double> part(3 * static_cast<size_t>(std::max(diag_max_blocks(c), kEnergyBlocks)));
-  const int blocks = c->diag_blocks[isp];
-  if (blocks > 0) {
-    HIP_TRY(hipStreamSynchronize(c->st));
-    HIP_TRY(hipMemcpy(part.data(), part_dev, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
-    for (int b = 0; b < blocks; ++b)
-      for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
-  }
-  // the reference sums the whole local vector (VecSum); slots beyond np live in set 0
-  const int64_t ntail = S.nalloc - S.np;
-  if (ntail > 0) {
-    const int tb = static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256));
-    HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, ntail, c->d_scratch, tb,
-                               c->st));
-    HIP_TRY(hipStreamSynchronize(c->st));
-    HIP_TRY(hipMemcpy(part.data(), c->d_scratch, sizeof(double) * tb * 3, hipMemcpyDeviceToHost));
-    for (int b = 0; b < tb; ++b)
-      for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
-  }
-  c->diag_pending[isp] = 0;
-  return 0;
-}
-
-int pic1dp_hip_energy_sums(pic1dp_ctx *c, int32_t isp, double out[3]) {
-  CHECK_CTX(c);
-  if (isp < 0 || isp >= c->in.nspecies || !out) return fail(PIC1DP_ERR_ARG, "bad argument");
-  if (int rc = require_loaded(c)) return rc;
-  if (int rc = ensure_diag(c, isp)) return rc;
-  for (int k = 0; k < 3; ++k) out[k] = c->diag_sums[3 * static_cast<size_t>(isp) + k];
-  if (!c->in.deltaf) out[2] = out[1];
-  return 0;
-}
-
 int pic1dp_hip_cell_indices(pic1dp_ctx *c, int32_t isp, int32_t *ix, int64_t *count) {
   CHECK_CTX(c);
   if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
@@ -2218,156 +1723,6 @@ int pic1dp_hip_cell_indices(pic1dp_ctx *c, int32_t isp, int32_t *ix, int64_t *co
   (void)hipFree(d_ix);
   (void)hipFree(d_cnt);
   HIP_TRY(e);
-  return 0;
-}
-
-// ---------------------------------------------------------------------------
-// diagnostics of output_all
-// ---------------------------------------------------------------------------
-static int allreduce_doubles(pic1dp_ctx *c, double *d, size_t n) {
-  if (!c->comm) {
-    if (c->lay.nranks > 1)
-      return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: reduce the local sums on the host instead");
-    return 0;
-  }
-  ncclResult_t r = rccl().AllReduce(d, d, n, ncclDouble, ncclSum, c->comm, c->st);
-  if (r != ncclSuccess) return fail(PIC1DP_ERR_COMM, "ncclAllReduce: %s", rccl().GetErrorString(r));
-  return 0;
-}
-
-int pic1dp_hip_output_scalars(pic1dp_ctx *c, double *out, int32_t n) {
-  CHECK_CTX(c);
-  const int ns = c->in.nspecies;
-  if (!out || n != 2 + 3 * ns) return fail(PIC1DP_ERR_ARG, "out must hold 2 + 3*nspecies doubles");
-  std::vector<double> sums(3 * ns);
-  for (int s = 0; s < ns; ++s)
-    if (int rc = pic1dp_hip_energy_sums(c, s, &sums[3 * s])) return rc;
-  if (c->comm) {  // VecSum's scalar all-reduce
-    double *d = c->d_scratch;
-    HIP_TRY(hipMemcpyAsync(d, sums.data(), sizeof(double) * 3 * ns, hipMemcpyHostToDevice, c->st));
-    if (int rc = allreduce_doubles(c, d, 3 * ns)) return rc;
-    HIP_TRY(hipStreamSynchronize(c->st));
-    HIP_TRY(hipMemcpy(sums.data(), d, sizeof(double) * 3 * ns, hipMemcpyDeviceToHost));
-  }
-  return pic1dp_hip_output_scalars_from(c, sums.data(), out, n);
-}
-
-int pic1dp_hip_output_scalars_from(pic1dp_ctx *c, const double *sums, double *out, int32_t n) {
-  CHECK_CTX(c);
-  const int ns = c->in.nspecies;
-  if (!sums || !out || n != 2 + 3 * ns) return fail(PIC1DP_ERR_ARG, "sums must hold 3*nspecies and out 2 + 3*nspecies doubles");
-  out[0] = c->time;
-  if (int rc = pic1dp_hip_field_energy(c, &out[1])) return rc;
-  const pic1dp_input &in = c->in;
-  for (int s = 0; s < ns; ++s) {
-    double marker = sums[3 * s], total = sums[3 * s + 1], pert;
-    if (in.deltaf == 1) {
-      pert = sums[3 * s + 2];
-      if (in.linear == 1) total = total + pert;  // :152-155
-    } else {                                      // :156-170
-      pert = total;
-      if (in.iptcldist == 1) {
-        pert = pert - 3.0 * in.species_density[s] * in.lx;
-      } else if (in.iptcldist == 0) {
-        pert = pert - in.species_temperature[s] / in.species_mass[s] * in.species_density[s] * in.lx;
-      }
-    }
-    out[2 + 3 * s] = marker;
-    out[3 + 3 * s] = total;
-    out[4 + 3 * s] = pert;
-  }
-  return 0;
-}
-
-// equilibrium f0(v) as the full-f branch of output_ptcldist normalises it
-// (src/pic1dp_output.F90:375-451; note the reference divides by T/m, not sqrt(T/m))
-static double output_f0(const pic1dp_input &in, int s, double sv) {
-  const double T = in.species_temperature[s], T2 = in.species_temperature2[s], m = in.species_mass[s];
-  const double den = in.species_density[s], v0 = in.species_v0[s];
-  if (in.iptcldist == 1) return den * (sv * sv) * std::exp(-(sv * sv) / 2.0) / std::sqrt(2.0 * kPi);
-  if (in.iptcldist == 2)
-    return den * (std::exp(-((sv + v0) * (sv + v0)) / (2.0 * T / m)) + std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T / m))) /
-           (std::sqrt(8.0 * kPi) * T / m);
-  if (in.iptcldist == 3)
-    return den * std::exp(-(sv * sv) / (2.0 * T / m)) / (std::sqrt(2.0 * kPi) * T / m) +
-           (1.0 - den) * std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T2 / m)) / (std::sqrt(2.0 * kPi) * T2 / m);
-  return den * std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T / m)) / (std::sqrt(2.0 * kPi) * T / m);
-}
-
-// what output_ptcldist does with the sums over ranks (src/pic1dp_output.F90:328-331, :361-453): linear total +=
-// pertb, scaling by the histogram cell sizes, full-f pertb = total - f0; in place on host arrays
-static void finish_ptcldist(const pic1dp_input &in, int isp, double *mxv, double *txv, double *pxv, double *mv, double *tv,
-                            double *pv) {
-  const int nxo = in.nx_opd, nvo = in.nv_opd;
-  const size_t nxv = static_cast<size_t>(nxo) * nvo;
-  if (in.linear == 1) {  // :328-331
-    for (size_t i = 0; i < nxv; ++i) txv[i] = txv[i] + pxv[i];
-    for (int i = 0; i < nvo; ++i) tv[i] = tv[i] + pv[i];
-  }
-  const double delv_inv = static_cast<double>(nvo - 1) / (2.0 * in.v_max);  // :203-205
-  const double delx_inv = static_cast<double>(nxo) / in.lx;
-  for (size_t i = 0; i < nxv; ++i) {
-    mxv[i] = mxv[i] * delx_inv * delv_inv;
-    txv[i] = txv[i] * delx_inv * delv_inv;
-  }
-  for (int i = 0; i < nvo; ++i) {
-    mv[i] = mv[i] * delv_inv;
-    tv[i] = tv[i] * delv_inv;
-  }
-  if (in.deltaf == 1) {
-    for (size_t i = 0; i < nxv; ++i) pxv[i] = pxv[i] * delx_inv * delv_inv;
-    for (int i = 0; i < nvo; ++i) pv[i] = pv[i] * delv_inv;
-  } else {  // :370-453
-    for (int iv = 0; iv < nvo; ++iv) {
-      const double sv = (static_cast<double>(iv) / static_cast<double>(nvo - 1) * 2.0 - 1.0) * in.v_max;
-      const double f0 = output_f0(in, isp, sv);
-      for (int ix = 0; ix < nxo; ++ix) pxv[static_cast<size_t>(iv) * nxo + ix] = txv[static_cast<size_t>(iv) * nxo + ix] - f0;
-      pv[iv] = tv[iv] - in.lx * f0;
-    }
-  }
-}
-
-int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *markr_xv, double *total_xv,
-                        double *pertb_xv, double *markr_v, double *total_v, double *pertb_v) {
-  CHECK_CTX(c);
-  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
-  if (int rc = require_loaded(c)) return rc;
-  const pic1dp_input &in = c->in;
-  const int nxo = in.nx_opd, nvo = in.nv_opd;
-  if (int rc = ensure_diag(c, isp)) return rc;
-  const size_t nxv = static_cast<size_t>(nxo) * nvo, ntot = 3 * nxv + 3 * nvo;
-  const double *hist = c->d_dist + ntot * isp;
-  if (finish && c->comm) {  // reduce a copy: the cached local histograms stay local
-    double *red = c->d_dist + ntot * in.nspecies;
-    HIP_TRY(hipMemcpyAsync(red, hist, sizeof(double) * ntot, hipMemcpyDeviceToDevice, c->st));
-    if (int rc = allreduce_doubles(c, red, ntot)) return rc;
-    hist = red;
-  } else if (finish && c->lay.nranks > 1) {
-    return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: take finish = 0 and reduce the local sums on the host");
-  }
-  std::vector<double> h(ntot);
-  HIP_TRY(hipStreamSynchronize(c->st));
-  HIP_TRY(hipMemcpy(h.data(), hist, sizeof(double) * ntot, hipMemcpyDeviceToHost));
-  double *mxv = h.data(), *txv = mxv + nxv, *pxv = txv + nxv, *mv = pxv + nxv, *tv = mv + nvo, *pv = tv + nvo;
-  if (finish) finish_ptcldist(in, isp, mxv, txv, pxv, mv, tv, pv);
-  auto give = [&](double *dst, const double *src, size_t n) {
-    if (dst) std::memcpy(dst, src, sizeof(double) * n);
-  };
-  give(markr_xv, mxv, nxv);
-  give(total_xv, txv, nxv);
-  give(pertb_xv, pxv, nxv);
-  give(markr_v, mv, nvo);
-  give(total_v, tv, nvo);
-  give(pertb_v, pv, nvo);
-  return 0;
-}
-
-int pic1dp_hip_ptcldist_finish(pic1dp_ctx *c, int32_t isp, double *markr_xv, double *total_xv, double *pertb_xv,
-                               double *markr_v, double *total_v, double *pertb_v) {
-  CHECK_CTX(c);
-  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
-  if (!markr_xv || !total_xv || !pertb_xv || !markr_v || !total_v || !pertb_v) return fail(PIC1DP_ERR_ARG, "null array");
-  finish_ptcldist(c->in, isp, markr_xv, total_xv, pertb_xv, markr_v, total_v, pertb_v);
   return 0;
 }
 
@@ -2417,141 +1772,6 @@ int pic1dp_hip_charge_reduced(pic1dp_ctx *c, const double *charge1) {
   else
     HIP_TRY(launch_chargeden(c->fa, false, c->st));
   return 0;
-}
-
-// ---------------------------------------------------------------------------
-// RCCL
-// ---------------------------------------------------------------------------
-int pic1dp_hip_comm_unique_id(unsigned char id[PIC1DP_COMM_ID_BYTES]) {
-  static_assert(sizeof(ncclUniqueId) == PIC1DP_COMM_ID_BYTES, "unique id size");
-  if (!id) return fail(PIC1DP_ERR_ARG, "null id");
-  std::string err;
-  if (!rccl().load(err)) return fail(PIC1DP_ERR_COMM, "%s", err.c_str());
-  ncclUniqueId u;
-  ncclResult_t r = rccl().GetUniqueId(&u);
-  if (r != ncclSuccess) return fail(PIC1DP_ERR_COMM, "ncclGetUniqueId: %s", rccl().GetErrorString(r));
-  std::memcpy(id, u.internal, PIC1DP_COMM_ID_BYTES);
-  return 0;
-}
-
-int pic1dp_hip_comm_init(pic1dp_ctx *c, const unsigned char id[PIC1DP_COMM_ID_BYTES]) {
-  CHECK_CTX(c);
-  if (!id) return fail(PIC1DP_ERR_ARG, "null id");
-  if (c->comm) return fail(PIC1DP_ERR_STATE, "communicator already initialised");
-  std::string err;
-  if (!rccl().load(err)) return fail(PIC1DP_ERR_COMM, "%s", err.c_str());
-  HIP_TRY(hipSetDevice(c->device));
-  ncclUniqueId u;
-  std::memcpy(u.internal, id, PIC1DP_COMM_ID_BYTES);
-  ncclResult_t r = rccl().CommInitRank(&c->comm, c->lay.nranks, u, c->lay.rank);
-  if (r != ncclSuccess) {
-    c->comm = nullptr;
-    return fail(PIC1DP_ERR_COMM, "ncclCommInitRank: %s", rccl().GetErrorString(r));
-  }
-  return 0;
-}
-
-// ---------------------------------------------------------------------------
-// one-hop charge exchange over peer-mapped memory (alternative to the RCCL
-// all-reduce; kernels_field.hip exchange_charge)
-// ---------------------------------------------------------------------------
-int pic1dp_hip_comm_available(void) {
-  std::string err;
-  if (!rccl().load(err)) return fail(PIC1DP_ERR_COMM, "%s", err.c_str());
-  return 0;
-}
-
-int pic1dp_hip_xchg_create(pic1dp_ctx *c, unsigned char handle[PIC1DP_XCHG_HANDLE_BYTES]) {
-  static_assert(sizeof(hipIpcMemHandle_t) == PIC1DP_XCHG_HANDLE_BYTES, "ipc handle size");
-  CHECK_CTX(c);
-  if (!handle) return fail(PIC1DP_ERR_ARG, "null handle");
-  if (c->lay.nranks > XCHG_MAX_RANKS) return fail(PIC1DP_ERR_ARG, "the exchange serves at most %d ranks", XCHG_MAX_RANKS);
-  if (c->xc.local) return fail(PIC1DP_ERR_STATE, "exchange area already created");
-  HIP_TRY(hipSetDevice(c->device));
-  const size_t bytes = kXchgFlagBytes + sizeof(double) * 2 * static_cast<size_t>(c->lay.nranks) * XCHG_MAX_VEC * c->in.nx;
-  // memory the peers' stores and this GPU's polls meet in has to be coherent across agents INSIDE a kernel:
-  // fine-grained, else uncached.  Plain (coarse-grained) hipMalloc memory is not -- a stale L2 line of the
-  // same-parity slot of exchange e - 2 would be summed without any error showing -- so the automatic chain stops
-  // after the two coherent kinds and reports PIC1DP_ERR_COMM (the host then agrees on RCCL or its own sum);
-  // kind 3 only when PIC1DP_XCHG_MEM=3 asks for it by name (experiments).
-  int want = 1, last = 2;
-  if (const char *e = std::getenv("PIC1DP_XCHG_MEM")) {
-    want = std::atoi(e);
-    if (want < 1 || want > 3) return fail(PIC1DP_ERR_ARG, "PIC1DP_XCHG_MEM must be 1 (fine-grained), 2 (uncached) or 3 (plain)");
-    last = want == 3 ? 3 : 2;
-  }
-  hipError_t e = hipErrorUnknown;
-  for (int kind = want; kind <= last && e != hipSuccess; ++kind) {
-    if (kind == 1) e = hipExtMallocWithFlags(&c->xc.local, bytes, hipDeviceMallocFinegrained);
-    if (kind == 2) e = hipExtMallocWithFlags(&c->xc.local, bytes, hipDeviceMallocUncached);
-    if (kind == 3) e = hipMalloc(&c->xc.local, bytes);
-    hipIpcMemHandle_t h;
-    if (e == hipSuccess) {
-      e = hipIpcGetMemHandle(&h, c->xc.local);
-      if (e == hipSuccess) {
-        std::memcpy(handle, &h, sizeof h);
-        c->xc.memkind = kind;
-      } else {
-        (void)hipFree(c->xc.local);
-        c->xc.local = nullptr;
-      }
-    }
-    if (e != hipSuccess) (void)hipGetLastError();
-  }
-  if (e != hipSuccess)
-    return fail(PIC1DP_ERR_COMM, "exchange area: no fine-grained or uncached device memory with an IPC handle (%s)",
-                hipGetErrorString(e));
-  HIP_TRY(hipMemset(c->xc.local, 0, bytes));
-  if (!c->xc.err) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->xc.err), 64, hipHostMallocDefault));
-    *c->xc.err = 0;
-  }
-  double tmo_ms = 20000.0;
-  if (const char *t = std::getenv("PIC1DP_XCHG_TIMEOUT_MS")) tmo_ms = std::atof(t);
-  c->xc.timeout_ticks = static_cast<long long>(tmo_ms * 1e5);  // wall_clock64 counts at 100 MHz
-  c->xc.epoch = 0;
-  HIP_TRY(hipDeviceSynchronize());
-  return 0;
-}
-
-int pic1dp_hip_xchg_connect(pic1dp_ctx *c, const unsigned char *handles) {
-  CHECK_CTX(c);
-  if (!handles) return fail(PIC1DP_ERR_ARG, "null handles");
-  if (!c->xc.local) return fail(PIC1DP_ERR_STATE, "xchg_connect before xchg_create");
-  if (c->xc.connected) return fail(PIC1DP_ERR_STATE, "exchange already connected");
-  HIP_TRY(hipSetDevice(c->device));
-  for (int q = 0; q < c->lay.nranks; ++q) {
-    if (q == c->lay.rank) {
-      c->xc.peer[q] = c->xc.local;
-      continue;
-    }
-    hipIpcMemHandle_t h;
-    std::memcpy(&h, handles + static_cast<size_t>(q) * PIC1DP_XCHG_HANDLE_BYTES, sizeof h);
-    hipError_t e = hipIpcOpenMemHandle(&c->xc.peer[q], h, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      return fail(PIC1DP_ERR_COMM, "hipIpcOpenMemHandle for the exchange area of rank %d: %s", q, hipGetErrorString(e));
-    }
-    c->xc.opened[q] = true;
-  }
-  c->xc.connected = true;
-  return 0;
-}
-
-int pic1dp_hip_set_allreduce(pic1dp_ctx *c, int32_t kind) {
-  CHECK_CTX(c);
-  if (kind < 0 || kind > 2) return fail(PIC1DP_ERR_ARG, "allreduce kind must be 0 (auto), 1 (RCCL) or 2 (one-hop exchange)");
-  if (kind == 2 && !c->xc.connected) return fail(PIC1DP_ERR_STATE, "the one-hop exchange is not connected");
-  if (kind == 1 && !c->comm) return fail(PIC1DP_ERR_STATE, "no RCCL communicator");
-  c->allreduce_kind = kind;
-  return 0;
-}
-
-int pic1dp_hip_xchg_info(pic1dp_ctx *c, int32_t *memkind, int64_t *exchanges) {
-  CHECK_CTX(c);
-  if (memkind) *memkind = c->xc.memkind;
-  if (exchanges) *exchanges = static_cast<int64_t>(c->xc.epoch);
-  return xchg_check(c);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,235 @@
+// capi_diag.cpp -- diagnostics of output_all (src/pic1dp_output.F90:100-189, 196-477): the kinetic sums and the
+// (x, v) / v histograms, one fused pass per species, cached against state_version.
+#include "ctx.hpp"
+
+namespace pic1dp_host {
+
+// One fused pass over a species' markers for output_all: histograms of
+// output_ptcldist into d_dist[isp] and the kinetic sums of output_field; results
+// stay valid until the markers change (state_version).
+size_t dist_len(const pic1dp_input &in) {
+  return 3 * static_cast<size_t>(in.nx_opd) * in.nv_opd + 3 * static_cast<size_t>(in.nv_opd);
+}
+
+int diag_max_blocks(const pic1dp_ctx *c) { return 2 * c->num_cu; }
+
+// buffers of the marker diagnostics: [nspecies] cached histograms + one for the all-reduced
+// copy handed out, per-workgroup partial sums per species
+int diag_buffers(pic1dp_ctx *c) {
+  const pic1dp_input &in = c->in;
+  const int ns = in.nspecies;
+  if (in.nx_opd < 1 || in.nv_opd < 2) return fail(PIC1DP_ERR_ARG, "nx_opd >= 1 and nv_opd >= 2 required");
+  if (c->diag_version.empty()) {
+    c->diag_version.assign(ns, 0);
+    c->diag_sums.assign(3 * static_cast<size_t>(ns), 0.0);
+    c->diag_pending.assign(ns, 0);
+    c->diag_blocks.assign(ns, 0);
+  }
+  if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * dist_len(in) * (ns + 1)));
+  if (!c->d_diag_part) HIP_TRY(hipMalloc(&c->d_diag_part, sizeof(double) * 3 * diag_max_blocks(c) * ns));
+  return 0;
+}
+
+int ensure_diag(pic1dp_ctx *c, int isp) {
+  const pic1dp_input &in = c->in;
+  if (int rc = diag_buffers(c)) return rc;
+  const size_t ntot = dist_len(in);
+  Species &S = c->sp[isp];
+  double *part_dev = c->d_diag_part + static_cast<size_t>(3) * diag_max_blocks(c) * isp;
+  if (c->diag_version[isp] != c->state_version) {  // no pass has seen these markers yet: run one
+    const PSet &A = S.set[c->cur];
+    double *hist = c->d_dist + ntot * isp;
+    HIP_TRY(hipMemsetAsync(hist, 0, sizeof(double) * ntot, c->st));
+    c->diag_blocks[isp] = 0;
+    if (S.np > 0) {
+      c->diag_blocks[isp] = ptcldist_blocks(S.np, in.nx_opd, in.nv_opd, c->num_cu);
+      HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, in.lx, in.v_max, in.nx_opd, in.nv_opd, in.deltaf == 1, hist,
+                              part_dev, c->num_cu, c->st));
+      c->diag_passes++;
+    }
+    c->diag_pending[isp] = 1;
+    c->diag_version[isp] = c->state_version;
+  }
+  if (!c->diag_pending[isp]) return 0;
+  // collect: partial kinetic sums of the pass (k_ptcldist, or k_step_full's DIAG variant), workgroup order
+  double *sums = &c->diag_sums[3 * static_cast<size_t>(isp)];
+  sums[0] = sums[1] = sums[2] = 0.0;
+  std::vector<double> part(3 * static_cast<size_t>(std::max(diag_max_blocks(c), kEnergyBlocks)));
+  const int blocks = c->diag_blocks[isp];
+  if (blocks > 0) {
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(part.data(), part_dev, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
+    for (int b = 0; b < blocks; ++b)
+      for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
+  }
+  // the reference sums the whole local vector (VecSum); slots beyond np live in set 0
+  const int64_t ntail = S.nalloc - S.np;
+  if (ntail > 0) {
+    const int tb = static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256));
+    HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, ntail, c->d_scratch, tb,
+                               c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(part.data(), c->d_scratch, sizeof(double) * tb * 3, hipMemcpyDeviceToHost));
+    for (int b = 0; b < tb; ++b)
+      for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
+  }
+  c->diag_pending[isp] = 0;
+  return 0;
+}
+
+
+}  // namespace pic1dp_host
+
+extern "C" {
+
+int pic1dp_hip_energy_sums(pic1dp_ctx *c, int32_t isp, double out[3]) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies || !out) return fail(PIC1DP_ERR_ARG, "bad argument");
+  if (int rc = require_loaded(c)) return rc;
+  if (int rc = ensure_diag(c, isp)) return rc;
+  for (int k = 0; k < 3; ++k) out[k] = c->diag_sums[3 * static_cast<size_t>(isp) + k];
+  if (!c->in.deltaf) out[2] = out[1];
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// diagnostics of output_all
+// ---------------------------------------------------------------------------
+int pic1dp_hip_output_scalars(pic1dp_ctx *c, double *out, int32_t n) {
+  CHECK_CTX(c);
+  const int ns = c->in.nspecies;
+  if (!out || n != 2 + 3 * ns) return fail(PIC1DP_ERR_ARG, "out must hold 2 + 3*nspecies doubles");
+  std::vector<double> sums(3 * ns);
+  for (int s = 0; s < ns; ++s)
+    if (int rc = pic1dp_hip_energy_sums(c, s, &sums[3 * s])) return rc;
+  if (c->comm) {  // VecSum's scalar all-reduce
+    double *d = c->d_scratch;
+    HIP_TRY(hipMemcpyAsync(d, sums.data(), sizeof(double) * 3 * ns, hipMemcpyHostToDevice, c->st));
+    if (int rc = allreduce_doubles(c, d, 3 * ns)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(sums.data(), d, sizeof(double) * 3 * ns, hipMemcpyDeviceToHost));
+  }
+  return pic1dp_hip_output_scalars_from(c, sums.data(), out, n);
+}
+
+int pic1dp_hip_output_scalars_from(pic1dp_ctx *c, const double *sums, double *out, int32_t n) {
+  CHECK_CTX(c);
+  const int ns = c->in.nspecies;
+  if (!sums || !out || n != 2 + 3 * ns) return fail(PIC1DP_ERR_ARG, "sums must hold 3*nspecies and out 2 + 3*nspecies doubles");
+  out[0] = c->time;
+  if (int rc = pic1dp_hip_field_energy(c, &out[1])) return rc;
+  const pic1dp_input &in = c->in;
+  for (int s = 0; s < ns; ++s) {
+    double marker = sums[3 * s], total = sums[3 * s + 1], pert;
+    if (in.deltaf == 1) {
+      pert = sums[3 * s + 2];
+      if (in.linear == 1) total = total + pert;  // :152-155
+    } else {                                      // :156-170
+      pert = total;
+      if (in.iptcldist == 1) {
+        pert = pert - 3.0 * in.species_density[s] * in.lx;
+      } else if (in.iptcldist == 0) {
+        pert = pert - in.species_temperature[s] / in.species_mass[s] * in.species_density[s] * in.lx;
+      }
+    }
+    out[2 + 3 * s] = marker;
+    out[3 + 3 * s] = total;
+    out[4 + 3 * s] = pert;
+  }
+  return 0;
+}
+
+// equilibrium f0(v) as the full-f branch of output_ptcldist normalises it
+// (src/pic1dp_output.F90:375-451; note the reference divides by T/m, not sqrt(T/m))
+static double output_f0(const pic1dp_input &in, int s, double sv) {
+  const double T = in.species_temperature[s], T2 = in.species_temperature2[s], m = in.species_mass[s];
+  const double den = in.species_density[s], v0 = in.species_v0[s];
+  if (in.iptcldist == 1) return den * (sv * sv) * std::exp(-(sv * sv) / 2.0) / std::sqrt(2.0 * kPi);
+  if (in.iptcldist == 2)
+    return den * (std::exp(-((sv + v0) * (sv + v0)) / (2.0 * T / m)) + std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T / m))) /
+           (std::sqrt(8.0 * kPi) * T / m);
+  if (in.iptcldist == 3)
+    return den * std::exp(-(sv * sv) / (2.0 * T / m)) / (std::sqrt(2.0 * kPi) * T / m) +
+           (1.0 - den) * std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T2 / m)) / (std::sqrt(2.0 * kPi) * T2 / m);
+  return den * std::exp(-((sv - v0) * (sv - v0)) / (2.0 * T / m)) / (std::sqrt(2.0 * kPi) * T / m);
+}
+
+// what output_ptcldist does with the sums over ranks (src/pic1dp_output.F90:328-331, :361-453): linear total +=
+// pertb, scaling by the histogram cell sizes, full-f pertb = total - f0; in place on host arrays
+static void finish_ptcldist(const pic1dp_input &in, int isp, double *mxv, double *txv, double *pxv, double *mv, double *tv,
+                            double *pv) {
+  const int nxo = in.nx_opd, nvo = in.nv_opd;
+  const size_t nxv = static_cast<size_t>(nxo) * nvo;
+  if (in.linear == 1) {  // :328-331
+    for (size_t i = 0; i < nxv; ++i) txv[i] = txv[i] + pxv[i];
+    for (int i = 0; i < nvo; ++i) tv[i] = tv[i] + pv[i];
+  }
+  const double delv_inv = static_cast<double>(nvo - 1) / (2.0 * in.v_max);  // :203-205
+  const double delx_inv = static_cast<double>(nxo) / in.lx;
+  for (size_t i = 0; i < nxv; ++i) {
+    mxv[i] = mxv[i] * delx_inv * delv_inv;
+    txv[i] = txv[i] * delx_inv * delv_inv;
+  }
+  for (int i = 0; i < nvo; ++i) {
+    mv[i] = mv[i] * delv_inv;
+    tv[i] = tv[i] * delv_inv;
+  }
+  if (in.deltaf == 1) {
+    for (size_t i = 0; i < nxv; ++i) pxv[i] = pxv[i] * delx_inv * delv_inv;
+    for (int i = 0; i < nvo; ++i) pv[i] = pv[i] * delv_inv;
+  } else {  // :370-453
+    for (int iv = 0; iv < nvo; ++iv) {
+      const double sv = (static_cast<double>(iv) / static_cast<double>(nvo - 1) * 2.0 - 1.0) * in.v_max;
+      const double f0 = output_f0(in, isp, sv);
+      for (int ix = 0; ix < nxo; ++ix) pxv[static_cast<size_t>(iv) * nxo + ix] = txv[static_cast<size_t>(iv) * nxo + ix] - f0;
+      pv[iv] = tv[iv] - in.lx * f0;
+    }
+  }
+}
+
+int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *markr_xv, double *total_xv,
+                        double *pertb_xv, double *markr_v, double *total_v, double *pertb_v) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  if (int rc = require_loaded(c)) return rc;
+  const pic1dp_input &in = c->in;
+  const int nxo = in.nx_opd, nvo = in.nv_opd;
+  if (int rc = ensure_diag(c, isp)) return rc;
+  const size_t nxv = static_cast<size_t>(nxo) * nvo, ntot = 3 * nxv + 3 * nvo;
+  const double *hist = c->d_dist + ntot * isp;
+  if (finish && c->comm) {  // reduce a copy: the cached local histograms stay local
+    double *red = c->d_dist + ntot * in.nspecies;
+    HIP_TRY(hipMemcpyAsync(red, hist, sizeof(double) * ntot, hipMemcpyDeviceToDevice, c->st));
+    if (int rc = allreduce_doubles(c, red, ntot)) return rc;
+    hist = red;
+  } else if (finish && c->lay.nranks > 1) {
+    return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: take finish = 0 and reduce the local sums on the host");
+  }
+  std::vector<double> h(ntot);
+  HIP_TRY(hipStreamSynchronize(c->st));
+  HIP_TRY(hipMemcpy(h.data(), hist, sizeof(double) * ntot, hipMemcpyDeviceToHost));
+  double *mxv = h.data(), *txv = mxv + nxv, *pxv = txv + nxv, *mv = pxv + nxv, *tv = mv + nvo, *pv = tv + nvo;
+  if (finish) finish_ptcldist(in, isp, mxv, txv, pxv, mv, tv, pv);
+  auto give = [&](double *dst, const double *src, size_t n) {
+    if (dst) std::memcpy(dst, src, sizeof(double) * n);
+  };
+  give(markr_xv, mxv, nxv);
+  give(total_xv, txv, nxv);
+  give(pertb_xv, pxv, nxv);
+  give(markr_v, mv, nvo);
+  give(total_v, tv, nvo);
+  give(pertb_v, pv, nvo);
+  return 0;
+}
+
+int pic1dp_hip_ptcldist_finish(pic1dp_ctx *c, int32_t isp, double *markr_xv, double *total_xv, double *pertb_xv,
+                               double *markr_v, double *total_v, double *pertb_v) {
+  CHECK_CTX(c);
+  if (isp < 0 || isp >= c->in.nspecies) return fail(PIC1DP_ERR_ARG, "bad species index");
+  if (!markr_xv || !total_xv || !pertb_xv || !markr_v || !total_v || !pertb_v) return fail(PIC1DP_ERR_ARG, "null array");
+  finish_ptcldist(c->in, isp, markr_xv, total_xv, pertb_xv, markr_v, total_v, pertb_v);
+  return 0;
+}
+
+
+}  // extern "C"

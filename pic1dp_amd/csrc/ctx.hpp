@@ -1,0 +1,277 @@
+// ctx.hpp -- what the translation units behind the C ABI share: the context (one process = one GPU = one HIP stream),
+// the error convention, the event spans, and the internal entry points one unit offers the others.
+//   capi.cpp           context, transfers, the hot path's sequencing and the state machine of the lazy call sites
+//   capi_comm.cpp      RCCL communicator, the one-hop exchange's set-up, the charge sum over ranks
+//   capi_diag.cpp      diagnostics of output_all
+//   capi_optimize.cpp  marker optimisation events (merge / remove / split)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../../include/pic1dp_hip.h"
+#include "kernels.hpp"
+#include "loader.hpp"
+#include "multirand.hpp"
+#include "optimize.hpp"
+#include "rccl_dyn.hpp"
+
+using namespace pic1dp;
+
+namespace pic1dp_host {
+
+// the message pic1dp_hip_last_error() hands out (thread-local, capi.cpp); returns code
+int fail(int code, const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(PIC1DP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+#define CHECK_CTX(c) \
+  if (!(c)) return fail(PIC1DP_ERR_ARG, "null context")
+
+constexpr double kPi = 3.14159265358979323846264;        // PETSC_PI
+constexpr double kSqrtEps = 1.490116119384766e-08;       // PETSC_SQRT_MACHINE_EPSILON
+constexpr int kTagFused = 100, kTagPush = 101, kTagDeposit = 102, kTagStepHalf = 103, kTagStepFull = 104, kTagStepOne = 106,
+              kNumTags = 128;
+constexpr int64_t kHistCap = 1 << 20;
+constexpr bool kCarryOneExpDefault = false;  // k_step_one with the one-exp form of -f0'/f0: carry it (72 B) or evaluate it again (56 B)
+constexpr int kEnergyBlocks = 1024;
+constexpr size_t kCuLds = 160 * 1024, kStaticLds = 1024;  // LDS of a CU; static LDS of a marker kernel (the exp table)
+// states of the lazy call sites (pic1dp_ctx::lz)
+enum { LZ_CLEAN = 0, LZ_PUSH1, LZ_HALF, LZ_PUSH2 };
+
+struct Species {
+  int64_t nalloc = 0, np = 0;
+  PSet set[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  double *p = nullptr;
+  double *t2 = nullptr;   // carry of -f0'/f0 between the whole-step kernels
+  uint64_t t2_version = 0;  // state_version whose step-start velocities the values in t2 belong to (0: none)
+  double *slab[2] = {nullptr, nullptr};  // tiled storage of set 0 (+ p) and of the RK ping-pong set (kernels.hpp)
+  double *rho = nullptr;  // slice of rho_sp
+  SpeciesConst sc{};
+};
+
+struct EvPair {
+  hipEvent_t a, b;
+  int tag;
+};
+
+}  // namespace pic1dp_host
+using namespace pic1dp_host;
+
+struct pic1dp_ctx {
+  pic1dp_input in{};
+  pic1dp_layout lay{};
+  int device = 0, num_cu = 256;
+  hipStream_t st = nullptr;
+  int cur = 0;  // which particle set is particle_x/v/w right now
+  std::vector<Species> sp;
+  int blk0 = 0, nblk = 1;  // owned reference blocks [blk0, blk0+nblk)
+  std::vector<int64_t> blk_alloc;                 // [nblk] allocated slots of each owned block
+  std::vector<std::vector<int64_t>> blk_np;       // [nspecies][nblk] valid markers
+  std::vector<Multirand> blk_rng;                 // [nblk] generators as particle_load left them
+  bool rng_ready = false;
+  int imerge = 0, iremove = 0, isplit = 0;        // particle_imerge / _iremove / _isplit
+  bool loaded = false;
+  bool charge_pending = false;  // charge_local ran, waiting for charge_reduced
+  // field
+  double *d_rho_sp = nullptr, *d_charge = nullptr, *d_chargeden = nullptr, *d_E = nullptr;
+  // The species accumulators and the six sums of the prediction exist three times (kernels.hpp FusedSolve): d_rho_sp /
+  // Species::rho / fa.rho_sp / d_pred always name the set the marker kernels deposit into NOW (acc_idx); all sets are
+  // zero whenever no fused launch sequence is under way
+  double *d_rho_all = nullptr, *d_pred_all = nullptr;
+  size_t rho_set_doubles = 0, pred_set_doubles = 0;
+  int acc_idx = 0;
+  int fuse_solve = 1;           // PIC1DP_FUSE_SOLVE=0: the field solve always in a launch of its own; 2: fused whatever the grid
+  bool fused_pending = false;   // step(): the last marker launch left the solve of its step to the next launch's prologue
+  int fused_dirty = -1;         // accumulator set the last fused launch read (still holding that step's deposits), or -1
+  FusedSolve fuse_args{};       // what the next marker launch's prologue has to solve (on = 1), consumed by step_particles
+  double *d_mode_re = nullptr, *d_mode_im = nullptr, *d_fre = nullptr, *d_fim = nullptr;
+  double *d_ginv = nullptr, *d_hist = nullptr, *d_scratch = nullptr, *d_dist = nullptr;
+  // one pass per step (kernels_step.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
+  // prediction accumulators [nspecies][1 + 2 nm][nx], the combined half-step charge density
+  double *d_tabA = nullptr, *d_tabB = nullptr, *d_pred = nullptr, *d_cd_h = nullptr, *d_mode_h = nullptr;
+  int pair_plain = 0;              // PIC1DP_PAIR_PLAIN
+  int osub_req = 0;                // PIC1DP_OSUB: grid size of the marker kernels in units of the resident one (0: auto)
+  int pred_kind = 0;               // 0 no one-pass step here, 1 prediction tiles (k_step_one), 2 six sums (k_step_sums)
+  int pred_private = 0;            // pred_kind 2 and E0, Eh, the table tiles and the private sums of two workgroups fit a
+                                   // CU's LDS: the sums are taken by k_step_one<PRIV> (thread-private LDS slots)
+  PredTab pred_tab{};              // kind 2: sums / Gram matrix of the kept mode's tables (host, libm)
+  int eh_modes = 0;                // kind 2: where the kept mode of the Eh about to be used lies: 0 nowhere, 1 fa.mode_*, 2 d_mode_h
+  bool charge_pending_pred = false;  // kind 2: charge_local handed out the six sums, not a charge vector
+  double *d_Ehn = nullptr;         // half-step field predicted for the NEXT step (d_Eh stays the last step's)
+  double *d_pack = nullptr;        // [2 + 2 nmode][nx] one all-reduce per one-pass step (RCCL path)
+  int predict = 1;                 // PIC1DP_PREDICT=0: always two passes per step
+  uint64_t pred_version = 0;       // state_version the accumulators in d_pred belong to (0: none)
+  uint64_t eh_version = 0;         // state_version d_Eh has been predicted for (step() path)
+  uint64_t field_version = 1, eh_field_version = 0, modes_field_version = 0;  // who wrote d_E last
+  double *d_stage = nullptr;  // contiguous staging buffer between host arrays and the tiled marker arrays
+  double *d_Eh = nullptr;  // field after the first sub-step of the last whole-step call
+  // The reference's three call sites at whole-step cost (see "lazy call sites"
+  // below): a push is only noted; the collect_charge that follows runs the
+  // whole-step kernel instead of push + deposit.
+  int lazy_calls = 1;            // PIC1DP_LAZY_CALLS=0: every call launches its own kernel at once
+  // collect_charge leaves its last step to the solve_field that follows (one launch less per sub-step):
+  // 0 field_chargeden is current; 1 d_charge holds the summed charge1, its scaling is pending; 2 (one rank) the
+  // species accumulators hold the deposits, species sum and scaling pending; 3 (one rank, mode-filter solve, few
+  // modes) k_step_one's prediction accumulators hold the charge, combination with the kept modes, species sum and
+  // scaling pending; 4 (one rank, mode-filter solve) the six sums of the prediction are pending: the kept mode's
+  // content of chargeden follows from them.  materialize_cd() before anything else looks at charge, chargeden or the
+  // accumulators.
+  int cd_lazy = 0;
+  // field_chargeden holds only the kept mode's content of the half-step charge density (collect_charge after a
+  // noted push(1) served from the six sums, pred_kind 2): all solve_field looks at, but not what the reference
+  // holds there.  get_field rebuilds the full vector on one rank (rebuild_half_step_chargeden); cleared by
+  // everything that writes field_chargeden.
+  bool cd_kept_mode_only = false;
+  int lz = 0;                    // LZ_CLEAN / LZ_PUSH1 / LZ_HALF / LZ_PUSH2
+  double *d_E0 = nullptr;        // field the noted push(1) saw
+  double *d_rho_dummy = nullptr; // accumulator of a wrap-only deposit
+  int carry = -1;          // whole-step kernels carry -f0'/f0 between them: -1 where measured to pay, 0 never
+                           // (PIC1DP_CARRY=0), 1 wherever -f0'/f0 bears an exp, 2 also two-stream2 between k_step_half / _full
+  int step_mode = 0;       // 0 auto (recompute path when the LDS allows), 1 two fused sub-steps
+  int field_solver = 0;    // 0 the reference's mode-filter DFT solve, 1 finite-difference tridiagonal (opt-in)
+  // marker state (bytes) above which k_step_half / k_step_full stream non-temporally
+  // The two kernels leave the caches to each other, so the pairs were compared inside
+  // one process on the same arrays (tools/ab_nt.py, nx = 1024, half + full in ms):
+  //   markers   plain/plain   nt/nt    half nt, full plain   half plain, full nt
+  //   6.4e6       0.102*      0.114         0.105                 0.106
+  //   1e7         0.159       0.169         0.158*                0.158*
+  //   2e7         0.372       0.332         0.326                 0.319*
+  //   3e7         0.539       0.497         0.492                 0.483*
+  //   5e7         0.886       0.829*        0.835                 0.828*
+  //   1e8         1.745       1.657*        1.676                 1.678
+  // => both plain below 288 MiB of marker state, the full kernel non-temporal above
+  //    it, the half kernel only above 2 GiB
+  double nt_threshold_half = 2048.0 * 1048576.0, nt_threshold_full = 288.0 * 1048576.0;
+  int64_t hist_count = 0;
+  // marker diagnostics of output_all: one fused pass per species (histograms +
+  // kinetic sums), kept until the markers change
+  uint64_t state_version = 1;              // bumped by everything that writes marker arrays
+  std::vector<uint64_t> diag_version;      // [nspecies] version the cached results belong to
+  std::vector<double> diag_sums;           // [nspecies][3]
+  double *d_diag_part = nullptr;           // [nspecies][3 * diag_max_blocks] per-workgroup partial sums of the pass
+  std::vector<char> diag_pending;          // [nspecies] a pass ran, its partial sums are still on the device
+  std::vector<int> diag_blocks;            // [nspecies] workgroups of that pass
+  int fuse_output = 0;                     // take the diagnostics inside k_step_full on steps output_all follows
+  int64_t diag_passes = 0;                 // separate k_ptcldist passes launched so far
+  int64_t fused_solves = 0;                // marker launches whose prologue solved the previous step's field
+  int32_t itime = 0;
+  double time = 0.0;
+  GridConst grid{};
+  FieldArgs fa{};
+  // comm
+  ncclComm_t comm = nullptr;
+  // one-hop charge exchange (kernels_field.hip exchange_charge): the own area, the peers'
+  // areas as mapped through hipIpc, and the running exchange number
+  struct Xchg {
+    void *local = nullptr;                       // flags + slots of this rank
+    void *peer[XCHG_MAX_RANKS] = {nullptr};      // every rank's area as mapped here (own: local)
+    bool opened[XCHG_MAX_RANKS] = {false};       // peer[q] came from hipIpcOpenMemHandle
+    unsigned long long *err = nullptr;           // pinned host word the kernel reports a time-out in
+    unsigned long long epoch = 0;
+    long long timeout_ticks = 0;
+    bool connected = false;
+    int memkind = 0;                             // 1 fine-grained, 2 uncached, 3 plain hipMalloc
+  } xc;
+  int allreduce_kind = 0;  // 0 auto (RCCL when a communicator exists), 1 RCCL, 2 one-hop exchange
+  // launch
+  int threads_req = 0, bpc_req = 0;
+  // timing
+  bool timers_on = false, stats_on = false;
+  std::vector<EvPair> evpool;
+  size_t ev_used = 0;
+  double acc_ms[kNumTags] = {0};
+  int64_t acc_n[kNumTags] = {0};
+  // what the marker kernel launched last under a tag moves per marker (pic1dp_hip_kernel_bytes)
+  struct KernelBytes {
+    double rd = 0.0, wr = 0.0, carry = 0.0;
+    char name[64] = {0};
+  } kbytes[kNumTags];
+};
+
+namespace pic1dp_host {
+
+inline int ev_resolve(pic1dp_ctx *c) {
+  if (c->ev_used == 0) return 0;
+  HIP_TRY(hipStreamSynchronize(c->st));
+  for (size_t i = 0; i < c->ev_used; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->evpool[i].a, c->evpool[i].b));
+    c->acc_ms[c->evpool[i].tag] += ms;
+    c->acc_n[c->evpool[i].tag] += 1;
+  }
+  c->ev_used = 0;
+  return 0;
+}
+
+// bracket helper: records a start event on construction (if enabled) and the
+// stop event in end(); pairs are resolved to milliseconds lazily (ev_resolve)
+struct Span {
+  pic1dp_ctx *c;
+  long idx = -1;
+  int rc = 0;
+  Span(pic1dp_ctx *c_, int tag, bool on) : c(c_) {
+    if (!on) return;
+    if (c->ev_used == c->evpool.size() && c->evpool.size() >= (1u << 16)) {
+      // a long run that reads its timers only at the end: fold what has been recorded into
+      // the accumulators (one stream synchronisation per 65 536 spans) and reuse the pool
+      if ((rc = ev_resolve(c)) != 0) return;
+    }
+    if (c->ev_used == c->evpool.size()) {
+      EvPair p{};
+      if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
+        rc = fail(PIC1DP_ERR_HIP, "hipEventCreate failed");
+        return;
+      }
+      c->evpool.push_back(p);
+    }
+    idx = static_cast<long>(c->ev_used++);
+    c->evpool[idx].tag = tag;
+    if (hipEventRecord(c->evpool[idx].a, c->st) != hipSuccess) rc = fail(PIC1DP_ERR_HIP, "hipEventRecord failed");
+  }
+  int end() {
+    if (idx >= 0 && hipEventRecord(c->evpool[idx].b, c->st) != hipSuccess)
+      return fail(PIC1DP_ERR_HIP, "hipEventRecord failed");
+    return rc;
+  }
+};
+
+// ---- what capi.cpp offers the other units ----
+int require_loaded(pic1dp_ctx *c);        // markers loaded, no charge_local pending; memory as eager calls would have left it
+int materialize(pic1dp_ctx *c);           // a noted push becomes memory
+int materialize_cd(pic1dp_ctx *c);        // what collect_charge left to the next solve_field becomes field_chargeden
+int ensure_second_set(pic1dp_ctx *c);     // the second slab (RK ping-pong set; re-packing target of the optimiser)
+int put_range(pic1dp_ctx *c, double *arr, int64_t off, const double *host, int64_t cnt);
+int get_range(pic1dp_ctx *c, const double *arr, int64_t off, double *host, int64_t cnt);
+// ---- capi_comm.cpp ----
+int allreduce_charge(pic1dp_ctx *c);
+int allreduce_doubles(pic1dp_ctx *c, double *d, size_t n);
+int reduce_charge(pic1dp_ctx *c);
+bool xchg_active(const pic1dp_ctx *c);
+XchgArgs next_xchg_args(pic1dp_ctx *c);
+int xchg_check(pic1dp_ctx *c);
+void comm_release(pic1dp_ctx *c);         // communicator and exchange mappings, for destroy
+// ---- capi_optimize.cpp ----
+void optimize_due_at(const pic1dp_ctx *c, double time0, bool due[3]);  // which events a step starting at time0 fires
+void optimize_due(const pic1dp_ctx *c, bool due[3]);
+bool optimize_due_any(const pic1dp_ctx *c);
+// ---- capi_diag.cpp ----
+int diag_buffers(pic1dp_ctx *c);
+int diag_max_blocks(const pic1dp_ctx *c);
+size_t dist_len(const pic1dp_input &in);
+
+}  // namespace pic1dp_host
