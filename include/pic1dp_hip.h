@@ -461,7 +461,9 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
  * one-pass-per-step kernel k_step_one (second sub-step + prediction of the next first
  * sub-step's charge); which = 7: number of k_step_one / k_step_sums launches so far whose
  * prologue solved the field of the previous step (one launch per time step inside
- * pic1dp_hip_step: no field_solve_electric launch in between), *ms = 0 */
+ * pic1dp_hip_step: no field_solve_electric launch in between), *ms = 0; which = 8:
+ * *launches = bytes marker optimisation events (pic1dp_hip_particle_optimize) have moved
+ * between host and device so far, *ms = 0 */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

@@ -1825,10 +1825,11 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 7) return fail(PIC1DP_ERR_ARG, "which must be 0..7");
-  if (which == 5 || which == 7) {  // separate diagnostics passes (k_ptcldist) / field solves inside marker launches: counts
+  if (which < 0 || which > 8) return fail(PIC1DP_ERR_ARG, "which must be 0..8");
+  if (which == 5 || which == 7 || which == 8) {  // counts: separate diagnostics passes (k_ptcldist), field solves inside
+                                                 // marker launches, bytes marker optimisation events moved over PCIe
     if (ms) *ms = 0.0;
-    if (launches) *launches = which == 5 ? c->diag_passes : c->fused_solves;
+    if (launches) *launches = which == 5 ? c->diag_passes : (which == 7 ? c->fused_solves : c->opt_pcie_bytes);
     return 0;
   }
   if (int rc = ev_resolve(c)) return rc;

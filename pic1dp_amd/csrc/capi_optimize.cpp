@@ -1,5 +1,7 @@
 // capi_optimize.cpp -- marker optimisation events (particle_optimize -> particle_merge / particle_remove /
 // particle_split, src/pic1dp_particle.F90:356-813).
+#include <algorithm>
+
 #include "ctx.hpp"
 
 namespace pic1dp_host {
@@ -26,31 +28,204 @@ bool optimize_due_any(const pic1dp_ctx *c) {
 
 }  // namespace pic1dp_host
 
-extern "C" {
 
-int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optimized) {
-  CHECK_CTX(c);
-  if (flag_optimized) *flag_optimized = 0;
-  if (irk != 1 && irk != 2) return fail(PIC1DP_ERR_ARG, "irk must be 1 or 2");
-  bool due[3];
-  optimize_due(c, due);
-  if (irk != 2 || !(due[0] || due[1] || due[2])) return 0;
-  if (int rc = require_loaded(c)) return rc;
-  if (c->cur != 0) return fail(PIC1DP_ERR_STATE, "particle_optimize must follow the push of sub-step 2");
-  if ((due[1] || due[2]) && !c->rng_ready)
-    return fail(PIC1DP_ERR_STATE,
-                "particle_remove / particle_split continue the loader's random stream: load the markers with "
-                "pic1dp_hip_particle_load");
+namespace {
+
+// RAII for the event's device scratch (rare events: allocated and freed per use)
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) {
+    (void)hipFree(p);
+    p = nullptr;
+    return hipMalloc(&p, bytes ? bytes : 16);
+  }
+  template <class T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+// The event with the markers staying on the device (kernels_opt.hip): per block the |delta f|(v) histogram in the
+// reference's order of additions, one small key per marker to the host, the sequential walk there (optimize.cpp
+// plan_*: visiting order, swap-with-last, merge partners, the block's random stream), and what the walk decided back:
+// moves, merge pairs, the split parents and their velocity offsets.  4 B per marker over PCIe for a merge, 8 B
+// (typeremove 2) or 1 B (typeremove 1) for a remove, 1 B for a split, plus the lists -- instead of 64 B.  Bit for bit
+// what opt_merge / opt_remove / opt_split leave (tests/test_gpu_optimize.py, unchanged).
+int optimize_on_device(pic1dp_ctx *c, const bool due[3]) {
   const pic1dp_input &in = c->in;
   const int ns = in.nspecies, nb = c->nblk, nv = in.nv;
+  if (int rc = ensure_second_set(c)) return rc;  // the re-packing target
+  const OptGrid grid{in.lx, in.v_max, in.nx, nv};
+  // the layout the event starts from: valid markers of the owned blocks packed first, their tail slots behind
+  std::vector<std::vector<OptBlock>> ob(ns, std::vector<OptBlock>(nb));
   for (int s = 0; s < ns; ++s) {
-    int64_t sum = 0;
-    for (int b = 0; b < nb; ++b) sum += c->blk_np[s][b];
-    if (sum != c->sp[s].np) return fail(PIC1DP_ERR_STATE, "marker counts per block unknown (uploaded over several blocks)");
+    Species &S = c->sp[s];
+    int64_t voff = 0, toff = S.np;
+    for (int b = 0; b < nb; ++b) {
+      const int64_t na = c->blk_alloc[b], np = c->blk_np[s][b];
+      ob[s][b] = OptBlock{S.set[0].x, S.set[0].v, S.p, S.set[0].w, voff, np, toff};
+      voff += np;
+      toff += na - np;
+    }
   }
-  Span tm(c, PIC1DP_IWT_PARTICLE_OPTIMIZE, c->timers_on);
-  c->state_version++;
-  HIP_TRY(hipStreamSynchronize(c->st));
+  DevBuf d_hist, d_local, d_key, d_lists;
+  HIP_TRY(d_hist.alloc(sizeof(double) * ns * nv));
+  HIP_TRY(d_local.alloc(sizeof(double) * nv));
+  const double *thresholds[3] = {in.thshmerge, in.thshremove, in.thshsplit};
+  int *counters[3] = {&c->imerge, &c->iremove, &c->isplit};
+  std::vector<double> hist(static_cast<size_t>(ns) * nv), local(nv);
+  auto to_device = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+    c->opt_pcie_bytes += static_cast<int64_t>(bytes);
+    return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  auto to_host = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+    c->opt_pcie_bytes += static_cast<int64_t>(bytes);
+    return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) : hipSuccess;
+  };
+  for (int kind = 0; kind < 3; ++kind) {
+    if (!due[kind]) continue;
+    // particle_compute_dist_pertb_abs_v: block by block, summed in block order, then over processes (:356-403)
+    for (int s = 0; s < ns; ++s) {
+      double *h = &hist[static_cast<size_t>(s) * nv];
+      for (int b = 0; b < nb; ++b) {
+        HIP_TRY(opt_hist_block(ob[s][b], grid, c->blk_np[s][b], d_local.as<double>(), c->st));
+        HIP_TRY(to_host(local.data(), d_local.p, sizeof(double) * nv));
+        for (int i = 0; i < nv; ++i) h[i] = b == 0 ? local[i] : h[i] + local[i];
+      }
+    }
+    if (c->lay.nranks > 1 || c->comm) {
+      double *d = c->d_scratch;
+      if (static_cast<size_t>(ns) * nv > static_cast<size_t>(kEnergyBlocks) * 3)
+        return fail(PIC1DP_ERR_ARG, "nv too large for the reduction scratch");
+      HIP_TRY(hipMemcpy(d, hist.data(), sizeof(double) * ns * nv, hipMemcpyHostToDevice));
+      if (int rc = allreduce_doubles(c, d, static_cast<size_t>(ns) * nv)) return rc;
+      HIP_TRY(hipStreamSynchronize(c->st));
+      HIP_TRY(hipMemcpy(hist.data(), d, sizeof(double) * ns * nv, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(to_device(d_hist.p, hist.data(), sizeof(double) * ns * nv));
+    const double th = thresholds[kind][*counters[kind] - 1];
+    for (int b = 0; b < nb; ++b)
+      for (int s = 0; s < ns; ++s) {
+        const OptBlock &B = ob[s][b];
+        const double *h = &hist[static_cast<size_t>(s) * nv];
+        const double *dh = d_hist.as<double>() + static_cast<size_t>(s) * nv;
+        const double peak = *std::max_element(h, h + nv), limit = peak * th;
+        int64_t &np = c->blk_np[s][b];
+        if (np <= 0) continue;
+        if (c->blk_alloc[b] >= (static_cast<int64_t>(1) << 32)) return fail(PIC1DP_ERR_ARG, "a block of 2^32 slots or more");
+        // the moved markers' ids travel; the holes they move into are found on the device (opt_holes)
+        auto upload_moves = [&](const OptMoves &m, uint32_t *&d_pos, uint32_t *&d_id, size_t extra, char *&d_extra) -> int {
+          const size_t nm = m.id.size();
+          HIP_TRY(d_lists.alloc(sizeof(uint32_t) * 2 * (nm + 2) + extra + 64));
+          d_pos = d_lists.as<uint32_t>();
+          d_id = d_pos + nm;
+          d_extra = reinterpret_cast<char *>(d_lists.p) + ((sizeof(uint32_t) * 2 * nm + 15) & ~static_cast<size_t>(15));
+          HIP_TRY(to_device(d_id, m.id.data(), sizeof(uint32_t) * nm));
+          return 0;
+        };
+        if (kind == 0) {  // particle_merge
+          std::vector<uint32_t> keys(static_cast<size_t>(np));
+          HIP_TRY(d_key.alloc(sizeof(uint32_t) * np));
+          HIP_TRY(opt_merge_keys(B, grid, dh, limit, np, d_key.as<uint32_t>(), c->st));
+          HIP_TRY(hipStreamSynchronize(c->st));
+          HIP_TRY(to_host(keys.data(), d_key.p, sizeof(uint32_t) * np));
+          MergePlan plan;
+          plan_merge(keys.data(), np, static_cast<size_t>(in.nx) * nv * 2, plan);
+          const size_t npairs = plan.dst.size();
+          uint32_t *d_pos, *d_id;
+          char *d_extra;
+          if (int rc = upload_moves(plan.moves, d_pos, d_id, sizeof(uint32_t) * 2 * (npairs + 2) + sizeof(double) * 4 * npairs + 32, d_extra)) return rc;
+          double *d_scr = reinterpret_cast<double *>(d_extra);     // (16-byte aligned)
+          uint32_t *d_dst = reinterpret_cast<uint32_t *>(d_scr + 4 * npairs), *d_k = d_dst + npairs;
+          HIP_TRY(to_device(d_dst, plan.dst.data(), sizeof(uint32_t) * npairs));
+          HIP_TRY(to_device(d_k, plan.idk.data(), sizeof(uint32_t) * npairs));
+          HIP_TRY(opt_holes(d_k, static_cast<int64_t>(npairs), nullptr, plan.np_new, static_cast<int64_t>(plan.moves.id.size()), d_pos,
+                            c->st));
+          HIP_TRY(opt_merge_apply(B, grid, dh, limit, d_dst, d_k, static_cast<int64_t>(npairs), d_pos, d_id,
+                                  static_cast<int64_t>(plan.moves.id.size()), plan.moves.ghost, plan.np_new, d_scr, c->st));
+          np = plan.np_new;
+        } else if (kind == 1) {  // particle_remove
+          const bool by_threshold = in.typeremove == 1;
+          std::vector<uint8_t> skip;
+          std::vector<double> df;
+          HIP_TRY(d_key.alloc((by_threshold ? sizeof(uint8_t) : sizeof(double)) * np));
+          HIP_TRY(opt_remove_vals(B, grid, dh, peak, limit, by_threshold ? 1 : 0, np, d_key.as<uint8_t>(), d_key.as<double>(), c->st));
+          HIP_TRY(hipStreamSynchronize(c->st));
+          if (by_threshold) {
+            skip.resize(static_cast<size_t>(np));
+            HIP_TRY(to_host(skip.data(), d_key.p, sizeof(uint8_t) * np));
+          } else {
+            df.resize(static_cast<size_t>(np));
+            HIP_TRY(to_host(df.data(), d_key.p, sizeof(double) * np));
+          }
+          RemovePlan plan;
+          plan_remove(in, by_threshold ? skip.data() : nullptr, by_threshold ? nullptr : df.data(), c->blk_rng[b], np, plan);
+          uint32_t *d_pos, *d_id;
+          char *d_extra;
+          if (int rc = upload_moves(plan.moves, d_pos, d_id, sizeof(uint32_t) * (plan.gone_bits.size() + 4), d_extra)) return rc;
+          uint32_t *d_bits = reinterpret_cast<uint32_t *>(d_extra);
+          HIP_TRY(to_device(d_bits, plan.gone_bits.data(), sizeof(uint32_t) * plan.gone_bits.size()));
+          HIP_TRY(opt_holes(nullptr, 0, d_bits, plan.np_new, static_cast<int64_t>(plan.moves.id.size()), d_pos, c->st));
+          HIP_TRY(opt_remove_apply(B, grid, dh, peak, limit, by_threshold ? 1 : 0, 1.0 - in.remove_frac, d_pos, d_id,
+                                   static_cast<int64_t>(plan.moves.id.size()), plan.moves.ghost, plan.np_new, c->st));
+          np = plan.np_new;
+        } else {  // particle_split
+          std::vector<uint8_t> flag(static_cast<size_t>(np));
+          HIP_TRY(d_key.alloc(sizeof(uint8_t) * np));
+          HIP_TRY(opt_split_flags(B, grid, dh, limit, np, d_key.as<uint8_t>(), c->st));
+          HIP_TRY(hipStreamSynchronize(c->st));
+          HIP_TRY(to_host(flag.data(), d_key.p, sizeof(uint8_t) * np));
+          SplitPlan plan;
+          plan_split(in, flag.data(), c->blk_rng[b], c->blk_alloc[b], np, plan);
+          const size_t nsp = plan.ks.size();
+          HIP_TRY(d_lists.alloc(sizeof(double) * plan.dv.size() + sizeof(uint32_t) * nsp + 64));
+          double *d_dv = d_lists.as<double>();
+          uint32_t *d_ks = reinterpret_cast<uint32_t *>(d_dv + plan.dv.size());
+          HIP_TRY(to_device(d_ks, plan.ks.data(), sizeof(uint32_t) * nsp));
+          HIP_TRY(to_device(d_dv, plan.dv.data(), sizeof(double) * plan.dv.size()));
+          HIP_TRY(opt_split_apply(B, np, d_ks, d_dv, static_cast<int64_t>(nsp), in.split_ngroup, in.deltaf, c->st));
+          np = plan.np_new;
+        }
+        HIP_TRY(hipStreamSynchronize(c->st));  // (the lists are freed / reused next)
+      }
+    *counters[kind] += 1;
+  }
+  // re-pack into the other slab -- valid markers of all blocks first, their tail slots behind, as the layout wants
+  // them -- and make it the species' storage
+  for (int s = 0; s < ns; ++s) {
+    Species &S = c->sp[s];
+    const int64_t as = slab_array_stride(S.nalloc + 2);
+    double *nx_ = S.slab[1], *nv_ = S.slab[1] + as, *nw_ = S.slab[1] + 2 * as, *np_ = S.slab[1] + 3 * as;
+    S.np = 0;
+    for (int b = 0; b < nb; ++b) S.np += c->blk_np[s][b];
+    int64_t voff = 0, toff = S.np;
+    for (int b = 0; b < nb; ++b) {
+      const int64_t na = c->blk_alloc[b], np = c->blk_np[s][b];
+      HIP_TRY(opt_copy_segment(ob[s][b], 0, np, nx_, nv_, np_, nw_, voff, c->st));
+      HIP_TRY(opt_copy_segment(ob[s][b], np, na - np, nx_, nv_, np_, nw_, toff, c->st));
+      voff += np;
+      toff += na - np;
+    }
+    HIP_TRY(hipStreamSynchronize(c->st));
+    std::swap(S.slab[0], S.slab[1]);
+    S.set[0].x = S.slab[0];
+    S.set[0].v = S.slab[0] + as;
+    S.set[0].w = S.slab[0] + 2 * as;
+    S.p = S.slab[0] + 3 * as;
+    S.set[1].x = S.slab[1];
+    S.set[1].v = in.linear == 1 ? S.set[0].v : S.slab[1] + as;
+    S.set[1].w = in.deltaf == 0 ? S.set[0].w : S.slab[1] + 2 * as;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// the event on host copies of the owned blocks (PIC1DP_OPT_HOST=1): every marker crosses PCIe twice, 64 B in all
+static int optimize_on_host(pic1dp_ctx *c, const bool due[3]) {
+  const pic1dp_input &in = c->in;
+  const int ns = in.nspecies, nb = c->nblk, nv = in.nv;
   // host copy of every owned block, full allocation (valid markers + tail slots)
   struct Block {
     std::vector<double> a[4];  // x v p w
@@ -130,9 +305,38 @@ int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optim
       toff += na - np;
     }
   }
+  for (int s = 0; s < ns; ++s) c->opt_pcie_bytes += 2 * 32 * c->sp[s].nalloc;
+  return 0;
+}
+
+int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optimized) {
+  CHECK_CTX(c);
+  if (flag_optimized) *flag_optimized = 0;
+  if (irk != 1 && irk != 2) return fail(PIC1DP_ERR_ARG, "irk must be 1 or 2");
+  bool due[3];
+  optimize_due(c, due);
+  if (irk != 2 || !(due[0] || due[1] || due[2])) return 0;
+  if (int rc = require_loaded(c)) return rc;
+  if (c->cur != 0) return fail(PIC1DP_ERR_STATE, "particle_optimize must follow the push of sub-step 2");
+  if ((due[1] || due[2]) && !c->rng_ready)
+    return fail(PIC1DP_ERR_STATE,
+                "particle_remove / particle_split continue the loader's random stream: load the markers with "
+                "pic1dp_hip_particle_load");
+  const pic1dp_input &in = c->in;
+  const int ns = in.nspecies, nb = c->nblk;
+  for (int s = 0; s < ns; ++s) {
+    int64_t sum = 0;
+    for (int b = 0; b < nb; ++b) sum += c->blk_np[s][b];
+    if (sum != c->sp[s].np) return fail(PIC1DP_ERR_STATE, "marker counts per block unknown (uploaded over several blocks)");
+  }
+  Span tm(c, PIC1DP_IWT_PARTICLE_OPTIMIZE, c->timers_on);
+  c->state_version++;
+  HIP_TRY(hipStreamSynchronize(c->st));
+  const char *eh = std::getenv("PIC1DP_OPT_HOST");  // (read per event: rare)
+  const bool on_host = eh && std::atoi(eh) != 0;
+  if (int rc = on_host ? optimize_on_host(c, due) : optimize_on_device(c, due)) return rc;
   if (flag_optimized) *flag_optimized = 1;
   return tm.end();
 }
-
 
 }  // extern "C"

@@ -167,6 +167,7 @@ struct pic1dp_ctx {
   std::vector<char> diag_pending;          // [nspecies] a pass ran, its partial sums are still on the device
   std::vector<int> diag_blocks;            // [nspecies] workgroups of that pass
   int fuse_output = 0;                     // take the diagnostics inside k_step_full on steps output_all follows
+  int64_t opt_pcie_bytes = 0;              // bytes marker optimisation events have moved between host and device
   int64_t diag_passes = 0;                 // separate k_ptcldist passes launched so far
   int64_t fused_solves = 0;                // marker launches whose prologue solved the previous step's field
   int32_t itime = 0;

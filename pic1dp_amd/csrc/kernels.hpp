@@ -323,6 +323,43 @@ hipError_t launch_ptcldist(const double *x, const double *v, const double *p, co
                            int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
                            double *out, double *partial, int num_cu, hipStream_t st);
 int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu);
+// ---- marker optimisation events (kernels_opt.hip; host side of the sequential part: optimize.hpp plan_*) ----
+// one reference rank block of a species inside the species' packed (tiled) arrays: block-local marker i lies at global
+// marker voff + i while i < nvalid0 (the block's valid markers when the event began), else at toff + (i - nvalid0) (its
+// tail slots); nvalid0 is the LAYOUT's split point, fixed during an event -- the block's current count travels apart
+struct OptBlock {
+  double *x, *v, *p, *w;
+  int64_t voff, nvalid0, toff;
+};
+struct OptGrid {
+  double lx, v_max;
+  int nx, nv;
+};
+constexpr uint32_t OPT_KEY_IMPORTANT = 0xFFFFFFFFu;
+// this block's |delta f|(v) into hist[nv] (device), every bin summed in storage order; synchronises the stream
+hipError_t opt_hist_block(const OptBlock &b, const OptGrid &g, int64_t np, double *hist, hipStream_t st);
+hipError_t opt_merge_keys(const OptBlock &b, const OptGrid &g, const double *hist, double limit, int64_t np, uint32_t *keys,
+                          hipStream_t st);
+hipError_t opt_remove_vals(const OptBlock &b, const OptGrid &g, const double *hist, double peak, double limit, int by_threshold,
+                           int64_t np, uint8_t *skip, double *df, hipStream_t st);
+hipError_t opt_split_flags(const OptBlock &b, const OptGrid &g, const double *hist, double limit, int64_t np, uint8_t *flag,
+                           hipStream_t st);
+// holes[nholes]: the positions below np_new whose marker is gone, ascending (gone: the ids listed, or -- gone_bits
+// non-null -- one bit per position); fails when their number is not nholes
+hipError_t opt_holes(const uint32_t *gone_ids, int64_t ngone, const uint32_t *gone_bits, int64_t np_new, int64_t nholes,
+                     uint32_t *holes, hipStream_t st);
+// scratch: [4 npairs] doubles.  Indices are block-local, 32 bits (a block holds < 2^32 slots)
+hipError_t opt_merge_apply(const OptBlock &b, const OptGrid &g, const double *hist, double limit, const uint32_t *dst,
+                           const uint32_t *idk, int64_t npairs, const uint32_t *move_pos, const uint32_t *move_id, int64_t nmoves,
+                           int64_t ghost, int64_t np_new, double *scratch, hipStream_t st);
+hipError_t opt_remove_apply(const OptBlock &b, const OptGrid &g, const double *hist, double peak, double limit, int by_threshold,
+                            double keep_scale, const uint32_t *move_pos, const uint32_t *move_id, int64_t nmoves, int64_t ghost,
+                            int64_t np_new, hipStream_t st);
+hipError_t opt_split_apply(const OptBlock &b, int64_t parents, const uint32_t *ks, const double *dv, int64_t nsplit, int ng, int deltaf,
+                           hipStream_t st);
+hipError_t opt_copy_segment(const OptBlock &b, int64_t i0, int64_t n, double *dx, double *dv, double *dp, double *dw, int64_t doff,
+                            hipStream_t st);
+
 // div_lx's / div_const's algorithm (reciprocal + two FMA corrections) with the host's fma against the true
 // quotient on n generated operands: the number of results that differ in any bit (hostcheck.cpp)
 int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n);

@@ -161,4 +161,111 @@ void opt_split(const pic1dp_input &in, double threshold, const double *hist, Mul
   np = parents + added;
 }
 
+namespace {
+
+// the final arrangement against the original one: position pos holds marker id_at[pos]; a position that does not hold
+// its own marker any more is a hole that a marker from beyond the new count has moved into
+void collect_moves(const std::vector<int64_t> &id_at, int64_t np_new, OptMoves &m) {
+  m.id.clear();
+  for (int64_t pos = 0; pos < np_new; ++pos)
+    if (id_at[pos] != pos) m.id.push_back(static_cast<uint32_t>(id_at[pos]));
+}
+
+}  // namespace
+
+void plan_merge(const uint32_t *keys, int64_t np, size_t nslots, MergePlan &plan) {
+  plan = MergePlan{};
+  std::vector<uint32_t> key_at(keys, keys + np);
+  std::vector<int64_t> id_at(static_cast<size_t>(np));
+  for (int64_t i = 0; i < np; ++i) id_at[i] = i;
+  std::vector<int64_t> waiting(nslots, -1);  // position of the marker waiting in a slot (opt_merge)
+  for (int64_t k = 0; k < np; ++k) {
+    const uint32_t key = key_at[k];
+    if (key == 0xFFFFFFFFu) continue;
+    int64_t &slot = waiting[key];
+    if (slot < 0) {
+      slot = k;
+      continue;
+    }
+    const int64_t j = slot;
+    plan.dst.push_back(static_cast<uint32_t>(j));
+    plan.idk.push_back(static_cast<uint32_t>(id_at[k]));
+    slot = -1;
+    const int64_t last = np - 1;
+    if (k < last) {  // the last valid marker takes the place of k and is looked at next
+      key_at[k] = key_at[last];
+      id_at[k] = id_at[last];
+      np = last;
+      --k;
+    } else {
+      np = last;
+      plan.moves.ghost = id_at[k];  // (the loop ends here)
+    }
+  }
+  plan.np_new = np;
+  const int64_t ghost = plan.moves.ghost;
+  collect_moves(id_at, np, plan.moves);
+  plan.moves.ghost = ghost;
+}
+
+void plan_remove(const pic1dp_input &in, const uint8_t *skip, const double *df, Multirand &rng, int64_t np, RemovePlan &plan) {
+  plan = RemovePlan{};
+  const bool by_threshold = in.typeremove == 1;
+  std::vector<uint8_t> skip_at;
+  std::vector<double> df_at;
+  if (by_threshold)
+    skip_at.assign(skip, skip + np);
+  else
+    df_at.assign(df, df + np);
+  std::vector<int64_t> id_at(static_cast<size_t>(np));
+  for (int64_t i = 0; i < np; ++i) id_at[i] = i;
+  for (int64_t k = 0; k < np; ++k) {
+    if (by_threshold && skip_at[k]) continue;
+    const double dice = rng.real();
+    const bool out = by_threshold ? dice < in.remove_frac : dice > df_at[k];
+    if (!out) continue;  // (the survivor's weights are rescaled on the device)
+    const int64_t last = np - 1;
+    if (k < last) {
+      if (by_threshold)
+        skip_at[k] = skip_at[last];
+      else
+        df_at[k] = df_at[last];
+      id_at[k] = id_at[last];
+      np = last;
+      --k;
+    } else {
+      np = last;
+      plan.moves.ghost = id_at[k];  // (the loop ends here)
+    }
+  }
+  plan.np_new = np;
+  const int64_t ghost = plan.moves.ghost;
+  collect_moves(id_at, np, plan.moves);
+  plan.moves.ghost = ghost;
+  plan.gone_bits.assign(static_cast<size_t>((np + 31) / 32), 0u);
+  for (int64_t pos = 0; pos < np; ++pos)
+    if (id_at[pos] != pos) plan.gone_bits[pos >> 5] |= 1u << (pos & 31);
+}
+
+void plan_split(const pic1dp_input &in, const uint8_t *flag, Multirand &rng, int64_t nalloc, int64_t np, SplitPlan &plan) {
+  plan = SplitPlan{};
+  plan.np_new = np;
+  const int ng = in.split_ngroup;
+  const int64_t children = 2 * static_cast<int64_t>(ng) - 1;
+  if (nalloc - np < children) return;
+  std::vector<double> dv(ng);
+  int64_t added = 0;
+  const int64_t parents = np;
+  for (int64_t k = 0; k < parents; ++k) {
+    if (nalloc - (parents + added) < children) break;
+    if (!flag[k]) continue;
+    rng.fill_gaussian(dv.data(), ng);
+    for (double &d : dv) d = d * 2.0 * in.v_max / static_cast<double>(in.nv) * in.split_dv_sig_frac;
+    plan.ks.push_back(static_cast<uint32_t>(k));
+    plan.dv.insert(plan.dv.end(), dv.begin(), dv.end());
+    added += children;
+  }
+  plan.np_new = parents + added;
+}
+
 }  // namespace pic1dp

@@ -188,3 +188,43 @@ def test_call_site_path_needs_the_library_clock(amd):
     assert with_clock.local_sizes()[1] == counts[-1]
     without = fresh()
     assert drive(without, 6, False) == [] and without.local_sizes()[1] == 90000
+
+
+@pytest.mark.parametrize("kind,kw", [
+    ("merge", dict(nmerge=1, tmerge=[0.1], thshmerge=[0.5])),
+    ("remove_profile", dict(nremove=1, tremove=[0.1], typeremove=2)),
+    ("remove_threshold", dict(nremove=1, tremove=[0.1], typeremove=1, thshremove=[0.4], remove_frac=0.7)),
+    ("split", dict(nsplit=1, tsplit=[0.1], thshsplit=[0.3], split_ngroup=3)),
+], ids=lambda v: v if isinstance(v, str) else "")
+def test_event_moves_keys_not_markers_over_pcie(amd, monkeypatch, kind, kw):
+    """the markers stay on the device during an event -- |delta f|(v) is summed there (in the
+    reference's order of additions), one small key per marker goes to the host for the sequential walk, and the
+    walk's decisions come back: at most 9 B per marker between host and device (the host-side pass moves 64 per
+    allocated slot), with the same markers afterwards as the pass on host copies (PIC1DP_OPT_HOST=1)."""
+    n = 2_000_000
+    base = dict(nparticle_max=n + n // 2, species_nparticle_init=[n], nx=64, nv=64, **kw)
+
+    def run(host):
+        monkeypatch.setenv("PIC1DP_OPT_HOST", "1" if host else "0")
+        e = amd.Pic1dp(amd.make_input(**base), npe=2)
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+        e.step(1)                       # t = 0.05: the event fires in the next step (0.05 + dt >= 0.1)
+        before = e.kernel_stats(8)[1]
+        e.step(1)
+        return e, e.kernel_stats(8)[1] - before
+
+    dev, bytes_dev = run(False)
+    ref, bytes_host = run(True)
+    nalloc, npv = dev.local_sizes()
+    assert npv != n and npv == ref.local_sizes()[1]
+    assert bytes_host == 64 * nalloc
+    print("%s: %.2f B per marker between host and device (host-side pass: %.0f)" % (kind, bytes_dev / n, bytes_host / n))
+    assert 0 < bytes_dev <= 9 * n, bytes_dev / n
+    # the two engines' fields differ in the last bits by then (order of the charge atomics), hence v and w too: the same
+    # markers in the same slots to rounding (bit for bit against the oracle on aligned inputs: the tests above)
+    a, b = dev.particles_download(), ref.particles_download()
+    for k in "xvpw":
+        assert np.allclose(a[k][:npv], b[k][:npv], rtol=1e-9, atol=1e-18), k
+    assert relerr(dev.energy_sums(), ref.energy_sums()) < 1e-12      # (the whole local vector: tail slots too)
