@@ -52,7 +52,7 @@ pic1dp_amd = None   # imported by main() in a rank process only (it loads libpic
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 PRICED_BYTES_PER_UPDATE = 80.0  # what a store-and-reload push+gather sub-step would move
-IWT_PUSH, IWT_FIELD, IWT_ALLREDUCE = 4, 7, 21   # the reference's timer ids (src/pic1dp_global.F90:38-50)
+IWT_PUSH, IWT_COLLECT, IWT_FIELD, IWT_ALLREDUCE = 4, 6, 7, 21   # the reference's timer ids (src/pic1dp_global.F90:38-50)
 
 # BASELINE.json configs[1..4]; physics per SURVEY 8(d).  "per_gpu": weak, "total": strong.
 CONFIGS = {
@@ -512,23 +512,39 @@ def main():
         return tab
 
     def attribution(j, nsteps=10):
-        """device time per step under the reference's timer ids (HIP events on the stream),
-        in a pass of its own so that the timed region carries no extra events"""
+        """device time per step under the reference's timer ids (HIP events on the stream; the one-hop exchange, which
+        runs inside the field solve's launch, from a wall clock read in the kernel), in a pass of its own so that the
+        timed region carries no extra events.  Per charge-sum kind: with RCCL the step is marker kernel | pack |
+        all-reduce | paired solve; with the exchange marker kernel | [exchange + paired solve] in one launch -- the line
+        shows directly whether the communication latency or the marker kernel limits a strong-scaled step."""
         e = j.eng
         e.timers_enable(True)
         e.timers_reset()
+        if world > 1:
+            e.xchg_time(reset=True)
         barrier()
         j.run(nsteps)
         device_sync(e)
         out = {"particle_kernels_ms_per_step": e.timer_ms(IWT_PUSH) / nsteps,
-               "field_solve_ms_per_step": e.timer_ms(IWT_FIELD) / nsteps,
+               "charge_pack_ms_per_step": e.timer_ms(IWT_COLLECT) / nsteps,
                "allreduce_ms_per_step": e.timer_ms(IWT_ALLREDUCE) / nsteps,
-               "steps": nsteps,
-               "note": "max over ranks; with the one-hop exchange the charge sum runs inside the field solve's "
-                       "launch and is part of field_solve_ms_per_step"}
+               "field_solve_ms_per_step": e.timer_ms(IWT_FIELD) / nsteps,
+               "exchange_inside_field_launch_ms_per_step": None,
+               "steps": nsteps, "charge_sum": j.kind}
+        if world > 1:
+            x_ms, x_n = e.xchg_time(reset=True)
+            out["exchange_inside_field_launch_ms_per_step"] = x_ms / nsteps
+            out["exchanges_per_step"] = x_n / nsteps
         e.timers_enable(False)
-        for k in ("particle_kernels_ms_per_step", "field_solve_ms_per_step", "allreduce_ms_per_step"):
-            out[k] = max_over_ranks(out[k])
+        for k in ("particle_kernels_ms_per_step", "charge_pack_ms_per_step", "allreduce_ms_per_step",
+                  "field_solve_ms_per_step", "exchange_inside_field_launch_ms_per_step"):
+            if out[k] is not None:
+                out[k] = max_over_ranks(out[k])
+        out["note"] = ("max over ranks, device time.  rccl: allreduce_ms_per_step is the ncclAllReduce of the packed vector "
+                       "(nx + 8 doubles), charge_pack the kernel in front of it, field_solve the paired solve behind it.  "
+                       "one-hop exchange: the sum runs inside the field solve's launch -- field_solve_ms_per_step contains "
+                       "exchange_inside_field_launch_ms_per_step (stores into the peers' slots, the wait for their flags, "
+                       "the rank-order sum; in-kernel 100 MHz clock), allreduce_ms_per_step is then 0")
         barrier()
         return out
 
@@ -758,6 +774,7 @@ def main():
                 "parallelism": "particle shard x%d, replicated grid, charge vector summed over GPUs once per "
                                "sub-step" % world,
                 "path": path, "allreduce": headline_kind, "rccl_ranks": world if headline_kind == "rccl" else 0,
+                "charge_sum_not_used_because": {"rccl": job.rccl_why, "one-hop exchange": job.p2p_why} if world > 1 else None,
                 "exchange_memkind": {0: None, 1: "fine-grained", 2: "uncached", 3: "plain"}[job.xchg_memkind],
                 "marker_layout": "x, v, w, p interleaved in 32 KiB tiles in one slab per species",
                 "timed_blocks": repeats,

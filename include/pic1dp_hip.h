@@ -438,6 +438,13 @@ int pic1dp_hip_set_allreduce(pic1dp_ctx *ctx, int32_t kind);
 /* memory kind of the exchange area (1 fine-grained, 2 uncached, 3 plain device
  * memory), exchanges performed so far; returns PIC1DP_ERR_COMM after a time-out */
 int pic1dp_hip_xchg_info(pic1dp_ctx *ctx, int32_t *memkind, int64_t *exchanges);
+/* device time spent INSIDE the exchanges (the stores into the peers' slots, the wait for
+ * their flags, the rank-order sum) of the launches enqueued while the timers were on
+ * (pic1dp_hip_timers_enable), from a 100 MHz wall clock read in the kernel: with the
+ * exchange being the prologue of the field solve's launch, this is what splits the
+ * reference's "mpiallredu" share (src/pic1dp_global.F90:38-50, timer 21) from "field
+ * electric" (7) in that launch.  reset != 0: start over.  Synchronises the stream. */
+int pic1dp_hip_xchg_time(pic1dp_ctx *ctx, double *ms, int64_t *exchanges_timed, int32_t reset);
 
 /* ---- timers: accumulated milliseconds under the reference's timer ids
  * (src/pic1dp_global.F90:38-50), measured with HIP events on the stream ---- */

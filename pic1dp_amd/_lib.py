@@ -125,6 +125,7 @@ SIGNATURES = {
     "pic1dp_hip_xchg_connect": [_P, _P],
     "pic1dp_hip_set_allreduce": [_P, C.c_int32],
     "pic1dp_hip_xchg_info": [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int64)],
+    "pic1dp_hip_xchg_time": [_P, _D, C.POINTER(C.c_int64), C.c_int32],
     "pic1dp_hip_timers_enable": [_P, C.c_int32],
     "pic1dp_hip_timer_ms": [_P, C.c_int32, _D],
     "pic1dp_hip_timers_reset": [_P],

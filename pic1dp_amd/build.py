@@ -76,6 +76,20 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    # one build at a time per tree: the objects of the translation units are shared files
+    import fcntl
+    lock = open(os.path.join(LIBDIR, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not stale():      # another process built it while this one waited
+            return LIB
+        return _build_locked(verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(verbose):
     # tuning builds: PIC1DP_EXTRA_FLAGS="-DPIC1DP_NT=0" PIC1DP_LIB_OUT=/path/variant.so
     # (load one with PIC1DP_LIB=/path/variant.so); their objects go to a directory of their own
     out = os.environ.get("PIC1DP_LIB_OUT") or LIB

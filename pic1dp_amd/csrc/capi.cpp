@@ -84,6 +84,8 @@ int validate(const pic1dp_input &in, const pic1dp_layout &lay) {
   if (lay.nranks < 1 || lay.rank < 0 || lay.rank >= lay.nranks) return fail(PIC1DP_ERR_ARG, "bad rank/nranks");
   const int npe = lay.npe > 0 ? lay.npe : lay.nranks;
   if (npe % lay.nranks) return fail(PIC1DP_ERR_ARG, "npe must be a multiple of nranks");
+  // (the field kernels hold the partial sums of the npe-rank summation order in LDS: 2 npe doubles beside their tiles)
+  if (npe > 1024) return fail(PIC1DP_ERR_ARG, "npe must be at most 1024 reference ranks");
   return 0;
 }
 
@@ -1426,7 +1428,11 @@ static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred) {
   const bool will_pack = pred && c->pred_version == c->state_version && multi && !fused_xchg && c->comm != nullptr &&
                          !xchg_active(c) && c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (will_pack) {
-    HIP_TRY(launch_charge_pack(c->fa, c->d_pred, c->in.nmode, c->pred_kind, c->d_pack, c->st));
+    {  // the species sum and the packing are collect_charge's share of the step (src/pic1dp_interaction.F90:126-127)
+      Span pk(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
+      HIP_TRY(launch_charge_pack(c->fa, c->d_pred, c->in.nmode, c->pred_kind, c->d_pack, c->st));
+      if (int rc = pk.end()) return rc;
+    }
     Span sp(c, PIC1DP_IWT_MPIALLREDU, c->timers_on);
     ncclResult_t r = rccl().AllReduce(c->d_pack, c->d_pack, pack_doubles(c->in.nx, c->in.nmode, c->pred_kind), ncclDouble,
                                       ncclSum, c->comm, c->st);

@@ -33,6 +33,7 @@ XchgArgs next_xchg_args(pic1dp_ctx *c) {
   x.rank = c->lay.rank;
   x.nranks = c->lay.nranks;
   x.vstride = XCHG_MAX_VEC * c->in.nx;
+  x.ticks = c->timers_on ? c->xc.ticks : nullptr;
   return x;
 }
 
@@ -78,6 +79,7 @@ void comm_release(pic1dp_ctx *c) {
     if (c->xc.opened[q]) (void)hipIpcCloseMemHandle(c->xc.peer[q]);
   if (c->xc.local) (void)hipFree(c->xc.local);
   if (c->xc.err) (void)hipHostFree(c->xc.err);
+  (void)hipFree(c->xc.ticks);
 }
 
 }  // namespace pic1dp_host
@@ -175,6 +177,10 @@ int pic1dp_hip_xchg_create(pic1dp_ctx *c, unsigned char handle[PIC1DP_XCHG_HANDL
   if (const char *t = std::getenv("PIC1DP_XCHG_TIMEOUT_MS")) tmo_ms = std::atof(t);
   c->xc.timeout_ticks = static_cast<long long>(tmo_ms * 1e5);  // wall_clock64 counts at 100 MHz
   c->xc.epoch = 0;
+  if (!c->xc.ticks) {
+    HIP_TRY(hipMalloc(&c->xc.ticks, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->xc.ticks, 0, 2 * sizeof(unsigned long long)));
+  }
   HIP_TRY(hipDeviceSynchronize());
   return 0;
 }
@@ -210,6 +216,21 @@ int pic1dp_hip_set_allreduce(pic1dp_ctx *c, int32_t kind) {
   if (kind == 1 && !c->comm) return fail(PIC1DP_ERR_STATE, "no RCCL communicator");
   c->allreduce_kind = kind;
   return 0;
+}
+
+int pic1dp_hip_xchg_time(pic1dp_ctx *c, double *ms, int64_t *exchanges_timed, int32_t reset) {
+  CHECK_CTX(c);
+  if (ms) *ms = 0.0;
+  if (exchanges_timed) *exchanges_timed = 0;
+  if (!c->xc.ticks) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  unsigned long long t[2] = {0, 0};
+  HIP_TRY(hipMemcpy(t, c->xc.ticks, sizeof t, hipMemcpyDeviceToHost));
+  if (ms) *ms = static_cast<double>(t[0]) * 1e-5;  // 100 MHz wall clock
+  if (exchanges_timed) *exchanges_timed = static_cast<int64_t>(t[1]);
+  if (reset) HIP_TRY(hipMemset(c->xc.ticks, 0, sizeof t));
+  return xchg_check(c);
 }
 
 int pic1dp_hip_xchg_info(pic1dp_ctx *c, int32_t *memkind, int64_t *exchanges) {

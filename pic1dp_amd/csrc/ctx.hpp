@@ -185,6 +185,7 @@ struct pic1dp_ctx {
     unsigned long long *err = nullptr;           // pinned host word the kernel reports a time-out in
     unsigned long long epoch = 0;
     long long timeout_ticks = 0;
+    unsigned long long *ticks = nullptr;         // device [2]: ticks inside exchanges, exchanges timed (while timers are on)
     bool connected = false;
     int memkind = 0;                             // 1 fine-grained, 2 uncached, 3 plain hipMalloc
   } xc;

@@ -249,6 +249,8 @@ struct XchgArgs {
   int rank, nranks;
   int local_in_charge;                         // 1: this rank's charge2 is already in FieldArgs::charge
   int vstride;                                 // doubles per (parity, rank) slot: XCHG_MAX_VEC * nx
+  unsigned long long *ticks;                   // null, or [2] device words: wall-clock ticks (100 MHz) spent inside
+                                               // exchanges so far (stores, the wait for the peers, the sum) and their number
 };
 // vectors of nx doubles one exchange can carry: charge2 + the 1 + 2 * PRED_MAX_MODES prediction slices
 constexpr int XCHG_MAX_VEC = 2 + 2 * PRED_MAX_MODES;

@@ -449,6 +449,7 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_pred_sums(const F
 // threadIdx.x + k * blockDim.x and only ever touches those -- summed over ranks in rank order, in place
 __device__ __forceinline__ void exchange_vectors(const XchgArgs &x, double *sV, int n) {
   const int nr = x.nranks, par = static_cast<int>(x.epoch & 1);
+  const long long t_in = x.ticks ? wall_clock64() : 0;
   for (int k = 0; k < nr; ++k) {
     int q = x.rank + k;  // start with the own area, then the peers in ring order
     if (q >= nr) q -= nr;
@@ -485,6 +486,10 @@ __device__ __forceinline__ void exchange_vectors(const XchgArgs &x, double *sV, 
     for (int q = 1; q < XCHG_MAX_RANKS; ++q)
       if (q < nr) sum = sum + t[q];
     sV[i] = sum;
+  }
+  if (x.ticks && threadIdx.x == 0) {  // what of this launch was the exchange (the bench's attribution splits it from the solve)
+    x.ticks[0] += static_cast<unsigned long long>(wall_clock64() - t_in);
+    x.ticks[1] += 1;
   }
 }
 

@@ -349,6 +349,14 @@ class Pic1dp:
         check(self.L.pic1dp_hip_xchg_info(self._ctx, C.byref(kind), C.byref(n)))
         return kind.value, n.value
 
+    def xchg_time(self, reset=False):
+        """(ms, exchanges): device time spent inside the one-hop exchanges enqueued while the timers were on (the
+        stores into the peers' slots, the wait for their flags, the rank-order sum) -- what splits the charge sum
+        from the field solve inside the launch they share"""
+        ms, n = C.c_double(), C.c_int64()
+        check(self.L.pic1dp_hip_xchg_time(self._ctx, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
     # -- timers / knobs -----------------------------------------------------------------
     def timers_enable(self, on=True):
         check(self.L.pic1dp_hip_timers_enable(self._ctx, int(on)))

@@ -412,6 +412,14 @@ interface
     integer(c_int64_t), intent(out) :: exchanges
     integer(c_int) :: ierr
   end function pic1dp_hip_xchg_info
+  function pic1dp_hip_xchg_time(ctx, ms, exchanges_timed, reset) bind(C, name="pic1dp_hip_xchg_time") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    real(c_double), intent(out) :: ms
+    integer(c_int64_t), intent(out) :: exchanges_timed
+    integer(c_int32_t), value :: reset
+    integer(c_int) :: ierr
+  end function pic1dp_hip_xchg_time
   function pic1dp_hip_timers_enable(ctx, on) bind(C, name="pic1dp_hip_timers_enable") result(ierr)
     import
     type(c_ptr), value :: ctx

@@ -137,6 +137,13 @@ def test_bench_two_ranks_share_the_gpu(amd, config, particles, allreduce, self_l
     # auto: RCCL cannot put two ranks on one GPU, every rank agrees on the exchange instead
     assert d["config"]["allreduce"].startswith("host-staged" if allreduce == "host" else "one-hop")
     assert "allreduce_ms_per_step" in d["attribution"] and "field_solve_ms_per_step" in d["attribution"]
+    at = d["attribution"]
+    assert at["charge_sum"] == d["config"]["allreduce"] and set(d["config"]["charge_sum_not_used_because"]) == {"rccl", "one-hop exchange"}
+    if allreduce != "host":
+        # the exchange runs inside the field solve's launch: its share is read from a clock in the kernel, two a step
+        # (one per charge sum ... a one-pass step sends both sums in ONE exchange)
+        assert 0 < at["exchange_inside_field_launch_ms_per_step"] <= at["field_solve_ms_per_step"]
+        assert at["exchanges_per_step"] >= 1 and at["allreduce_ms_per_step"] == 0
     nsteps = d["steps_before_field_energy_end"]
     assert nsteps == d["warmup_effective"] + d["repeats"] * steps
     e = virtual_rank_energy(amd, dict(nparticle_max=total, **phys), 2, nsteps)
