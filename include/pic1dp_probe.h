@@ -38,6 +38,15 @@ int pic1dp_probe_host_div_lx(double lx, int32_t nx, int64_t n, uint64_t seed, in
 int pic1dp_probe_div_const(int32_t device, double divisor, int64_t n, uint64_t seed, int64_t *mismatches);
 int pic1dp_probe_host_div_const(double divisor, int64_t n, uint64_t seed, int64_t *mismatches);
 
+/* The sequential walks of the GPU marker optimisation (pic1dp_amd/csrc/optimize.hpp plan_merge / plan_remove /
+ * plan_split: one key per marker) against the routines on whole markers they restate (opt_merge / opt_remove /
+ * opt_split, src/pic1dp_particle.F90:411-746), on the HOST: np generated markers in nalloc slots, the event (kind 0
+ * merge, 1 remove, 2 split) applied both ways, *mismatches = slots that differ in v, p, w (and x inside the new count);
+ * -1: the marker counts differ, -2: the random stream was consumed differently; *np_after (may be NULL) = the marker
+ * count the routine leaves.  No GPU needed. */
+int pic1dp_probe_host_optimize(int32_t kind, int32_t typeremove, int32_t nx, int32_t nv, int32_t split_ngroup, double threshold,
+                               uint64_t seed, int64_t np, int64_t nalloc, int64_t *mismatches, int64_t *np_after);
+
 /* y[i] = exp(x[i]) as the marker kernels evaluate it (pexp; host arrays) */
 int pic1dp_probe_exp(int32_t device, const double *x, double *y, int64_t n);
 

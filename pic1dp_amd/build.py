@@ -31,8 +31,8 @@ PRODUCT_UNITS = [("kernels_step.hip", ["-DPIC1DP_STEP_DIST=%d" % d], "kernels_st
     ("capi.cpp", [], "capi"), ("capi_comm.cpp", [], "capi_comm"), ("capi_diag.cpp", [], "capi_diag"),
     ("capi_optimize.cpp", [], "capi_optimize"), ("loader.cpp", [], "loader"), ("multirand.cpp", [], "multirand"),
     ("optimize.cpp", [], "optimize"), ("species.cpp", [], "species"), ("hostcheck.cpp", [], "hostcheck")]
-PROBE_UNITS = [("probe.hip", [], "probe")]
-PROBE_SHARED = ["species", "hostcheck"]      # objects of the product the probe library links as well
+PROBE_UNITS = [("probe.hip", [], "probe"), ("optcheck.cpp", [], "optcheck")]
+PROBE_SHARED = ["species", "hostcheck", "optimize", "multirand"]      # objects of the product the probe library links as well
 HEADERS = ["kernels.hpp", "device_math.hpp", "device_field.hpp", "device_diag.hpp", "step_args.hpp", "check_values.hpp", "loader.hpp",
            "multirand.hpp", "optimize.hpp", "rccl_dyn.hpp", "ctx.hpp",
            os.path.join("..", "..", "include", "pic1dp_hip.h"), os.path.join("..", "..", "include", "pic1dp_probe.h")]

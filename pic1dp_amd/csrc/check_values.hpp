@@ -38,6 +38,15 @@ __host__ __device__ inline double div_check_value(uint64_t seed, int64_t i, doub
   return lx * (u - 0.5) * 1e6;
 }
 
+// a uniform deviate in [0, 1) per (seed, index) (splitmix64)
+__host__ __device__ inline double check_uniform(uint64_t seed, int64_t i) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ULL * static_cast<uint64_t>(i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  return static_cast<double>(z >> 11) * 0x1p-53;
+}
+
 // dividends for the div_const check: random sign, exponent in [-300, 300],
 // random significand -- every 16th one from the edges (0...0k, 1...1k) where
 // rounding decisions are closest

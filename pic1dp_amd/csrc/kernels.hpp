@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/pic1dp_hip.h"
+
 #include <cstdint>
 #include <cstdlib>
 
@@ -365,6 +367,10 @@ hipError_t opt_copy_segment(const OptBlock &b, int64_t i0, int64_t n, double *dx
 // div_lx's / div_const's algorithm (reciprocal + two FMA corrections) with the host's fma against the true
 // quotient on n generated operands: the number of results that differ in any bit (hostcheck.cpp)
 int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n);
+// the planners of the GPU marker optimisation against the host routines they restate (optcheck.cpp; test support):
+// slots that differ, -1 / -2 when the marker counts / the random streams' positions differ
+int64_t host_optimize_check(const pic1dp_input &in, int kind, double threshold, uint64_t seed, int64_t np0, int64_t nalloc,
+                            int64_t *np_after);
 int64_t host_divc_check(double c, uint64_t seed, int64_t n);
 // cell index per marker and per-cell counts from (wrapped) x
 hipError_t launch_cell_indices(const double *x, int64_t np, const GridConst &g, int32_t *ix,

@@ -426,6 +426,18 @@ int pic1dp_probe_host_div_const(double divisor, int64_t n, uint64_t seed, int64_
   return 0;
 }
 
+int pic1dp_probe_host_optimize(int32_t kind, int32_t typeremove, int32_t nx, int32_t nv, int32_t split_ngroup, double threshold,
+                               uint64_t seed, int64_t np, int64_t nalloc, int64_t *mismatches, int64_t *np_after) {
+  if (!mismatches || kind < 0 || kind > 2 || nx < 2 || nv < 2 || np < 0 || nalloc < np || split_ngroup < 1)
+    return pfail("bad argument");
+  pic1dp_input in{};
+  in.lx = 17.45, in.v_max = 8.0, in.nx = nx, in.nv = nv, in.deltaf = 1;
+  in.typeremove = typeremove, in.remove_frac = 0.7, in.split_ngroup = split_ngroup, in.split_dv_sig_frac = 0.1;
+  in.multirand_al_int = 3;
+  *mismatches = pic1dp::host_optimize_check(in, kind, threshold, seed, np, nalloc, np_after);
+  return 0;
+}
+
 int pic1dp_probe_exp(int32_t device, const double *x, double *y, int64_t n) {
   if (!x || !y || n < 0) return pfail("bad argument");
   if (n == 0) return 0;

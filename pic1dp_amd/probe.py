@@ -33,6 +33,8 @@ SIGNATURES = {
     "pic1dp_probe_host_div_lx": [C.c_double, C.c_int32, C.c_int64, C.c_uint64, _I64],
     "pic1dp_probe_div_const": [C.c_int32, C.c_double, C.c_int64, C.c_uint64, _I64],
     "pic1dp_probe_host_div_const": [C.c_double, C.c_int64, C.c_uint64, _I64],
+    "pic1dp_probe_host_optimize": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_uint64, C.c_int64,
+                                   C.c_int64, _I64, _I64],
     "pic1dp_probe_exp": [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64],
     "pic1dp_probe_species_const": [_SP, _I32, _I32, _I32, _I32, _D],
     "pic1dp_probe_dlnf0": [C.c_int32, _SP, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64],
@@ -132,3 +134,12 @@ def dlnf0(sp, v, form, device=0):
     _check(load().pic1dp_probe_dlnf0(device, C.byref(sp), form, v.ctypes.data_as(C.c_void_p),
                                      y.ctypes.data_as(C.c_void_p), v.size))
     return y
+
+
+def host_optimize_mismatches(kind, np_, nalloc, threshold, seed=1, typeremove=2, nx=32, nv=64, split_ngroup=3):
+    """the key-walking planners of the GPU marker optimisation against the host routines on whole markers (0 merge, 1
+    remove, 2 split), on the host: (slots that differ (-1 / -2: marker counts / random stream differ), markers after the event)"""
+    m, after = C.c_int64(), C.c_int64()
+    _check(load().pic1dp_probe_host_optimize(kind, typeremove, nx, nv, split_ngroup, threshold, seed, int(np_), int(nalloc),
+                                             C.byref(m), C.byref(after)))
+    return m.value, after.value

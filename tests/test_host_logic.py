@@ -356,3 +356,24 @@ def test_one_exp_constants_of_a_species(amd, probe, monkeypatch, name, kw):
     assert np.allclose(fd1 * v + fd0, (B - A) / 2, rtol=1e-13, atol=1e-13)
     monkeypatch.setenv("PIC1DP_DLNF0", "ref")
     assert probe.species_const(sp)["one_exp"] == 0
+
+
+@pytest.mark.parametrize("kind,typeremove,threshold,name", [
+    (0, 2, 0.5, "merge"), (0, 2, 2.0, "merge_everything"), (0, 2, 0.02, "merge_few"),
+    (1, 2, 0.3, "remove_profile"), (1, 1, 0.4, "remove_threshold"),
+    (2, 2, 0.3, "split"), (2, 2, 0.01, "split_until_full")], ids=lambda v: v if isinstance(v, str) else "")
+@pytest.mark.parametrize("np_,nalloc", [(50_000, 80_000), (1, 40), (2, 2), (4097, 4200)], ids=lambda v: str(v))
+def test_optimisation_planners_equal_the_routines_on_markers(probe, kind, typeremove, threshold, name, np_, nalloc):
+    """The GPU marker optimisation (N3) sends ONE KEY per marker to the host; plan_merge / plan_remove / plan_split
+    (pic1dp_amd/csrc/optimize.cpp) walk the keys as particle_merge / particle_remove / particle_split walk the markers
+    (src/pic1dp_particle.F90:411-746: visiting order, swap-with-last, the waiting merge partner, the random stream) and
+    record what is to be done to the markers.  Here, on the host: the routine on whole markers against the walk + a
+    host statement of the device's apply kernels -- every slot bit for bit, same count, same random-stream position."""
+    for seed in (1, 2, 3):
+        bad, after = probe.host_optimize_mismatches(kind, np_, nalloc, threshold, seed=seed, typeremove=typeremove)
+        assert bad == 0, (seed, bad)
+        if np_ >= 4097:
+            if kind == 2:
+                assert after > np_
+            elif name != "merge_few" or np_ > 10000:
+                assert after < np_
