@@ -470,7 +470,10 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
  * prologue solved the field of the previous step (one launch per time step inside
  * pic1dp_hip_step: no field_solve_electric launch in between), *ms = 0; which = 8:
  * *launches = bytes marker optimisation events (pic1dp_hip_particle_optimize) have moved
- * between host and device so far, *ms = 0 */
+ * between host and device so far, *ms = 0; which = 9: *launches = how the serial forward
+ * sums of the field solve (one-rank order, up to eight kept modes) run: 0 chains of
+ * additions in single lanes, 1 through the FP64 matrix unit (only where pic1dp_hip_create
+ * found it to reproduce the sequential sums bit for bit; PIC1DP_CHAIN_MFMA=0 keeps the chains) */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

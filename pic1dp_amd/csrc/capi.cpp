@@ -567,6 +567,50 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   f.dnx = static_cast<double>(nx);
   f.sc_re = 1.0 / static_cast<double>(nx);    // src/pic1dp_field.F90:239
   f.sc_im = -1.0 / static_cast<double>(nx);   // :234
+  // The serial forward sums through the FP64 matrix unit -- only if this device gives the sequential sums bit for bit
+  // that way (device_field.hpp chain_rows_mfma): sixteen rows of 1031 values of mixed sign and magnitude against the
+  // host's additions one after the other.  PIC1DP_CHAIN_MFMA=0 keeps the chain of additions in one lane.
+  f.chain_mfma = 0;
+  {
+    const char *e = std::getenv("PIC1DP_CHAIN_MFMA");
+    if (!e || std::atoi(e) != 0) {
+      constexpr int kn = 1031, kr = 16;
+      std::vector<double> v(kr * kn);
+      uint64_t z = 0x9E3779B97F4A7C15ull;
+      for (double &x : v) {  // splitmix64 -> sign, exponent in [-20, 20], random significand
+        z += 0x9E3779B97F4A7C15ull;
+        uint64_t y = z;
+        y = (y ^ (y >> 30)) * 0xBF58476D1CE4E5B9ull;
+        y = (y ^ (y >> 27)) * 0x94D049BB133111EBull;
+        y ^= y >> 31;
+        const uint64_t bits = (y & 0x8000000000000000ull) | ((1023 - 20 + (y >> 52) % 41) << 52) | (y & 0xFFFFFFFFFFFFFull);
+        std::memcpy(&x, &bits, 8);
+      }
+      double want[kr];
+      for (int r = 0; r < kr; ++r) {
+        volatile double t = 0.0;  // (one rounding per addition whatever the compiler would like)
+        for (int i = 0; i < kn; ++i) t = t + v[r * kn + i];
+        want[r] = t;
+      }
+      double *d_v = nullptr;
+      double got[32];
+      HIP_TRY_C(hipMalloc(&d_v, sizeof(double) * (kr * kn + 32)));
+      HIP_TRY_C(hipMemcpy(d_v, v.data(), sizeof(double) * kr * kn, hipMemcpyHostToDevice));
+      HIP_TRY_C(launch_chain_selftest(d_v, kr, kn, d_v + kr * kn, c->st));
+      HIP_TRY_C(hipStreamSynchronize(c->st));
+      HIP_TRY_C(hipMemcpy(got, d_v + kr * kn, sizeof got, hipMemcpyDeviceToHost));
+      (void)hipFree(d_v);
+      if (std::memcmp(got, want, sizeof want) != 0) {
+        pic1dp_hip_destroy(c);
+        return fail(PIC1DP_ERR_HIP, "the device's serial sum differs from the host's sequential additions");
+      }
+      f.chain_mfma = std::memcmp(got + 16, want, sizeof want) == 0 ? 1 : 0;
+      if (e && std::atoi(e) > 0 && f.chain_mfma == 0) {
+        pic1dp_hip_destroy(c);
+        return fail(PIC1DP_ERR_HIP, "PIC1DP_CHAIN_MFMA asked for, but the matrix unit does not give the sequential sums on this device");
+      }
+    }
+  }
   for (int s = 0; s < ns; ++s) {
     f.Z[s] = in->species_charge[s];
     f.n0[s] = in->species_density[s];
@@ -1831,7 +1875,12 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 8) return fail(PIC1DP_ERR_ARG, "which must be 0..8");
+  if (which < 0 || which > 9) return fail(PIC1DP_ERR_ARG, "which must be 0..9");
+  if (which == 9) {  // how the serial forward sums of the one-rank order run: 0 chains of additions, 1 the matrix unit
+    if (ms) *ms = 0.0;
+    if (launches) *launches = c->fa.chain_mfma;
+    return 0;
+  }
   if (which == 5 || which == 7 || which == 8) {  // counts: separate diagnostics passes (k_ptcldist), field solves inside
                                                  // marker launches, bytes marker optimisation events moved over PCIe
     if (ms) *ms = 0.0;

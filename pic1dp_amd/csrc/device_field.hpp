@@ -137,6 +137,42 @@ __device__ __forceinline__ double ranks_sum_serial(P term, int nx, int npe, int 
 // table t & 1, block t >> 1 (the one mode entry is owned by rank 0: plain rank order) --, then threads 0 and 1 add
 // the partials.  Called by every thread (the npe-rank form meets at a barrier); `beside` runs between the chains'
 // start and the meeting, on threads that do not carry a chain where there are any.
+// Up to sixteen serial sums side by side -- row r = rows[r stride .. + n), each summed in ascending order, every addition
+// rounded: the reference's one-rank order -- through the FP64 matrix unit.  v_mfma_f64_4x4x4f64 computes, for four
+// independent 4x4 blocks, D = C + A B with the four k-steps as four consecutive fused multiply-adds (tools/
+// mfma_probe.hip: in ascending k, one rounding per step): with B = 1 in every element each step is an exactly-rounded
+// addition, D[i][*] = (((C + A[i][0]) + A[i][1]) + A[i][2]) + A[i][3] -- four terms of the sequential sum per
+// instruction at the instruction's four passes (16 cycles) instead of four dependent v_add_f64 (~12 cycles each), and
+// sixteen sums (four blocks of four rows) for the price of one.  Operand layout on gfx950 (the probe): lane l holds,
+// of block (l / 4) % 4, A[i = l % 4][k = l / 16] and B[k = l / 16][j = l % 4]; D / C [i = l / 16][j = l % 4].  Row r of
+// the caller is row r % 4 of block r / 4: its sum comes out in lane chain_mfma_lane(r).
+// That this reproduces the sequential sums BIT FOR BIT on the device at hand is not assumed: create() runs
+// launch_chain_selftest and FieldArgs::chain_mfma stays 0 (the chain of additions in one lane) unless it does.
+// Called by all 64 lanes of one wave.
+__device__ __forceinline__ int chain_mfma_lane(int r) { return 16 * (r & 3) + 4 * (r >> 2); }
+__device__ __forceinline__ double chain_rows_mfma(const double *rows, int stride, int nrows, int n) {
+  const int lane = threadIdx.x & 63;
+  const int k = lane >> 4;
+  const int ra = ((lane >> 2) & 3) * 4 + (lane & 3);   // the row this lane's A element belongs to
+  const int rd = ((lane >> 2) & 3) * 4 + (lane >> 4);  // the row this lane's D element (the running sum) belongs to
+  const double *src = rows + (ra < nrows ? ra : 0) * stride;
+  double acc = 0.0;
+  const int nb = n >> 2;
+  constexpr int U = 8;  // terms for eight instructions in flight ahead of the dependent chain
+  int t = 0;
+  for (; t + U <= nb; t += U) {
+    double a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = src[4 * (t + u) + k];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], 1.0, acc, 0, 0, 0);
+  }
+  for (; t < nb; ++t) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(src[4 * t + k], 1.0, acc, 0, 0, 0);
+  const double *dsrc = rows + (rd < nrows ? rd : 0) * stride;  // the last n % 4 terms, by the result's row
+  for (int i = 4 * nb; i < n; ++i) acc = acc + dsrc[i];
+  return acc;
+}
+
 // W: register batch of the chains (the marker kernels, held to 80 VGPRs, take 8)
 template <int W = CHAIN_W, class F>
 __device__ __forceinline__ double lean_forward_sums(const FieldArgs &f, const double *sPc, const double *sPs, double *sPart,
@@ -157,6 +193,13 @@ __device__ __forceinline__ double lean_forward_sums(const FieldArgs &f, const do
       acc = part[0];
       for (int k = 1; k < npe; ++k) acc = acc + part[k];
     }
+  } else if (npe == 1 && f.chain_mfma != 0 && nx >= 16) {
+    if (threadIdx.x < 64) {  // the first wave, all of it: the matrix unit wants every lane
+      const double d = chain_rows_mfma(sPc, static_cast<int>(sPs - sPc), 2, nx);  // row 0 cos -> lane 0, row 1 -sin -> lane 16
+      const double ds = __shfl(d, chain_mfma_lane(1), 64);
+      acc = threadIdx.x == 1 ? ds : d;
+    }
+    beside();
   } else {
     if (threadIdx.x < 2) {
       const double *prod = threadIdx.x ? sPs : sPc;

@@ -136,6 +136,9 @@ struct FieldArgs {
   int npe;               // reference ranks reproduced: > 1 takes the forward sums in the npe-rank order (MPI-AIJ row
                          // blocks, kernels_field.hip rank_block), 1 in the one-rank ascending order
   int tab_lds;           // 1: stage the tables in LDS (they fit)
+  int chain_mfma;        // 1: the serial forward sums of the one-rank order (up to eight kept modes) through the FP64
+                         // matrix unit (device_field.hpp chain_rows_mfma) -- set by create() only if the device gives the
+                         // sequential sums bit for bit that way (launch_chain_selftest); 0: a chain of additions in one lane
   double lx, dnx, sc_re, sc_im;
   double Z[8], n0[8];
 };
@@ -307,6 +310,9 @@ hipError_t launch_field_solve(const FieldArgs &f, bool with_local, bool from_cha
 // tridiagonal system, parallel cyclic reduction in LDS; chargeden -> E (+ energy)
 hipError_t launch_field_fd(const double *chargeden, double *E, double *history, int nx, double lx,
                            double dnx, hipStream_t st);
+// The serial sums of nrows (<= 16) rows of n generated doubles two ways: out[0 .. nrows) chain_sum_lds, out[16 .. 16 + nrows)
+// chain_rows_mfma -- create() compares them with the host's sequential sums
+hipError_t launch_chain_selftest(const double *v, int nrows, int n, double *out, hipStream_t st);
 // int E^2 dx into *out (device)
 hipError_t launch_field_energy(const double *E, int nx, double lx, double dnx, double *out,
                                hipStream_t st);

@@ -256,6 +256,15 @@ __device__ __forceinline__ void solve_body(const FieldArgs &f, double *sCD, doub
     }
     __syncthreads();
   }
+  // one-rank order, up to eight kept modes, on a device whose matrix unit reproduces the sequential sums: all 2 nm sums
+  // side by side through it (device_field.hpp chain_rows_mfma); rows of sTab: m the cos products of mode m, nm + m the -sin ones
+  const bool mfma_rows = !ranks && f.tab_lds && f.chain_mfma != 0 && 2 * nm <= 16 && nx >= 16;
+  double mf_acc = 0.0;
+  if (mfma_rows && threadIdx.x < 64) {
+    const double d = chain_rows_mfma(sTab, nx, 2 * nm, nx);
+    const int t = static_cast<int>(threadIdx.x) < 2 * nm ? static_cast<int>(threadIdx.x) : 0;
+    mf_acc = __shfl(d, chain_mfma_lane((t & 1) ? (t >> 1) : nm + (t >> 1)), 64);
+  }
   // thread t -> mode t>>1, (t&1 ? cos-table : -sin-table)
   if (threadIdx.x < 2 * nm) {
     const int m = threadIdx.x >> 1;
@@ -274,6 +283,8 @@ __device__ __forceinline__ void solve_body(const FieldArgs &f, double *sCD, doub
         const double *tab = (use_cos ? f.fre : f.fim) + static_cast<size_t>(m) * nx;
         acc = ranks_sum_serial([tab, sCD](int i) { return tab[i] * sCD[i]; }, nx, f.npe, owner);
       }
+    } else if (mfma_rows) {
+      acc = mf_acc;
     } else if (f.tab_lds) {
       const double *prod = sTab + (use_cos ? 0 : nm * nx) + m * nx;
       acc = chain_sum_lds(prod, nx);
@@ -1157,6 +1168,23 @@ k_field_fd(const double *chargeden, double *E, double *history, int nx, double l
 }
 
 }  // namespace
+
+// the serial sums two ways (kernels.hpp launch_chain_selftest): one wave
+__global__ void __launch_bounds__(64) k_chain_selftest(const double *v, int nrows, int n, double *out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *rows = reinterpret_cast<double *>(smem);
+  const int stride = (n + 1) & ~1;
+  for (int i = threadIdx.x; i < nrows * n; i += 64) rows[(i / n) * stride + i % n] = v[i];
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < nrows) out[threadIdx.x] = chain_sum_lds(rows + threadIdx.x * stride, n);
+  const double d = chain_rows_mfma(rows, stride, nrows, n);
+  for (int r = 0; r < nrows; ++r)
+    if (static_cast<int>(threadIdx.x) == chain_mfma_lane(r)) out[16 + r] = d;
+}
+hipError_t launch_chain_selftest(const double *v, int nrows, int n, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_chain_selftest, dim3(1), dim3(64), sizeof(double) * nrows * ((n + 1) & ~1), st, v, nrows, n, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_field_fd(const double *chargeden, double *E, double *history, int nx, double lx,
                            double dnx, hipStream_t st) {
