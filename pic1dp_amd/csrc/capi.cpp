@@ -1171,12 +1171,17 @@ static bool fuse_capable(const pic1dp_ctx *c) {
   if (!(c->fuse_solve && !multi && c->pred_kind == 2 && c->in.nmode == 1 && c->field_solver == 0 && c->fa.npe <= 32 &&
         predict_capable(c)))
     return false;
-  // ... and serial forward sums that are short.  The solve costs inside a marker launch what it costs in its own: a
+  // ... and serial forward sums that are short enough.  The solve costs inside a marker launch what it costs in its own: a
   // row of dependent round trips and the chain in the reference's order (12 cycles a term at the marker kernel's
   // clock).  With a chain of 1024 terms the launch it saves is level or slightly behind (1.25e7 markers / nx 1024:
   // 0.1471 against 0.1460 ms per step); with 192 terms it is 1 % ahead at 6.4e6 markers and 11 % at 2e5
   // (profiles/r04/experiments/ab_fused_solve.log, ab_small_knobs.log).  PIC1DP_FUSE_SOLVE=2 fuses whatever the length.
-  if (c->fuse_solve != 2 && c->in.nx / std::max(1, c->fa.npe) > 512) return false;
+  // Round 4, later: with the sums through the matrix unit (one-rank order, FieldArgs::chain_mfma: a third of the chain's
+  // time) the fused launch is ahead at nx 1024 too (1.25e7 markers: 0.1395-0.1416 against 0.1420-0.1429 ms per step) and
+  // level to +0.3 % at nx 4096 (ab_fused_solve_mfma_chain.log; left unfused: its kernel stays the plain stream the profiles
+  // price): the length that counts is the chain's cost in terms.
+  const int chain_terms = (c->fa.npe == 1 && c->fa.chain_mfma) ? c->in.nx / 3 : c->in.nx / std::max(1, c->fa.npe);
+  if (c->fuse_solve != 2 && chain_terms > 1024) return false;
   const bool priv = c->pred_private && c->threads_req <= 0;
   for (int s = 0; s < c->in.nspecies; ++s) {
     if (c->sp[s].np <= 0) continue;

@@ -428,7 +428,7 @@ def fused_pair(amd, monkeypatch, npe=1, env=None, **kw):
     """two engines on the same input: the solve inside the marker launches, and in launches of its own"""
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
-    monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "2")      # (1, the default, fuses where the serial sums are short: nx / npe <= 512)
+    monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "2")      # (1, the default, fuses where the serial sums are short enough)
     a = engine(amd, monkeypatch, True, 2, npe=npe, **kw)
     monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "0")
     b = engine(amd, monkeypatch, True, 2, npe=npe, **kw)
