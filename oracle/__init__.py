@@ -293,6 +293,17 @@ class Field:
             lib().orc_field_free(self.f)
             self.f = None
 
+    def tables(self):
+        """(fourier_re, fourier_im, grad_inv) of the orc_field, copied: [nx, nmode], [nx, nmode], [nmode]"""
+        class _F(C.Structure):
+            _fields_ = [("nx", C.c_int32), ("nmode", C.c_int32), ("re", C.POINTER(C.c_double)),
+                        ("im", C.POINTER(C.c_double)), ("ginv", C.POINTER(C.c_double))]
+        f = C.cast(self.f, C.POINTER(_F)).contents
+        n = f.nx * f.nmode
+        return (np.ctypeslib.as_array(f.re, (n,)).reshape(f.nx, f.nmode).copy(),
+                np.ctypeslib.as_array(f.im, (n,)).reshape(f.nx, f.nmode).copy(),
+                np.ctypeslib.as_array(f.ginv, (f.nmode,)).copy())
+
     def solve(self, rho, npe=1):
         """field_solve_electric in the summation order of an npe-rank reference run (1: SeqAIJ)"""
         nx, nm = self.inp.nx, self.inp.nmode

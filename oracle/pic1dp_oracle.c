@@ -640,9 +640,11 @@ void orc_field_free(orc_field *f) {
  * received contributions are added is the scatter's (message completion): stated
  * here as the canonical one -- the owner's own block first, then the other ranks
  * in rank order, which for mode entry 0 (the one kept mode of the default input,
- * owned by rank 0) is plain rank order.  The inverse (MatMult, MatMultAdd: <= 2 nmode
- * terms per row) keeps the one-rank order; under MPI-AIJ a row adds its rank's own
- * columns first, which is the same sum for nmode = 1. */
+ * owned by rank 0) is plain rank order.  The inverse (MatMult, then MatMultAdd onto its
+ * result) follows MPI-AIJ's two products per row: the columns of the row's own rank
+ * (its diagonal block: the PETSC_DECIDE block of the nmode entries that rank holds)
+ * ascending, then every other column ascending; for one rank, and for nmode <= 2, that
+ * is the one-rank sum. */
 void orc_field_solve_ranks(const orc_input *in, const orc_field *f, int npe,
                            const double *rho, double *E, double *mode_re,
                            double *mode_im) {
@@ -685,13 +687,25 @@ void orc_field_solve_ranks(const orc_input *in, const orc_field *f, int npe,
     mode_re[im] = mode_re[im] * f->grad_inv[im]; /* :243 */
     mode_im[im] = mode_im[im] * f->grad_inv[im]; /* :246 */
   }
-  for (int ix = 0; ix < nx; ix++) {
-    double s = 0.0;
-    for (int im = 0; im < nm; im++) /* :251 */
-      s += f->fourier_re[(size_t)ix * nm + im] * mode_re[im];
-    for (int im = 0; im < nm; im++) /* :253 */
-      s += f->fourier_im[(size_t)ix * nm + im] * mode_im[im];
-    E[ix] = s * 2.0; /* :256 */
+  for (int r = 0, row = 0; r < npe; r++) {
+    /* rank r's rows [row, row_end) and the mode entries it owns [own, own_end) */
+    const int row_end = row + (int)orc_local_size(nx, r, npe);
+    int own = 0;
+    for (int q = 0; q < r; q++) own += (int)orc_local_size(nm, q, npe);
+    const int own_end = own + (int)orc_local_size(nm, r, npe);
+    for (int ix = row; ix < row_end; ix++) {
+      double s = 0.0;
+      for (int im = own; im < own_end; im++) /* :251, diagonal block */
+        s += f->fourier_re[(size_t)ix * nm + im] * mode_re[im];
+      for (int im = 0; im < nm; im++)        /* :251, the other ranks' columns */
+        if (im < own || im >= own_end) s += f->fourier_re[(size_t)ix * nm + im] * mode_re[im];
+      for (int im = own; im < own_end; im++) /* :253 */
+        s += f->fourier_im[(size_t)ix * nm + im] * mode_im[im];
+      for (int im = 0; im < nm; im++)
+        if (im < own || im >= own_end) s += f->fourier_im[(size_t)ix * nm + im] * mode_im[im];
+      E[ix] = s * 2.0; /* :256 */
+    }
+    row = row_end;
   }
 }
 

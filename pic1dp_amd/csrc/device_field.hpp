@@ -102,6 +102,24 @@ __device__ __forceinline__ int entry_owner(int m, int nm, int npe) {
   if (m < rem * (q + 1)) return m / (q + 1);
   return q > 0 ? rem + (m - rem * (q + 1)) / q : npe - 1;
 }
+// One row of the inverse transform (:251-256) in the order of the npe-rank products: MatMult, and MatMultAdd onto
+// its result, each take the columns of the row's own rank first (MPI-AIJ's diagonal block: the PETSC_DECIDE block
+// of the nmode entries that rank holds), then every other column, both ascending.  One rank, or nmode <= 2: the
+// plain ascending sum.  sMode: [re(nm) | im(nm)]; tables mode-major.
+__device__ __forceinline__ double inverse_row(const FieldArgs &f, int ix, const double *sMode) {
+  const int nx = f.nx, nm = f.nmode;
+  int own = 0, len = nm;
+  if (f.npe > 1) rank_block(nm, f.npe, entry_owner(ix, nx, f.npe), own, len);
+  const int end = own + len;
+  double s = 0.0;
+  for (int m = own; m < end; ++m) s = s + f.fre[static_cast<size_t>(m) * nx + ix] * sMode[m];
+  for (int m = 0; m < own; ++m) s = s + f.fre[static_cast<size_t>(m) * nx + ix] * sMode[m];
+  for (int m = end; m < nm; ++m) s = s + f.fre[static_cast<size_t>(m) * nx + ix] * sMode[m];
+  for (int m = own; m < end; ++m) s = s + f.fim[static_cast<size_t>(m) * nx + ix] * sMode[nm + m];
+  for (int m = 0; m < own; ++m) s = s + f.fim[static_cast<size_t>(m) * nx + ix] * sMode[nm + m];
+  for (int m = end; m < nm; ++m) s = s + f.fim[static_cast<size_t>(m) * nx + ix] * sMode[nm + m];
+  return s * 2.0;
+}
 // sum of prod[lo .. lo + len) ascending, from zero (eight loads in flight ahead of their dependent adds)
 template <class P>
 __device__ __forceinline__ double chain_partial(P term, int lo, int len) {

@@ -134,7 +134,8 @@ struct FieldArgs {
   double *history;       // energy slot to write, or nullptr
   int nx, nmode, nspecies, deltaf;
   int npe;               // reference ranks reproduced: > 1 takes the forward sums in the npe-rank order (MPI-AIJ row
-                         // blocks, kernels_field.hip rank_block), 1 in the one-rank ascending order
+                         // blocks, device_field.hpp rank_block) and the inverse's per row with the row's own rank's mode
+                         // entries first (inverse_row); 1: the one-rank ascending order
   int tab_lds;           // 1: stage the tables in LDS (they fit)
   int chain_mfma;        // 1: the serial forward sums of the one-rank order (up to eight kept modes) through the FP64
                          // matrix unit (device_field.hpp chain_rows_mfma) -- set by create() only if the device gives the

@@ -316,7 +316,7 @@ __device__ __forceinline__ void solve_body(const FieldArgs &f, double *sCD, doub
   __syncthreads();
   }  // !TREE
 
-  // inverse: E = 2*(Fre*mode_re + Fim*mode_im), ascending mode order :251-256
+  // inverse: E = 2*(Fre*mode_re + Fim*mode_im), :251-256 (mode order: inverse_row)
   double e2 = 0.0;
   if (nm == 1) {  // the usual case: both table reads of four grid points in flight together
     for (int base = threadIdx.x; base < nx; base += U * FIELD_THREADS) {
@@ -342,10 +342,7 @@ __device__ __forceinline__ void solve_body(const FieldArgs &f, double *sCD, doub
     }
   } else {
     for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
-      double s = 0.0;
-      for (int m = 0; m < nm; ++m) s = s + f.fre[static_cast<size_t>(m) * nx + ix] * sMode[m];
-      for (int m = 0; m < nm; ++m) s = s + f.fim[static_cast<size_t>(m) * nx + ix] * sMode[nm + m];
-      const double e = s * 2.0;
+      const double e = inverse_row(f, ix, sMode);
       f.E[ix] = e;
       e2 += e * e;
     }
@@ -1049,7 +1046,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_field_modes_wide(const FieldAr
     f.mode_re[m] = acc * f.sc_re * f.grad_inv[m];
 }
 
-// inverse: one grid point per thread, serial over ascending mode (:251-256)
+// inverse: one grid point per thread, serial over the modes in the row's order (inverse_row, :251-256)
 __global__ void __launch_bounds__(WIDE_THREADS) k_field_inverse_wide(const FieldArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *sMode = reinterpret_cast<double *>(smem);  // [2*nmode]: re then im
@@ -1061,10 +1058,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) k_field_inverse_wide(const Field
   __syncthreads();
   const int ix = blockIdx.x * blockDim.x + threadIdx.x;
   if (ix >= nx) return;
-  double s = 0.0;
-  for (int m = 0; m < nm; ++m) s = s + f.fre[static_cast<size_t>(m) * nx + ix] * sMode[m];
-  for (int m = 0; m < nm; ++m) s = s + f.fim[static_cast<size_t>(m) * nx + ix] * sMode[nm + m];
-  f.E[ix] = s * 2.0;
+  f.E[ix] = inverse_row(f, ix, sMode);
 }
 
 __global__ void __launch_bounds__(FIELD_THREADS)

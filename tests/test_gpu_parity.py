@@ -364,7 +364,8 @@ def test_field_solve_bit_exact(oracle_mod, amd, nx, modes, npe):
     """same chargeden in -> identical E, mode_re, mode_im: the forward sums run in the reference's order -- one
     rank (SeqAIJ): ascending ix, one thread per mode component; npe ranks (MPI-AIJ, `mpiexec -n 4` is the
     reference's own launch line): every rank's PETSC_DECIDE row block from zero, the blocks added owner first then
-    in rank order (oracle: orc_field_solve_ranks), here as partial chains side by side"""
+    in rank order (oracle: orc_field_solve_ranks), here as partial chains side by side; the inverse takes, row by
+    row, the mode entries of the row's own rank first (MPI-AIJ's diagonal block), then the others"""
     if npe > 1 and nx > 1100 and len(modes) > 600:
         pytest.skip("one large many-mode case per order is enough")
     sim, eng = pair(oracle_mod, amd, load=False, npe=npe, nparticle_max=max(16, npe), nx=nx, nmode=len(modes), modes=modes)
@@ -374,6 +375,10 @@ def test_field_solve_bit_exact(oracle_mod, amd, nx, modes, npe):
     if npe > 1 and nx >= 64:   # the order is observable: not the one-rank sums
         E1, re1, im1 = oracle_mod.Field(sim.inp).solve(rho, 1)
         assert not (np.array_equal(re, re1) and np.array_equal(im, im1)) or len(modes) == 1
+        if len(modes) >= 60:   # so is the inverse's: the plain ascending sum of the same modes gives another E
+            fre, fim, _ = oracle_mod.Field(sim.inp).tables()
+            asc = 2.0 * np.cumsum(np.concatenate([fre * re, fim * im], axis=1), axis=1)[:, -1]
+            assert not np.array_equal(asc, E)
     eng.set_chargeden(rho)
     eng.field_solve_electric()
     f = eng.get_field()

@@ -75,6 +75,52 @@ def test_field_solve_full_spectrum(oracle_mod):
     assert len(re) == len(modes) and len(im) == len(modes)
 
 
+@pytest.mark.parametrize("nx,nm,npe", [(24, 5, 3), (40, 7, 4), (17, 3, 2), (12, 2, 5), (30, 9, 1)])
+def test_field_solve_rank_order_follows_mpiaij(oracle_mod, nx, nm, npe):
+    """orc_field_solve_ranks against a plain-Python walk of what an npe-rank MPI-AIJ run does with the same tables
+    (src/pic1dp_field.F90:86-88 layouts, :231-256 products): MatMultTranspose forms every rank's contribution from
+    its own rows and adds them into the owner's entry (the owner's own first, then rank order); MatMult and
+    MatMultAdd take, row by row, the columns of the row's rank first (the diagonal block), then the others"""
+    modes = list(range(1, nm + 1))
+    inp = oracle_mod.make_input(nx=nx, nmode=nm, modes=modes)
+    F = oracle_mod.Field(inp)
+    fre, fim, ginv = F.tables()
+    rho = np.random.default_rng(nx * nm).standard_normal(nx)
+    E, re, im = F.solve(rho, npe)
+
+    def block(n, r):
+        lo = sum(n // npe + (q < n % npe) for q in range(r))
+        return lo, lo + n // npe + (r < n % npe)
+
+    rows = [block(nx, r) for r in range(npe)]
+    cols = [block(nm, r) for r in range(npe)]
+    want_re, want_im = np.empty(nm), np.empty(nm)
+    for m in range(nm):
+        owner = next(r for r in range(npe) if cols[r][0] <= m < cols[r][1])
+        tot = [None, None]
+        for r in [owner] + [q for q in range(npe) if q != owner]:
+            part = [0.0, 0.0]
+            for ix in range(*rows[r]):
+                part[0] += float(fre[ix, m]) * float(rho[ix])
+                part[1] += float(fim[ix, m]) * float(rho[ix])
+            tot = part if tot[0] is None else [tot[0] + part[0], tot[1] + part[1]]
+        want_im[m] = tot[0] * (-1.0 / nx) * float(ginv[m])
+        want_re[m] = tot[1] * (1.0 / nx) * float(ginv[m])
+    assert np.array_equal(re, want_re) and np.array_equal(im, want_im)
+    want_E = np.empty(nx)
+    for r in range(npe):
+        own = list(range(*cols[r]))
+        order = own + [m for m in range(nm) if m not in own]
+        for ix in range(*rows[r]):
+            s = 0.0
+            for m in order:
+                s += float(fre[ix, m]) * float(want_re[m])
+            for m in order:
+                s += float(fim[ix, m]) * float(want_im[m])
+            want_E[ix] = s * 2.0
+    assert np.array_equal(E, want_E)
+
+
 def test_deposit_conserves_charge_and_wraps(oracle_mod):
     inp = oracle_mod.make_input(nx=50)
     rng = np.random.default_rng(2)
