@@ -28,7 +28,7 @@ STEP_DISTS = (0, 1, 2, 3, 4, 5)
 PRODUCT_UNITS = [("kernels_step.hip", ["-DPIC1DP_STEP_DIST=%d" % d], "kernels_step_d%d" % d) for d in STEP_DISTS] + [
     ("kernels_push.hip", [], "kernels_push"), ("kernels_field.hip", [], "kernels_field"),
     ("kernels_diag.hip", [], "kernels_diag"), ("kernels_opt.hip", [], "kernels_opt"), ("step_dispatch.cpp", [], "step_dispatch"),
-    ("capi.cpp", [], "capi"), ("capi_comm.cpp", [], "capi_comm"), ("capi_diag.cpp", [], "capi_diag"),
+    ("capi.cpp", [], "capi"), ("capi_step.cpp", [], "capi_step"), ("capi_comm.cpp", [], "capi_comm"), ("capi_diag.cpp", [], "capi_diag"),
     ("capi_optimize.cpp", [], "capi_optimize"), ("loader.cpp", [], "loader"), ("multirand.cpp", [], "multirand"),
     ("optimize.cpp", [], "optimize"), ("species.cpp", [], "species"), ("hostcheck.cpp", [], "hostcheck")]
 PROBE_UNITS = [("probe.hip", [], "probe"), ("optcheck.cpp", [], "optcheck")]

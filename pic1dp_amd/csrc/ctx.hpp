@@ -1,6 +1,7 @@
 // ctx.hpp -- what the translation units behind the C ABI share: the context (one process = one GPU = one HIP stream),
 // the error convention, the event spans, and the internal entry points one unit offers the others.
-//   capi.cpp           context, transfers, the hot path's sequencing and the state machine of the lazy call sites
+//   capi.cpp           context, input, transfers, field access, timers and knobs
+//   capi_step.cpp      the hot path: the three call sites and their lazy state machine, pic1dp_hip_step, the prediction
 //   capi_comm.cpp      RCCL communicator, the one-hop exchange's set-up, the charge sum over ranks
 //   capi_diag.cpp      diagnostics of output_all
 //   capi_optimize.cpp  marker optimisation events (merge / remove / split)
@@ -252,13 +253,17 @@ struct Span {
   }
 };
 
-// ---- what capi.cpp offers the other units ----
-int require_loaded(pic1dp_ctx *c);        // markers loaded, no charge_local pending; memory as eager calls would have left it
-int materialize(pic1dp_ctx *c);           // a noted push becomes memory
-int materialize_cd(pic1dp_ctx *c);        // what collect_charge left to the next solve_field becomes field_chargeden
+// ---- capi.cpp ----
 int ensure_second_set(pic1dp_ctx *c);     // the second slab (RK ping-pong set; re-packing target of the optimiser)
 int put_range(pic1dp_ctx *c, double *arr, int64_t off, const double *host, int64_t cnt);
 int get_range(pic1dp_ctx *c, const double *arr, int64_t off, double *host, int64_t cnt);
+// ---- capi_step.cpp (the hot path and the state machine of the lazy call sites) ----
+int require_loaded(pic1dp_ctx *c);        // markers loaded, no charge_local pending; memory as eager calls would have left it
+int materialize(pic1dp_ctx *c);           // a noted push becomes memory
+int materialize_cd(pic1dp_ctx *c);        // what collect_charge left to the next solve_field becomes field_chargeden
+int rebuild_half_step_chargeden(pic1dp_ctx *c);  // the whole vector where only the kept mode's content was formed
+void field_written(pic1dp_ctx *c, bool by_solve);  // d_E changed: versions, what a noted push may still assume
+size_t step_lds_bytes(int nx, bool full, int rcopies = 1);  // dynamic LDS of a whole-step kernel
 // ---- capi_comm.cpp ----
 int allreduce_charge(pic1dp_ctx *c);
 int allreduce_doubles(pic1dp_ctx *c, double *d, size_t n);
