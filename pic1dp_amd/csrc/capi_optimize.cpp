@@ -333,7 +333,11 @@ int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optim
   c->state_version++;
   HIP_TRY(hipStreamSynchronize(c->st));
   const char *eh = std::getenv("PIC1DP_OPT_HOST");  // (read per event: rare)
-  const bool on_host = eh && std::atoi(eh) != 0;
+  bool on_host = eh && std::atoi(eh) != 0;
+  // the device path names positions inside a block with 32 bits (keys, move lists, bit masks): a block of 2^32 slots or
+  // more -- 137 GB of markers in one reference block -- takes the host copies, which count in 64 bits
+  for (int b = 0; b < nb; ++b)
+    if (c->blk_alloc[b] >= (int64_t{1} << 32) - 2) on_host = true;
   if (int rc = on_host ? optimize_on_host(c, due) : optimize_on_device(c, due)) return rc;
   if (flag_optimized) *flag_optimized = 1;
   return tm.end();
