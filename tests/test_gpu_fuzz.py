@@ -3,12 +3,23 @@ modes, distribution, linear / nonlinear / full-f, species, masses and
 temperatures, virtual ranks, unloaded tails, odd marker counts) run for a few
 time steps on the GPU and in the oracle; the field-energy series must agree to
 1e-10 and positions to the trajectory-following tolerance."""
+import os
+
 import numpy as np
 import pytest
 
 from util import both_inputs
 
 pytestmark = pytest.mark.gpu
+
+# a longer campaign on request: PIC1DP_FUZZ_BASE=1000 PIC1DP_FUZZ_MULT=10 pytest tests/test_gpu_fuzz.py -m gpu
+# (seeds BASE ... BASE + MULT * the default count; the default, BASE 0 / MULT 1, is what the suite runs)
+_BASE = int(os.environ.get("PIC1DP_FUZZ_BASE", "0"))
+_MULT = int(os.environ.get("PIC1DP_FUZZ_MULT", "1"))
+
+
+def seeds(n):
+    return range(_BASE, _BASE + n * _MULT)
 
 
 def random_case(rng):
@@ -40,10 +51,17 @@ def random_case(rng):
         multirand_al_int=int(rng.choice([1, 2, 3])), multirand_warmup=int(rng.integers(0, 3)),
     )
     npe = int(rng.choice([1, 1, 2, 3]))
+    # keep the case inside the reference's own domain: with a heavy, cold species both Maxwellians of -f0'/f0 underflow
+    # at the edge of the velocity range (exp(-(v_max + v0)^2 m / 2T) = 0), the reference's ratio is 0/0 there, its markers
+    # turn NaN and index out of the grid (seed 1040: m = 16, T = 0.65) -- nothing to compare; the mass is capped instead
+    for i in range(nsp):
+        cold = min(kw["species_temperature"][i], kw["species_temperature2"][i])
+        cap = 1300.0 * cold / (8.0 + kw["species_v0"][i]) ** 2
+        kw["species_mass"][i] = min(kw["species_mass"][i], cap)
     return kw, npe
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", seeds(24))
 def test_random_configuration(oracle_mod, amd, seed):
     rng = np.random.default_rng(1000 + seed)
     kw, npe = random_case(rng)
@@ -82,7 +100,7 @@ def test_random_configuration(oracle_mod, amd, seed):
         assert np.max(np.abs(got["v"][:npv] - sim.gather("v", isp))) < 1e-8
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", seeds(16))
 def test_random_call_sequences_lazy_equals_eager(amd, monkeypatch, seed):
     """differential test of the lazy call sites: random sequences of the hot-path
     calls, field changes and inspections, applied to an engine with lazy call sites
@@ -158,7 +176,7 @@ def test_random_call_sequences_lazy_equals_eager(amd, monkeypatch, seed):
 
 
 @pytest.mark.parametrize("kind", [1, 2], ids=["tiles", "sums"])
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", seeds(10))
 def test_random_call_sequences_predicted_equals_two_pass(amd, monkeypatch, seed, kind):
     """differential test of the state machine behind the one-pass step (state_version,
     field_version, pred_version, eh_*, t2_version, cd_lazy, lz): random VALID sequences of every entry point that
