@@ -4,6 +4,8 @@ oracle.  The routines are sequential and run on the host inside the library; the
 tests feed both sides identical markers right before an optimisation event and
 require identical results (positions, velocities, weights, counts), then check
 whole runs statistically."""
+import os
+
 import numpy as np
 import pytest
 
@@ -56,12 +58,21 @@ def drive_to_event(sim, eng, nsteps):
 @pytest.mark.parametrize("npe", [1, 3])
 def test_optimisation_event_is_bit_identical(oracle_mod, amd, kind, kw, npe):
     base = dict(nparticle_max=60000, species_nparticle_init=[36000], nx=32, nv=64)
-    sim, eng = synced_pair(oracle_mod, amd, npe, **base, **kw)
-    # the event fires in the step that starts at t = 0.25 (0.25 + dt >= 0.3): take 5
+    n_after = aligned_event(oracle_mod, amd, npe, dict(base, **kw))
+    if kind.startswith("merge") or kind.startswith("remove"):
+        assert n_after < 36000
+    if kind.startswith("split"):
+        assert n_after > 36000
+
+
+def aligned_event(oracle_mod, amd, npe, kw, steps_before=5):
+    """both sides to the step in which the event fires (t = 0.25 + dt >= 0.3 with the default dt), the oracle's markers
+    put on the engine's values, the event step by hand on both sides; returns the valid markers after the event"""
+    sim, eng = synced_pair(oracle_mod, amd, npe, **kw)
     # identical steps (the initial steps agree bit for bit in x, v, and w to rounding),
     # then align the markers exactly and run the event step by hand on both sides
-    sim.step(5)
-    eng.step(5)
+    sim.step(steps_before)
+    eng.step(steps_before)
     got = eng.particles_download()
     off = 0
     for r in range(npe):
@@ -70,33 +81,22 @@ def test_optimisation_event_is_bit_identical(oracle_mod, amd, kind, kw, npe):
             sim.array(r, 0, k)[:n] = got[k][off:off + n]
         off += n
     sim.set_field(eng.get_field()["electric"])
+    n_after = None
     for irk in (1, 2):
         sim.push(irk)
         eng.interaction_push_particle(irk)
-        if irk == 1:
-            # weights may differ in the last bits (exp); re-align before the second push
-            g1 = eng.particles_download()
-            off = 0
-            for r in range(npe):
-                n = sim.rank_np(r)
-                sim.array(r, 0, "w")[:n] = g1["w"][off:off + n]
-                off += n
-        else:
-            g2 = eng.particles_download()
-            off = 0
-            for r in range(npe):
-                n = sim.rank_np(r)
-                sim.array(r, 0, "w")[:n] = g2["w"][off:off + n]
-                off += n
+        # weights may differ in the last bits (exp): re-align after either push
+        g = eng.particles_download()
+        off = 0
+        for r in range(npe):
+            n = sim.rank_np(r)
+            sim.array(r, 0, "w")[:n] = g["w"][off:off + n]
+            off += n
         did_o = sim.optimize(irk)
         did_g = eng.particle_optimize(irk)
         assert did_o == did_g == (irk == 2)
         if irk == 2:
             n_after = compare_blocks(sim, eng, npe)
-            if kind.startswith("merge") or kind.startswith("remove"):
-                assert n_after < 36000
-            if kind.startswith("split"):
-                assert n_after > 36000
         sim.collect_charge()
         eng.interaction_collect_charge()
         sim.solve_field()
@@ -105,6 +105,39 @@ def test_optimisation_event_is_bit_identical(oracle_mod, amd, kind, kw, npe):
     assert relerr(eng.get_field()["chargeden"], sim.get_field()[1]) < 1e-11
     # nothing further is due
     assert not eng.particle_optimize(2)
+    return n_after
+
+
+def random_event_case(rng):
+    nmax = int(rng.integers(3000, 70000))
+    ninit = int(nmax * rng.uniform(0.35, 1.0))
+    kw = dict(nparticle_max=nmax, species_nparticle_init=[ninit], nx=int(rng.choice([4, 8, 32, 100])),
+              nv=int(rng.choice([8, 16, 64, 128])), iptcldist=int(rng.choice([0, 2, 3, 3])))
+    kinds = rng.permutation(["merge", "remove", "split"])[:int(rng.integers(1, 4))]
+    for k in kinds:
+        if k == "merge":
+            kw.update(nmerge=1, tmerge=[0.3], thshmerge=[float(rng.choice([0.05, 0.3, 0.6, 2.0]))])
+        elif k == "remove":
+            kw.update(nremove=1, tremove=[0.3], typeremove=int(rng.choice([1, 2])),
+                      thshremove=[float(rng.uniform(0.1, 0.8))], remove_frac=float(rng.uniform(0.2, 0.9)))
+        else:
+            kw.update(nsplit=1, tsplit=[0.3], thshsplit=[float(rng.choice([0.01, 0.2, 0.5, 0.9]))],
+                      split_ngroup=int(rng.integers(2, 7)))
+    return kw, int(rng.choice([1, 1, 2, 3, 5]))
+
+
+_BASE = int(os.environ.get("PIC1DP_FUZZ_BASE", "0"))
+_MULT = int(os.environ.get("PIC1DP_FUZZ_MULT", "1"))
+
+
+@pytest.mark.parametrize("seed", range(_BASE, _BASE + 12 * _MULT))
+def test_random_optimisation_events(oracle_mod, amd, seed):
+    """seeded random events (kinds and their combinations, thresholds, both kinds of removal, group sizes, marker counts
+    with and without free tail slots, grids, distributions, 1 ... 5 reference ranks) with the markers on the device,
+    against the oracle on aligned inputs: every valid marker of every block bit for bit.  A longer campaign:
+    PIC1DP_FUZZ_BASE=1000 PIC1DP_FUZZ_MULT=20 (as tests/test_gpu_fuzz.py)"""
+    kw, npe = random_event_case(np.random.default_rng(77000 + seed))
+    aligned_event(oracle_mod, amd, npe, kw)
 
 
 def test_whole_step_path_runs_the_events(oracle_mod, amd):
