@@ -519,6 +519,10 @@ def main():
         shows directly whether the communication latency or the marker kernel limits a strong-scaled step."""
         e = j.eng
         e.timers_enable(True)
+        # a few steps first, not counted: the step after a change of path (the call sites before, the timers themselves)
+        # restarts the prediction with a first-sub-step pass of its own, which is not what a step of the run costs
+        j.run(3)
+        device_sync(e)
         e.timers_reset()
         if world > 1:
             e.xchg_time(reset=True)
