@@ -561,30 +561,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   double2 *t2 = reinterpret_cast<double2 *>(a.t2);
-#ifdef PIC1DP_TUNE_XCD_SKEW
-  // Tuning build, measurement only: the pairs in eight pools, one per XCD (workgroups go to the XCDs round-robin: the
-  // residue of blockIdx names the pool, the hardware's XCC id the weight), pool sizes 1 +- skew of an equal share
-  int64_t j_begin, j_end, j_stride;
-  {
-    const int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7, rho = blockIdx.x & 7;
-    const int off = (xcc - rho) & 7;                       // residue r runs on XCD (r + off) & 7
-    const int64_t units = (npair + blockDim.x - 1) / blockDim.x;  // workgroup trips
-    double cum = 0.0, lo = 0.0, hi = 0.0;
-    for (int r = 0; r < 8; ++r) {
-      const double w = (((r + off) & 7) & 1) ? 1.0 - a.xcd_skew : 1.0 + a.xcd_skew;
-      if (r == rho) lo = cum;
-      cum += w;
-      if (r == rho) hi = cum;
-    }
-    const int64_t u0 = static_cast<int64_t>(lo / 8.0 * units), u1 = rho == 7 ? units : static_cast<int64_t>(hi / 8.0 * units);
-    j_begin = (u0 + (blockIdx.x >> 3)) * blockDim.x + threadIdx.x;
-    j_end = min(u1 * static_cast<int64_t>(blockDim.x), npair);
-    j_stride = static_cast<int64_t>(gridDim.x >> 3) * blockDim.x;
-  }
-  for (int64_t j = j_begin; j < j_end; j += j_stride) {
-#else
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
-#endif
     const int64_t o = tidx2(j);
     const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);
@@ -873,18 +850,9 @@ hipError_t stamp_hook(StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
 
 template <typename K>
 hipError_t launch_step_kernel(K kern, const StepArgsDev &d0, const LaunchCfg &lc, hipStream_t st) {
-#if defined(PIC1DP_TUNE_STAMPS) || defined(PIC1DP_TUNE_XCD_SKEW)
-  StepArgsDev d = d0;
 #ifdef PIC1DP_TUNE_STAMPS
+  StepArgsDev d = d0;
   if (hipError_t e = stamp_hook(d, lc, st); e != hipSuccess) return e;
-#endif
-#ifdef PIC1DP_TUNE_XCD_SKEW
-  {
-    const char *e = std::getenv("PIC1DP_XCD_SKEW");
-    d.xcd_skew = e ? std::atof(e) : 0.0;
-    if (lc.blocks % 8) return hipErrorInvalidValue;  // (the tuning build's split wants whole rounds of the eight XCDs)
-  }
-#endif
 #else
   const StepArgsDev &d = d0;
 #endif

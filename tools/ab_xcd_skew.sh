@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the tuning code this drives was taken out of the kernel after the experiment: check out commit d5b7589 to run it again)
 # is the kernel held up by the slower (odd) XCDs?  The tuning build -DPIC1DP_TUNE_XCD_SKEW splits the pairs in eight
 # pools, one per XCD, of 1 +- skew of an equal share (PIC1DP_XCD_SKEW; odd XCDs take less):
 #   PIC1DP_EXTRA_FLAGS=-DPIC1DP_TUNE_XCD_SKEW PIC1DP_LIB_OUT=$PWD/pic1dp_amd/lib/v_skew.so python pic1dp_amd/build.py --force
