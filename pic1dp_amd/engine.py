@@ -261,11 +261,12 @@ class Pic1dp:
         check(self.L.pic1dp_hip_energy_sums(self._ctx, ispecies, _ptr(out)))
         return out
 
-    def cell_indices(self, ispecies=0):
+    def cell_indices(self, ispecies=0, want_ix=True):
+        """cell of every valid marker and markers per cell (want_ix=False: the counts only -- no host array per marker)"""
         _, npv = self.local_sizes(ispecies)
-        ix = np.empty(npv, dtype=np.int32)
+        ix = np.empty(npv, dtype=np.int32) if want_ix else None
         cnt = np.empty(self.inp.nx, dtype=np.int64)
-        check(self.L.pic1dp_hip_cell_indices(self._ctx, ispecies, _ptr(ix), _ptr(cnt)))
+        check(self.L.pic1dp_hip_cell_indices(self._ctx, ispecies, _ptr(ix) if want_ix else None, _ptr(cnt)))
         return ix, cnt
 
     # -- diagnostics of output_all (src/pic1dp_output.F90) ------------------------
