@@ -336,9 +336,22 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
 // accumulators the previous launch read.  Ends without a barrier: the caller's follows.
 // ---------------------------------------------------------------------------
 constexpr int FUSED_CHAIN_W = 8;  // register batch of the serial sums inside a kernel held to 80 VGPRs
-template <bool TILE_EH>
-__device__ __forceinline__ void fused_solve(const FusedSolve &fs, double *sE0, double *sX, double *sSc, double &re_h,
-                                            double &im_h) {
+// The marker loop's tables A = 2 fre, B = 2 fim (exact doublings: capi.cpp builds tabA / tabB that way) are staged by the
+// solve itself from the fre / fim it loads for its products, and its inverse transforms read them back from the LDS
+// (halved: exact again) -- one trip to memory in the prologue instead of three (tabA / tabB, fre / fim, fre / fim again).
+struct TabCells {  // k_step_one: [cell][A B]
+  double *ab;
+  __device__ __forceinline__ void put(int c, double a, double b) const { ab[2 * c] = a, ab[2 * c + 1] = b; }
+  __device__ __forceinline__ void get(int c, double &a, double &b) const { a = ab[2 * c], b = ab[2 * c + 1]; }
+};
+struct TabTiles {  // k_step_sums: a tile each
+  double *sa, *sb;
+  __device__ __forceinline__ void put(int c, double a, double b) const { sa[c] = a, sb[c] = b; }
+  __device__ __forceinline__ void get(int c, double &a, double &b) const { a = sa[c], b = sb[c]; }
+};
+template <bool TILE_EH, class TAB>
+__device__ __forceinline__ void fused_solve(const FusedSolve &fs, const TAB &tab, double *sE0, double *sX, double *sSc,
+                                            double &re_h, double &im_h) {
   const FieldArgs &f = fs.f;
   const int nx = f.nx;
   double *sMode = sSc, *sScr = sSc + 8, *sPart = sSc + 24;
@@ -357,8 +370,11 @@ __device__ __forceinline__ void fused_solve(const FusedSolve &fs, double *sE0, d
       f.charge[ix] = c2;
       f.chargeden[ix] = cd;
     }
-    sPc[ix] = f.fre[ix] * cd;
-    sPs[ix] = f.fim[ix] * cd;
+    const double tr = f.fre[ix], ti = f.fim[ix];
+    tab.put(ix, 2.0 * tr, 2.0 * ti);
+    if (ix == 0) tab.put(nx, 2.0 * tr, 2.0 * ti);  // the guard cell behind the last one
+    sPc[ix] = tr * cd;
+    sPs[ix] = ti * cd;
   }
   if (lead) {  // the accumulators the previous launch read: nobody looks at them any more
     for (int64_t i = threadIdx.x; i < fs.zero_rho_n; i += blockDim.x) fs.zero_rho[i] = 0.0;
@@ -404,7 +420,9 @@ __device__ __forceinline__ void fused_solve(const FusedSolve &fs, double *sE0, d
   }
   double e2 = 0.0;
   for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {  // both inverse transforms, :251-257
-    const double tr = f.fre[ix], ti = f.fim[ix];
+    double tA, tB;
+    tab.get(ix, tA, tB);
+    const double tr = 0.5 * tA, ti = 0.5 * tB;  // fre, fim: bit for bit
     double a = 0.0;
     a = a + tr * re;
     a = a + ti * im;
@@ -527,16 +545,18 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
       sEh[i] = a.Eh[i];
     }
   }
-  for (int i = threadIdx.x; i < nm * (nx + 1); i += blockDim.x) {
-    const int m = i / (nx + 1), c = i - m * (nx + 1), cs = c < nx ? c : 0;  // cell nx: the guard, = cell 0
-    sAB[c * 2 * nm + 2 * m] = a.tabA[m * nx + cs];
-    sAB[c * 2 * nm + 2 * m + 1] = a.tabB[m * nx + cs];
+  if constexpr (!FUSED) {
+    for (int i = threadIdx.x; i < nm * (nx + 1); i += blockDim.x) {
+      const int m = i / (nx + 1), c = i - m * (nx + 1), cs = c < nx ? c : 0;  // cell nx: the guard, = cell 0
+      sAB[c * 2 * nm + 2 * m] = a.tabA[m * nx + cs];
+      sAB[c * 2 * nm + 2 * m + 1] = a.tabB[m * nx + cs];
+    }
   }
   zero_rho(sR0, a.g);
   if constexpr (FUSED) {  // E0 and Eh of this step from the previous launch's deposits and six sums (scratch: the
                           // head of the slots, zeroed behind it)
     double re_h, im_h;
-    fused_solve<true>(a.fused, sE0, sEh, sP, re_h, im_h);
+    fused_solve<true>(a.fused, TabCells{sAB}, sE0, sEh, sP, re_h, im_h);  // (stages sAB as well)
     __syncthreads();
   } else if (threadIdx.x == 0) {
     sE0[nx] = a.E0[0];
@@ -725,20 +745,23 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   double *sB = sA + ne;
   double *sR0 = sB + ne;
   double *sScr = sR0 + ((nx * a.g.rcopies + 2) & ~1);  // [6][16] reduction scratch
-  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-    if constexpr (!FUSED) sE0[i] = a.E0[i];
-    sA[i] = a.tabA[i];
-    sB[i] = a.tabB[i];
-  }
-  if (threadIdx.x == 0) {
-    if constexpr (!FUSED) sE0[nx] = a.E0[0];
-    sA[nx] = a.tabA[0];
-    sB[nx] = a.tabB[0];
+  if constexpr (!FUSED) {
+    for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+      sE0[i] = a.E0[i];
+      sA[i] = a.tabA[i];
+      sB[i] = a.tabB[i];
+    }
+    if (threadIdx.x == 0) {
+      sE0[nx] = a.E0[0];
+      sA[nx] = a.tabA[0];
+      sB[nx] = a.tabB[0];
+    }
   }
   double re_h, im_h;
   if constexpr (FUSED) {  // E0 and the kept mode of Eh from the previous launch's deposits and six sums; the rho tile
                           // holds the second row of products meanwhile
-    fused_solve<false>(a.fused, sE0, sR0, sScr, re_h, im_h);  // (its sums have left the rho tile behind its last barrier)
+    fused_solve<false>(a.fused, TabTiles{sA, sB}, sE0, sR0, sScr, re_h, im_h);  // (stages sA, sB as well; its sums have left
+                                                                               // the rho tile behind its last barrier)
   } else {
     re_h = *a.eh_re;
     im_h = *a.eh_im;
