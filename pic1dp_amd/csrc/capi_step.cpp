@@ -393,8 +393,6 @@ static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
   return lc;
 }
 
-// the particle kernel(s) of one sub-step of the whole-step path: E0 = field at
-// the start of the step, Eh = field after the first sub-step (full only)
 // does output_all follow the step that is being taken?  (src/pic1dp.F90:98-107 evaluated one step ahead)
 static bool output_follows_at(const pic1dp_ctx *c, int32_t itime0, double time0) {  // (counters at the start of the step)
   const pic1dp_input &in = c->in;
@@ -484,6 +482,8 @@ static LaunchCfg pred_launch(const pic1dp_ctx *c, int64_t np, bool priv, int64_t
   return lc;
 }
 
+// the particle kernel(s) of one sub-step of the whole-step path: E0 = field at the start of the step, Eh = field after
+// the first sub-step (full only).
 // full = true: the caller has bumped state_version for this step; the state the kernel READS is version - 1
 static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag, bool pred) {
   if (pred && (!full || diag || !predict_capable(c))) pred = false;
