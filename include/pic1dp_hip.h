@@ -279,14 +279,19 @@ int pic1dp_hip_set_step_mode(pic1dp_ctx *ctx, int32_t mode);
 /* how step mode 0 predicts the next first sub-step's charge for this input: 0 not at
  * all (two passes per step), 1 prediction tiles (k_step_one), 2 six sums (k_step_sums) */
 int pic1dp_hip_predict_kind(pic1dp_ctx *ctx, int32_t *kind);
-/* on != 0: a time step after which the driver will call output_all (the cadence test of
- * src/pic1dp.F90:98-107 evaluated one step ahead from the library's time, see set_time; the
- * last step of a pic1dp_hip_step call, or the collect_charge that follows push(2)) takes the
- * histograms of output_ptcldist and the kinetic sums of output_field inside its second
- * kernel, on the state it has just computed: pic1dp_hip_output_scalars / pic1dp_hip_ptcldist
- * then cost no pass over the markers.  Results equal the separate pass up to the summation
- * order of the atomics.  Off by default (a host that never asks for output would pay ~30 % on
- * that one kernel launch for nothing). */
+/* Diagnostics of output_all taken inside the time step that precedes it.  A step after which the
+ * driver will call output_all (the cadence test of src/pic1dp.F90:98-107 evaluated one step ahead
+ * from the library's time, see set_time; the last step of a pic1dp_hip_step call, or the
+ * collect_charge that follows push(2)) can take the histograms of output_ptcldist and the kinetic
+ * sums of output_field inside its marker kernel, on the state it has just computed
+ * (k_step_full<DIAG>): pic1dp_hip_output_scalars / pic1dp_hip_ptcldist then cost no pass over the
+ * markers.  Results equal the separate pass up to the summation order of the atomics.
+ *   on = 0 (default): never -- a host that never asks for output would pay ~30 % on that launch;
+ *   on = 1: where it pays.  Not on a predicted one-pass step (pic1dp_hip_predict_kind != 0):
+ *           k_step_full<DIAG> cannot predict the next step's half-step charge, so the step after
+ *           the output would run a first-sub-step pass again; there the step stays k_step_one and
+ *           the diagnostics take their own pass (32 B per marker) when output_all asks for them;
+ *   on = 2: always. */
 int pic1dp_hip_set_output_fusion(pic1dp_ctx *ctx, int32_t on);
 /* which field solve pic1dp_hip_solve_field / substep / step perform:
  *   0 (default) the reference's field_solve_electric: mode-filtered partial DFT
@@ -310,6 +315,12 @@ int pic1dp_hip_set_time(pic1dp_ctx *ctx, int32_t itime, double time);
 int pic1dp_hip_check_termination(pic1dp_ctx *ctx, int32_t *flag);
 /* output cadence test of src/pic1dp.F90:98-106 evaluated at the current time */
 int pic1dp_hip_output_due(pic1dp_ctx *ctx, int32_t itermination, int32_t *flag);
+/* how many iterations of the driver loop (src/pic1dp.F90:78-109) lie between the current counters and the next
+ * output_all -- the cadence test of :98-106 and check_termination (:133-148) evaluated ahead, step by step, with
+ * the very additions the loop makes (time = time + dt).  A host that hands the whole irk loop to
+ * pic1dp_hip_step can ask for exactly that many steps in one call and loses no record: *nsteps >= 1 while the run
+ * has not terminated, 0 once it has. */
+int pic1dp_hip_steps_to_output(pic1dp_ctx *ctx, int32_t *nsteps);
 
 /* ---- field access (what output_field reads, src/pic1dp_output.F90:173-186) */
 /* any pointer may be NULL; E, chargeden: [nx]; mode_re, mode_im: [nmode].
@@ -473,7 +484,11 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
  * between host and device so far, *ms = 0; which = 9: *launches = how the serial forward
  * sums of the field solve (one-rank order, up to eight kept modes) run: 0 chains of
  * additions in single lanes, 1 through the FP64 matrix unit (only where pic1dp_hip_create
- * found it to reproduce the sequential sums bit for bit; PIC1DP_CHAIN_MFMA=0 keeps the chains) */
+ * found it to reproduce the sequential sums bit for bit; PIC1DP_CHAIN_MFMA=0 keeps the chains),
+ * *ms = that self-test's verdict (1 identical, 0 differs, -1 it could not run: the chains then);
+ * which = 10: *launches = marker launches so far whose last workgroup packed this rank's charge
+ * for the sum over ranks or posted it into the peers' exchange slots itself (several ranks: no
+ * separate packing launch in front of the all-reduce; PIC1DP_TAIL=0 keeps that launch), *ms = 0 */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

@@ -33,7 +33,7 @@ PRODUCT_UNITS = [("kernels_step.hip", ["-DPIC1DP_STEP_DIST=%d" % d], "kernels_st
     ("optimize.cpp", [], "optimize"), ("species.cpp", [], "species"), ("hostcheck.cpp", [], "hostcheck")]
 PROBE_UNITS = [("probe.hip", [], "probe"), ("optcheck.cpp", [], "optcheck")]
 PROBE_SHARED = ["species", "hostcheck", "optimize", "multirand"]      # objects of the product the probe library links as well
-HEADERS = ["kernels.hpp", "device_math.hpp", "device_field.hpp", "device_diag.hpp", "step_args.hpp", "check_values.hpp", "loader.hpp",
+HEADERS = ["kernels.hpp", "device_math.hpp", "device_field.hpp", "device_diag.hpp", "device_xchg.hpp", "step_args.hpp", "check_values.hpp", "loader.hpp",
            "multirand.hpp", "optimize.hpp", "rccl_dyn.hpp", "ctx.hpp",
            os.path.join("..", "..", "include", "pic1dp_hip.h"), os.path.join("..", "..", "include", "pic1dp_probe.h")]
 

@@ -225,6 +225,90 @@ int pic1dp_hip_host_multirand_int64(int32_t al_int, int32_t seed_type, int32_t m
   return 0;
 }
 
+// The create()-time self-test behind FieldArgs::chain_mfma (device_field.hpp chain_rows_mfma): do the serial sums come out
+// of the FP64 matrix unit bit for bit as the host's additions one after the other?  Two data sets of sixteen rows of 1031
+// values: A mixed signs, exponents in [-20, 20]; B the corners -- rows whose partial sums nearly cancel (a term, then its
+// negative one ulp off, then small terms), rows of subnormal terms, rows mixing the smallest normals with subnormals, rows
+// whose sums cross 2^-1022 in both directions (where a matrix unit's denormal handling would show).
+// Returns 1 the matrix unit agrees in every bit of both sets, 0 it does not, -1 the test could not run (any HIP failure:
+// an optional optimisation must not fail create(); the error state is cleared), -2 the ONE-LANE chain differs from the
+// host on set A (fatal for the caller: that is the arithmetic the solve's bit-identity rests on).
+static int chain_selftest(pic1dp_ctx *c) {
+  constexpr int kn = 1031, kr = 16;
+  std::vector<double> v(2 * kr * kn);
+  uint64_t z = 0x9E3779B97F4A7C15ull;
+  auto next = [&z]() {  // splitmix64
+    z += 0x9E3779B97F4A7C15ull;
+    uint64_t y = z;
+    y = (y ^ (y >> 30)) * 0xBF58476D1CE4E5B9ull;
+    y = (y ^ (y >> 27)) * 0x94D049BB133111EBull;
+    return y ^ (y >> 31);
+  };
+  auto make = [](uint64_t sign, uint64_t biased_exp, uint64_t frac) {
+    const uint64_t bits = (sign << 63) | (biased_exp << 52) | (frac & 0xFFFFFFFFFFFFFull);
+    double x;
+    std::memcpy(&x, &bits, 8);
+    return x;
+  };
+  for (int i = 0; i < kr * kn; ++i) {  // A: sign, exponent in [-20, 20], random significand
+    const uint64_t y = next();
+    v[i] = make(y >> 63, 1023 - 20 + (y >> 52) % 41, y);
+  }
+  for (int r = 0; r < kr; ++r) {
+    double *row = v.data() + static_cast<size_t>(kr + r) * kn;
+    for (int i = 0; i < kn; ++i) {
+      const uint64_t y = next();
+      switch (r & 3) {
+        case 0:  // near cancellation: x, -(x one ulp off), then a term 2^-40 .. 2^-60 of x
+          if (i % 3 == 0)
+            row[i] = make(y >> 63, 1023 + (y >> 52) % 7, y);
+          else if (i % 3 == 1)
+            row[i] = -std::nextafter(row[i - 1], (y & 1) ? 4e300 : 0.0);
+          else
+            row[i] = std::ldexp(row[i - 2], -40 - static_cast<int>((y >> 52) % 21));
+          break;
+        case 1:  // subnormal terms only
+          row[i] = make(y >> 63, 0, y);
+          break;
+        case 2:  // the smallest normals among subnormals
+          row[i] = make(y >> 63, (y >> 52) % 3, y);
+          break;
+        default:  // partial sums that cross the normal / subnormal border both ways
+          row[i] = (i & 1) ? -make(0, 1 + (y >> 52) % 2, y) : make(0, 1 + (y >> 53) % 2, y >> 1);
+          break;
+      }
+    }
+  }
+  double want[2 * kr];
+  for (int r = 0; r < 2 * kr; ++r) {
+    volatile double t = 0.0;  // (one rounding per addition whatever the compiler would like)
+    for (int i = 0; i < kn; ++i) t = t + v[static_cast<size_t>(r) * kn + i];
+    want[r] = t;
+  }
+  double *d_v = nullptr;
+  double got[2][32];
+  hipError_t err = hipMalloc(&d_v, sizeof(double) * (2 * kr * kn + 64));
+  if (err == hipSuccess) err = hipMemcpy(d_v, v.data(), sizeof(double) * 2 * kr * kn, hipMemcpyHostToDevice);
+  for (int set = 0; set < 2 && err == hipSuccess; ++set)
+    err = launch_chain_selftest(d_v + static_cast<size_t>(set) * kr * kn, kr, kn, d_v + 2 * kr * kn + 32 * set, c->st);
+  if (err == hipSuccess) err = hipStreamSynchronize(c->st);
+  if (err == hipSuccess) err = hipMemcpy(got, d_v + 2 * kr * kn, sizeof got, hipMemcpyDeviceToHost);
+  (void)hipFree(d_v);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();  // cleared: the next call must not trip over this one's error
+    return -1;
+  }
+  if (std::memcmp(got[0], want, sizeof(double) * kr) != 0) return -2;
+  const bool a_ok = std::memcmp(got[0] + 16, want, sizeof(double) * kr) == 0;
+  const bool b_ok = std::memcmp(got[1] + 16, want + kr, sizeof(double) * kr) == 0;
+  if (const char *dbg = std::getenv("PIC1DP_CHAIN_SELFTEST_VERBOSE"))
+    if (std::atoi(dbg) != 0)
+      std::fprintf(stderr, "pic1dp: chain self-test: matrix unit set A %s, set B (cancellation, subnormals) %s; one-lane chain set B %s\n",
+                   a_ok ? "identical" : "DIFFERS", b_ok ? "identical" : "DIFFERS",
+                   std::memcmp(got[1], want + kr, sizeof(double) * kr) == 0 ? "identical" : "DIFFERS");
+  return a_ok && b_ok ? 1 : 0;
+}
+
 int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1dp_ctx **out) {
   if (!in || !layout || !out) return fail(PIC1DP_ERR_ARG, "null argument");
   *out = nullptr;
@@ -321,6 +405,9 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMemsetAsync(c->d_rho_all, 0, sizeof(double) * 3 * rho_doubles, c->st));
   c->d_rho_sp = c->d_rho_all;
   if (const char *e = std::getenv("PIC1DP_FUSE_SOLVE")) c->fuse_solve = std::max(0, std::min(2, std::atoi(e)));
+  if (const char *e = std::getenv("PIC1DP_TAIL")) c->tail_on = std::atoi(e) != 0;
+  HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&c->d_ticket), 64));
+  HIP_TRY_C(hipMemsetAsync(c->d_ticket, 0, 64, c->st));
   for (int s = 0; s < ns; ++s) {
     Species &S = c->sp[s];
     S.nalloc = nalloc;
@@ -472,37 +559,13 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   {
     const char *e = std::getenv("PIC1DP_CHAIN_MFMA");
     if (!e || std::atoi(e) != 0) {
-      constexpr int kn = 1031, kr = 16;
-      std::vector<double> v(kr * kn);
-      uint64_t z = 0x9E3779B97F4A7C15ull;
-      for (double &x : v) {  // splitmix64 -> sign, exponent in [-20, 20], random significand
-        z += 0x9E3779B97F4A7C15ull;
-        uint64_t y = z;
-        y = (y ^ (y >> 30)) * 0xBF58476D1CE4E5B9ull;
-        y = (y ^ (y >> 27)) * 0x94D049BB133111EBull;
-        y ^= y >> 31;
-        const uint64_t bits = (y & 0x8000000000000000ull) | ((1023 - 20 + (y >> 52) % 41) << 52) | (y & 0xFFFFFFFFFFFFFull);
-        std::memcpy(&x, &bits, 8);
-      }
-      double want[kr];
-      for (int r = 0; r < kr; ++r) {
-        volatile double t = 0.0;  // (one rounding per addition whatever the compiler would like)
-        for (int i = 0; i < kn; ++i) t = t + v[r * kn + i];
-        want[r] = t;
-      }
-      double *d_v = nullptr;
-      double got[32];
-      HIP_TRY_C(hipMalloc(&d_v, sizeof(double) * (kr * kn + 32)));
-      HIP_TRY_C(hipMemcpy(d_v, v.data(), sizeof(double) * kr * kn, hipMemcpyHostToDevice));
-      HIP_TRY_C(launch_chain_selftest(d_v, kr, kn, d_v + kr * kn, c->st));
-      HIP_TRY_C(hipStreamSynchronize(c->st));
-      HIP_TRY_C(hipMemcpy(got, d_v + kr * kn, sizeof got, hipMemcpyDeviceToHost));
-      (void)hipFree(d_v);
-      if (std::memcmp(got, want, sizeof want) != 0) {
+      const int verdict = chain_selftest(c);
+      if (verdict == -2) {  // (the lane's own chain: the arithmetic every bit-identity claim of the solve rests on)
         pic1dp_hip_destroy(c);
         return fail(PIC1DP_ERR_HIP, "the device's serial sum differs from the host's sequential additions");
       }
-      f.chain_mfma = std::memcmp(got + 16, want, sizeof want) == 0 ? 1 : 0;
+      f.chain_mfma = verdict == 1 ? 1 : 0;  // -1 (the test itself could not run): the optimisation is simply off
+      c->chain_selftest = verdict;
       if (e && std::atoi(e) > 0 && f.chain_mfma == 0) {
         pic1dp_hip_destroy(c);
         return fail(PIC1DP_ERR_HIP, "PIC1DP_CHAIN_MFMA asked for, but the matrix unit does not give the sequential sums on this device");
@@ -532,6 +595,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
   double *bufs[] = {c->d_rho_all, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
                     c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred_all, c->d_cd_h, c->d_mode_h, c->d_Ehn, c->d_pack};
   for (double *b : bufs) (void)hipFree(b);
+  (void)hipFree(c->d_ticket);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -782,6 +846,27 @@ int pic1dp_hip_output_due(pic1dp_ctx *c, int32_t itermination, int32_t *flag) {
   return 0;
 }
 
+int pic1dp_hip_steps_to_output(pic1dp_ctx *c, int32_t *nsteps) {
+  CHECK_CTX(c);
+  if (!nsteps) return fail(PIC1DP_ERR_ARG, "null output");
+  const pic1dp_input &in = c->in;
+  int32_t it = c->itime, n = 0;
+  double t = c->time;
+  // src/pic1dp.F90:78-109 walked ahead: step, check_termination, the cadence test
+  while (!(it >= in.ntime_max || t + kSqrtEps >= in.time_max)) {
+    it += 1;
+    t = t + in.dt;
+    n += 1;
+    if (it >= in.ntime_max || t + kSqrtEps >= in.time_max) break;  // the last step always writes
+    if (in.output_interval > 0.0 &&
+        std::fmod(t + kSqrtEps, in.output_interval) < std::fmod(t + kSqrtEps - in.dt, in.output_interval))
+      break;
+    if (n == 0x7fffffff) break;
+  }
+  *nsteps = n;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // field access
 // ---------------------------------------------------------------------------
@@ -934,9 +1019,14 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 9) return fail(PIC1DP_ERR_ARG, "which must be 0..9");
-  if (which == 9) {  // how the serial forward sums of the one-rank order run: 0 chains of additions, 1 the matrix unit
+  if (which < 0 || which > 10) return fail(PIC1DP_ERR_ARG, "which must be 0..10");
+  if (which == 10) {  // marker launches whose last workgroup packed / posted this rank's charge (kernels.hpp StepTail)
     if (ms) *ms = 0.0;
+    if (launches) *launches = c->tail_launches;
+    return 0;
+  }
+  if (which == 9) {  // how the serial forward sums of the one-rank order run: 0 chains of additions, 1 the matrix unit
+    if (ms) *ms = static_cast<double>(c->chain_selftest);  // create()'s self-test: 1 identical, 0 differs, -1 could not run
     if (launches) *launches = c->fa.chain_mfma;
     return 0;
   }

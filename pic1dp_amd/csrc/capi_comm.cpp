@@ -229,7 +229,10 @@ int pic1dp_hip_xchg_time(pic1dp_ctx *c, double *ms, int64_t *exchanges_timed, in
   HIP_TRY(hipMemcpy(t, c->xc.ticks, sizeof t, hipMemcpyDeviceToHost));
   if (ms) *ms = static_cast<double>(t[0]) * 1e-5;  // 100 MHz wall clock
   if (exchanges_timed) *exchanges_timed = static_cast<int64_t>(t[1]);
-  if (reset) HIP_TRY(hipMemset(c->xc.ticks, 0, sizeof t));
+  if (reset) {  // on the stream the exchange kernels run on: ordered against the next exchange's additions
+    HIP_TRY(hipMemsetAsync(c->xc.ticks, 0, sizeof t, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+  }
   return xchg_check(c);
 }
 

@@ -13,6 +13,15 @@ size_t dist_len(const pic1dp_input &in) {
 
 int diag_max_blocks(const pic1dp_ctx *c) { return 2 * c->num_cu; }
 
+// the histogram geometry with its constant divisors vouched for, formed once per context
+const DistGeom &dist_geom(pic1dp_ctx *c) {
+  if (!c->dist_geom_ready) {
+    c->dist_geom_v = make_dist_geom(c->in.lx, c->in.v_max, c->in.nx_opd, c->in.nv_opd);
+    c->dist_geom_ready = true;
+  }
+  return c->dist_geom_v;
+}
+
 // buffers of the marker diagnostics: [nspecies] cached histograms + one for the all-reduced
 // copy handed out, per-workgroup partial sums per species
 int diag_buffers(pic1dp_ctx *c) {
@@ -43,8 +52,7 @@ int ensure_diag(pic1dp_ctx *c, int isp) {
     c->diag_blocks[isp] = 0;
     if (S.np > 0) {
       c->diag_blocks[isp] = ptcldist_blocks(S.np, in.nx_opd, in.nv_opd, c->num_cu);
-      HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, in.lx, in.v_max, in.nx_opd, in.nv_opd, in.deltaf == 1, hist,
-                              part_dev, c->num_cu, c->st));
+      HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, dist_geom(c), in.deltaf == 1, hist, part_dev, c->num_cu, c->st));
       c->diag_passes++;
     }
     c->diag_pending[isp] = 1;

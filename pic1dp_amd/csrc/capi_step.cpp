@@ -98,12 +98,13 @@ int enqueue_deposit(pic1dp_ctx *c) {
 
 static bool step_recompute_ok(const pic1dp_ctx *c);
 static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag = false,
-                          bool pred = false);
+                          bool pred = false, bool tail_ok = false);
 static bool predict_capable(const pic1dp_ctx *c);
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full);
 static LaunchCfg pred_launch(const pic1dp_ctx *c, int64_t np, bool priv, int64_t *resident);
 static bool output_follows(const pic1dp_ctx *c);
 static bool output_follows_at(const pic1dp_ctx *c, int32_t itime0, double time0);
+static bool diag_in_step(const pic1dp_ctx *c);
 static int finish_pending_solve(pic1dp_ctx *c);
 static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred);
 static bool pred_usable(const pic1dp_ctx *c);
@@ -197,7 +198,7 @@ static int deposit_or_step(pic1dp_ctx *c) {
   }
   if (c->lz == LZ_PUSH2) {
     c->state_version++;
-    const bool diag = c->fuse_output && output_follows(c);
+    const bool diag = diag_in_step(c) && output_follows(c);
     // Eh = d_E: the kept modes describe it when the mode-filter solve wrote it last
     c->eh_modes = (c->field_solver == 0 && c->modes_field_version == c->field_version) ? 1 : 0;
     if (int rc = step_particles(c, true, c->d_E0, c->d_E, diag, !diag)) return rc;
@@ -403,6 +404,16 @@ static bool output_follows_at(const pic1dp_ctx *c, int32_t itime0, double time0)
 }
 static bool output_follows(const pic1dp_ctx *c) { return output_follows_at(c, c->itime, c->time); }
 
+// Does a step that output_all follows take the diagnostics inside its marker kernel (k_step_full<DIAG>)?
+// fuse_output 2: always.  1 (what a host that calls output_all at the reference's cadence asks for): only where the step
+// is not a predicted one-pass step anyway.  Where it is, k_step_full<DIAG> costs the prediction -- the step after the
+// output pays a first-sub-step pass again (k_step_half): 10 steps + output_all at 1e8 markers 10.57 ms against 9.5 for
+// ten plain steps --, whereas k_step_one followed by the diagnostics' own pass (k_ptcldist: it changes no marker, the
+// prediction stays valid) costs that pass alone (profiles/r05/experiments/diag_bench.log).
+static bool diag_in_step(const pic1dp_ctx *c) {
+  return c->fuse_output == 2 || (c->fuse_output == 1 && !predict_capable(c));
+}
+
 // One pass per step (kernels_step.hip k_step_one) needs: the mode-filter solver (the kept modes must
 // describe E), few kept modes, and LDS for E0, Eh, the mode tables and the four accumulators
 static bool predict_capable(const pic1dp_ctx *c) {
@@ -449,7 +460,9 @@ static bool fuse_capable(const pic1dp_ctx *c) {
     if (c->sp[s].np <= 0) continue;
     int64_t resident = 0;
     const LaunchCfg lc = pred_launch(c, c->sp[s].np, priv, &resident);
-    return lc.blocks <= resident;  // (the first species launched carries the solve)
+    // (the first species launched carries the solve; the prologue needs a first and a last wave of its own:
+    // lean_forward_sums runs its chains in wave 0 while the last wave adds up the copies of the six sums)
+    return lc.blocks <= resident && lc.threads >= 128 && lc.threads % 64 == 0;
   }
   return false;
 }
@@ -485,7 +498,10 @@ static LaunchCfg pred_launch(const pic1dp_ctx *c, int64_t np, bool priv, int64_t
 // the particle kernel(s) of one sub-step of the whole-step path: E0 = field at the start of the step, Eh = field after
 // the first sub-step (full only).
 // full = true: the caller has bumped state_version for this step; the state the kernel READS is version - 1
-static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag, bool pred) {
+// tail_ok (the step() path on several ranks): the last species' launch may pack / post this rank's charge in its tail
+// (kernels.hpp StepTail) -- c->tail_done tells solve_phase what it did
+static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const double *Eh, bool diag, bool pred, bool tail_ok) {
+  c->tail_done = 0;
   if (pred && (!full || diag || !predict_capable(c))) pred = false;
   const bool priv = c->pred_kind == 2 && c->pred_private && c->threads_req <= 0;  // k_step_one<PRIV>: Eh from its tile
   if (pred && c->pred_kind == 2 && !priv && c->eh_modes == 0) pred = false;  // k_step_sums forms Eh from its kept mode
@@ -500,6 +516,16 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
   }
   if (diag)
     if (int rc = diag_buffers(c)) return rc;
+  // several ranks, the six sums of one kept mode, the mode-filter solver: the packing of this rank's charge for the sum
+  // over ranks rides in the tail of the last marker launch (RCCL: one all-reduce follows; exchange: posted at once)
+  int tail_mode = 0, tail_species = -1;
+  if (tail_ok && pred && c->tail_on && c->pred_kind == 2 && c->in.nmode == 1 && c->field_solver == 0 &&
+      (c->lay.nranks > 1 || c->comm != nullptr)) {
+    tail_mode = xchg_active(c) ? 2 : (c->comm != nullptr ? 1 : 0);
+    for (int s = 0; s < c->in.nspecies; ++s)
+      if (c->sp[s].np > 0) tail_species = s;
+    if (tail_species < 0) tail_mode = 0;
+  }
   // x, v, w, p of all species against the 256 MiB Infinity Cache
   double state_bytes = 0.0;
   for (int s = 0; s < c->in.nspecies; ++s) state_bytes += 32.0 * static_cast<double>(c->sp[s].np);
@@ -548,6 +574,9 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     }
     LaunchCfg lc = step_launch(c, S.np, full);
     if (pred && c->fuse_args.on) {  // this launch's prologue solves the previous step's field (first species launched)
+      const LaunchCfg fl = pred_launch(c, S.np, priv, nullptr);
+      if (fl.threads < 128 || fl.threads % 64 != 0)  // what fuse_capable promised (checked at the launch too)
+        return fail(PIC1DP_ERR_STATE, "internal: fused field solve in a launch of %d threads", fl.threads);
       a.fused = c->fuse_args;
       c->fuse_args.on = 0;
       c->fused_solves++;
@@ -580,10 +609,30 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
         S.t2_version = c->state_version;
       }
       lc = pred_launch(c, S.np, priv, nullptr);
+      if (tail_mode != 0 && s == tail_species && !a.fused.on) {
+        StepTail &t = a.tail;
+        t.mode = tail_mode;
+        t.ticket = c->d_ticket;
+        t.rho_sp = c->fa.rho_sp;
+        t.rho_copies = c->fa.rho_copies;
+        t.rho_stride = c->fa.rho_stride;
+        t.nspecies = c->in.nspecies;
+        t.nx = c->in.nx;
+        for (int k = 0; k < 8; ++k) t.Z[k] = c->fa.Z[k];
+        t.sums = c->d_pred;
+        t.pack = c->d_pack;
+        if (tail_mode == 2) {
+          c->tail_x = next_xchg_args(c);
+          t.x = c->tail_x;
+          t.x.ticks = nullptr;  // (the field launch's half of the exchange is the one the attribution times)
+        }
+        c->tail_done = tail_mode;
+        c->tail_launches++;
+      }
     }
     if (diag) {  // one workgroup of 1024 threads per CU: grid tiles + histograms in its LDS
       const size_t ntot = dist_len(c->in);
-      a.dg = DistGeom{c->in.lx, c->in.v_max, c->in.nx_opd, c->in.nv_opd};
+      a.dg = dist_geom(c);
       a.dist_out = c->d_dist + ntot * s;
       a.dist_partial = c->d_diag_part + static_cast<size_t>(3) * diag_max_blocks(c) * s;
       HIP_TRY(hipMemsetAsync(a.dist_out, 0, sizeof(double) * ntot, c->st));
@@ -719,7 +768,7 @@ static int step_phase(pic1dp_ctx *c, bool full, double *Eout, bool record, bool 
     c->pred_version = 0;
     c->eh_modes = 2;
   }
-  if (int rc = step_particles(c, full, c->d_E, c->d_Eh, diag, pred)) return rc;
+  if (int rc = step_particles(c, full, c->d_E, c->d_Eh, diag, pred, /*tail_ok=*/full && Eout == c->d_E)) return rc;
   if (fuse_out && pred && c->pred_version == c->state_version) {
     c->fused_pending = true;
     return 0;
@@ -740,8 +789,13 @@ static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred) {
   // RCCL path of a one-pass step: everything the two charge sums of the step need in one all-reduce
   const bool will_pack = pred && c->pred_version == c->state_version && multi && !fused_xchg && c->comm != nullptr &&
                          !xchg_active(c) && c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
+  const int tail_done = c->tail_done;  // what the marker launch's tail has done already (kernels.hpp StepTail)
+  c->tail_done = 0;
+  if (tail_done == 1 && !will_pack) return fail(PIC1DP_ERR_STATE, "internal: a packed charge nobody reduces");
+  if (tail_done == 2 && !(fused_xchg && pred && c->pred_version == c->state_version))
+    return fail(PIC1DP_ERR_STATE, "internal: a posted charge nobody waits for");
   if (will_pack) {
-    {  // the species sum and the packing are collect_charge's share of the step (src/pic1dp_interaction.F90:126-127)
+    if (tail_done != 1) {  // the species sum and the packing are collect_charge's share of the step (src/pic1dp_interaction.F90:126-127)
       Span pk(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
       HIP_TRY(launch_charge_pack(c->fa, c->d_pred, c->in.nmode, c->pred_kind, c->d_pack, c->st));
       if (int rc = pk.end()) return rc;
@@ -770,12 +824,19 @@ static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred) {
   const bool pair = pred && c->pred_version == c->state_version && (!multi || fused_xchg || will_pack) &&
                     c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (pair) {
-    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, c->pair_plain};
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, c->pair_plain, 0};
     if (will_pack) {  // both charge sums of the step came in ONE all-reduce (pack_doubles)
       pa.pack = c->d_pack;
       HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));
     } else if (fused_xchg) {  // ONE exchange: charge2 and the prediction slices travel together
-      const XchgArgs x1 = next_xchg_args(c);
+      XchgArgs x1;
+      if (tail_done == 2) {  // ... and this rank's half of it is under way since the marker launch's tail
+        x1 = c->tail_x;
+        x1.ticks = c->timers_on ? c->xc.ticks : nullptr;
+        pa.posted = 1;
+      } else {
+        x1 = next_xchg_args(c);
+      }
       HIP_TRY(launch_field_solve_pair(f, pa, &x1, c->st));
     } else {
       HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));
@@ -809,7 +870,7 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
       // first-sub-step pass over the markers
       const bool pc = predict_capable(c);
       // the host can only call output_all after the last step of this call
-      const bool diag = c->fuse_output && it == nsteps - 1 && output_follows(c);
+      const bool diag = diag_in_step(c) && it == nsteps - 1 && output_follows(c);
       const bool pred = pc && !diag;
       // the previous step left its solve to this step's marker launch (one launch per step, kernels.hpp FusedSolve)
       const bool fused_in = c->fused_pending && pred && fuse_capable(c);
@@ -830,7 +891,7 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
       // step after an output, an optimisation step or the last step of the call need the field in memory first)
       bool fuse_out = false;
       if (pred && it + 1 < nsteps && fuse_capable(c)) {
-        const bool next_diag = c->fuse_output && it + 1 == nsteps - 1 && output_follows_at(c, c->itime + 1, c->time + c->in.dt);
+        const bool next_diag = diag_in_step(c) && it + 1 == nsteps - 1 && output_follows_at(c, c->itime + 1, c->time + c->in.dt);
         bool due[3];
         optimize_due_at(c, c->time + c->in.dt, due);
         fuse_out = !next_diag && !(due[0] || due[1] || due[2]);
@@ -869,7 +930,8 @@ int pic1dp_hip_predict_kind(pic1dp_ctx *c, int32_t *kind) {
 
 int pic1dp_hip_set_output_fusion(pic1dp_ctx *c, int32_t on) {
   CHECK_CTX(c);
-  c->fuse_output = on != 0;
+  if (on < 0 || on > 2) return fail(PIC1DP_ERR_ARG, "output fusion must be 0 (off), 1 (where it pays) or 2 (always)");
+  c->fuse_output = on;
   return 0;
 }
 

@@ -115,6 +115,13 @@ struct pic1dp_ctx {
   bool charge_pending_pred = false;  // kind 2: charge_local handed out the six sums, not a charge vector
   double *d_Ehn = nullptr;         // half-step field predicted for the NEXT step (d_Eh stays the last step's)
   double *d_pack = nullptr;        // [2 + 2 nmode][nx] one all-reduce per one-pass step (RCCL path)
+  // several ranks, six-sum prediction: the marker launch's last workgroup packs / posts this rank's charge (kernels.hpp
+  // StepTail) instead of a launch of its own in front of the sum over ranks.  PIC1DP_TAIL=0: the separate launch
+  unsigned int *d_ticket = nullptr;  // the tail's arrival counter (zero between launches)
+  int tail_on = 1;
+  int tail_done = 0;                 // what the last marker launch's tail did: 0 nothing, 1 packed into d_pack, 2 posted (tail_x)
+  XchgArgs tail_x{};                 // tail_done == 2: the exchange the field launch has to finish
+  int64_t tail_launches = 0;         // marker launches that carried a tail so far (kernel_stats 10)
   int predict = 1;                 // PIC1DP_PREDICT=0: always two passes per step
   uint64_t pred_version = 0;       // state_version the accumulators in d_pred belong to (0: none)
   uint64_t eh_version = 0;         // state_version d_Eh has been predicted for (step() path)
@@ -168,9 +175,12 @@ struct pic1dp_ctx {
   std::vector<char> diag_pending;          // [nspecies] a pass ran, its partial sums are still on the device
   std::vector<int> diag_blocks;            // [nspecies] workgroups of that pass
   int fuse_output = 0;                     // take the diagnostics inside k_step_full on steps output_all follows
+  DistGeom dist_geom_v{};                  // output_ptcldist's histogram geometry (capi_diag.cpp dist_geom)
+  bool dist_geom_ready = false;
   int64_t opt_pcie_bytes = 0;              // bytes marker optimisation events have moved between host and device
   int64_t diag_passes = 0;                 // separate k_ptcldist passes launched so far
   int64_t fused_solves = 0;                // marker launches whose prologue solved the previous step's field
+  int chain_selftest = 0;                  // create()'s verdict on the serial sums through the matrix unit: 1 identical, 0 differs, -1 could not run
   int32_t itime = 0;
   double time = 0.0;
   GridConst grid{};
@@ -279,6 +289,7 @@ bool optimize_due_any(const pic1dp_ctx *c);
 // ---- capi_diag.cpp ----
 int diag_buffers(pic1dp_ctx *c);
 int diag_max_blocks(const pic1dp_ctx *c);
+const DistGeom &dist_geom(pic1dp_ctx *c);
 size_t dist_len(const pic1dp_input &in);
 
 }  // namespace pic1dp_host

@@ -43,4 +43,19 @@ int64_t host_div_check(double lx, int nx, uint64_t seed, int64_t n) {
   return bad;
 }
 
+// the histogram geometry of output_ptcldist with its two constant divisors prepared (kernels.hpp DistGeom)
+DistGeom make_dist_geom(double lx, double vmax, int nxo, int nvo) {
+  DistGeom dg{};
+  dg.lx = lx;
+  dg.vmax = vmax;
+  dg.nxo = nxo;
+  dg.nvo = nvo;
+  dg.rlx = 1.0 / lx;
+  dg.dv = vmax * 2.0;  // src/pic1dp_output.F90:247
+  dg.rdv = 1.0 / dg.dv;
+  const double ad = std::fabs(dg.dv);
+  dg.vfast = (ad > 0x1p-200 && ad < 0x1p+200 && host_divc_check(dg.dv, 0xD157ull, 50000) == 0) ? 1 : 0;
+  return dg;
+}
+
 }  // namespace pic1dp

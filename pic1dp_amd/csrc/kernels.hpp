@@ -111,7 +111,13 @@ struct PushArgs {
 struct DistGeom {
   double lx, vmax;
   int nxo, nvo;   // nx_opd, nv_opd
+  // the two divisions of :243, :247 are divisions by run-time constants: rlx = RN(1/lx) (GridConst::rlx), dv = vmax * 2.0
+  // and rdv = RN(1/dv); vfast = 1: the host vouches for div_const's five operations on dv (hostcheck.cpp), else the
+  // hardware's division.  Bit for bit the IEEE quotients either way (device_math.hpp div_lx).
+  double rlx, dv, rdv;
+  int vfast;
 };
+DistGeom make_dist_geom(double lx, double vmax, int nxo, int nvo);
 
 // dynamic LDS a particle kernel may ask for: 160 KiB per CU minus the 1 KiB static exp table
 constexpr size_t PARTICLE_LDS_CAP = 159 * 1024;
@@ -148,6 +154,36 @@ struct FieldArgs {
 // matrix (kept-mode reconstruction of chargeden for the call-site path)
 struct PredTab {
   double sum_fre, sum_fim, g11, g22, g12;
+};
+
+// one-hop charge exchange between the GPUs of a node (kernels_field.hip exchange_charge)
+constexpr int XCHG_MAX_RANKS = 16;
+struct XchgArgs {
+  double *slots[XCHG_MAX_RANKS];               // every rank's slot area [2][nranks][nx] as mapped here
+  unsigned long long *flags[XCHG_MAX_RANKS];   // every rank's flag area [2][XCHG_MAX_RANKS]
+  unsigned long long *err;                     // host-visible error word (0 = fine)
+  unsigned long long epoch;                    // number of this exchange, from 1
+  long long timeout_ticks;                     // wall_clock64 ticks (100 MHz) a rank waits for its peers
+  int rank, nranks;
+  int local_in_charge;                         // 1: this rank's charge2 is already in FieldArgs::charge
+  int vstride;                                 // doubles per (parity, rank) slot: XCHG_MAX_VEC * nx
+  unsigned long long *ticks;                   // null, or [2] device words: wall-clock ticks (100 MHz) spent inside
+                                               // exchanges so far (stores, the wait for the peers, the sum) and their number
+};
+// The TAIL of a one-pass marker launch on several ranks (device_xchg.hpp step_tail; k_step_one<PRIV>, k_step_sums, the
+// last species launched): the last workgroup to finish forms this rank's packed vector [charge2 | six sums | pad] from the
+// accumulators (re-zeroed) -- what k_charge_pack_sums did in a launch of its own -- and either leaves it in `pack` for
+// the all-reduce that follows on the stream (mode 1) or stores it into every rank's exchange slots (mode 2), so that
+// the field launch only waits for the flags, adds in rank order and solves.
+struct StepTail {
+  int mode;                    // 0 none, 1 pack for one all-reduce, 2 post into the peers' exchange slots
+  unsigned int *ticket;        // device word, zero between launches: workgroups that have finished
+  double *rho_sp;              // [rho_copies strides][nspecies][nx] the accumulators of ALL species (read, re-zeroed)
+  int rho_copies, rho_stride, nspecies, nx;
+  double Z[8];
+  double *sums;                // [PRED_SUM_COPIES][8] the six sums' copies (read, re-zeroed)
+  double *pack;                // mode 1: [nx + 8]
+  XchgArgs x;                  // mode 2
 };
 
 // A whole-step launch whose PROLOGUE solves the field of the previous step itself (kernels_step.hip FUSED; one rank, one
@@ -201,6 +237,7 @@ struct StepArgs {
                      // thread-private LDS slots (Eh staged from memory like k_step_one's)
   const double *eh_re, *eh_im;
   FusedSolve fused;  // pred_kind 2 only: the prologue solves the previous step's field (E0, Eh, eh_re / eh_im unused)
+  StepTail tail;     // pred_kind 2 only, several ranks: the last workgroup packs / posts this rank's charge (mode 0: no)
 };
 constexpr int PRED_MAX_MODES = 4;  // kept modes k_step_one's prediction tiles are instantiated for (1 .. 4)
 // pred_kind 2: the six sums (padded to 8) are kept in this many copies -- workgroup b of the marker kernel adds into
@@ -244,20 +281,6 @@ hipError_t launch_deposit(double *x, const double *q, double *rho, int64_t np, c
                           const LaunchCfg &lc, hipStream_t st);
 
 
-// one-hop charge exchange between the GPUs of a node (kernels_field.hip exchange_charge)
-constexpr int XCHG_MAX_RANKS = 16;
-struct XchgArgs {
-  double *slots[XCHG_MAX_RANKS];               // every rank's slot area [2][nranks][nx] as mapped here
-  unsigned long long *flags[XCHG_MAX_RANKS];   // every rank's flag area [2][XCHG_MAX_RANKS]
-  unsigned long long *err;                     // host-visible error word (0 = fine)
-  unsigned long long epoch;                    // number of this exchange, from 1
-  long long timeout_ticks;                     // wall_clock64 ticks (100 MHz) a rank waits for its peers
-  int rank, nranks;
-  int local_in_charge;                         // 1: this rank's charge2 is already in FieldArgs::charge
-  int vstride;                                 // doubles per (parity, rank) slot: XCHG_MAX_VEC * nx
-  unsigned long long *ticks;                   // null, or [2] device words: wall-clock ticks (100 MHz) spent inside
-                                               // exchanges so far (stores, the wait for the peers, the sum) and their number
-};
 // vectors of nx doubles one exchange can carry: charge2 + the 1 + 2 * PRED_MAX_MODES prediction slices
 constexpr int XCHG_MAX_VEC = 2 + 2 * PRED_MAX_MODES;
 // both fields of a one-pass step in one launch: the new state's field from its deposited charge, then the
@@ -272,6 +295,7 @@ struct PairArgs {
   int kind;         // 1 tiles, 2 sums
   PredTab pt;       // kind 2
   int plain;        // 1: k_field_solve_pair also where the lean k_field_solve_pair1 applies (PIC1DP_PAIR_PLAIN; tests)
+  int posted;       // kind 2 with x1: the marker launch's tail has stored this rank's vector and flag already (StepTail mode 2)
 };
 // doubles k_charge_pack writes / one exchange of a one-pass step carries per rank:
 // kind 1: charge2 + the 1 + 2 nmode Z-weighted prediction slices; kind 2: charge2 + the six sums (padded to 8)
@@ -331,7 +355,7 @@ hipError_t launch_tile_copy(double *dst, const double *src, int64_t n, hipStream
 // In the same pass: partial[blocks][3] = per-workgroup sums of v^2, v^2 p, v^2 w
 // over all np markers (nullptr: not wanted); blocks = ptcldist_blocks(...)
 hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
-                           int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
+                           int64_t np, const DistGeom &dg, bool deltaf,
                            double *out, double *partial, int num_cu, hipStream_t st);
 int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu);
 // ---- marker optimisation events (kernels_opt.hip; host side of the sequential part: optimize.hpp plan_*) ----

@@ -66,7 +66,16 @@ namespace {
 // within rounding (<= 1e-15 relative per term) of the separate accumulation.
 // LDS = false (grids too large for 160 KiB) adds everything straight to memory.
 // The per-marker part and the finish are shared with the DIAG variant of k_step_full.
-template <bool LDS, bool DELTAF>
+//
+// Round 5 (profiles/r05/sq_counters_diag.json: 0.85 ms at 1e8 markers = 3.8 TB/s for 32 B per marker): the histogram copy
+// leaves room for ONE workgroup of 1024 threads per CU, and with one marker per thread and 8-byte loads those sixteen
+// waves had 32 KB of loads in flight per CU -- by Little's law ~4 TB/s at the latency the memory system has under load;
+// the LDS pipe (twelve FP64 atomics at random bins per marker) was ~70 % busy BEHIND that, not the first limit.  Hence:
+// marker PAIRS per thread (16-byte loads, the marker kernels' access shape), the NEXT trip's loads issued before this
+// trip's atomics (twice the bytes in flight again), non-temporal loads once the state outgrows the Infinity Cache, the
+// two divisions by constants without the hardware's division sequence (bit for bit the same quotients), and the three
+// planes interleaved so that a corner's three atomics share one address computation (device_diag.hpp).
+template <bool LDS, bool DELTAF, bool NT>
 __global__ void __launch_bounds__(1024)
 k_ptcldist(const double *x, const double *v, const double *p, const double *w, int64_t np, const DistGeom dg,
            double *out, double *partial) {
@@ -78,10 +87,33 @@ k_ptcldist(const double *x, const double *v, const double *p, const double *w, i
     for (int i = threadIdx.x; i < ntot; i += blockDim.x) b.h[i] = 0.0;
     __syncthreads();
   }
+  const int64_t npair = np >> 1;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const double2 *x2 = reinterpret_cast<const double2 *>(x), *v2 = reinterpret_cast<const double2 *>(v);
+  const double2 *p2 = reinterpret_cast<const double2 *>(p), *w2 = reinterpret_cast<const double2 *>(w);
   DistSums sm;
-  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < np; k += stride) {
-    const int64_t i = tidx(k);
+  int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  double2 X = make_double2(0.0, 0.0), V = X, P = X, W = X;
+  if (j < npair) {
+    const int64_t o = tidx2(j);
+    X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
+    if constexpr (DELTAF) W = ld2t<NT>(w2 + o);
+  }
+  while (j < npair) {
+    const int64_t jn = j + stride;
+    double2 Xn = make_double2(0.0, 0.0), Vn = Xn, Pn = Xn, Wn = Xn;
+    if (jn < npair) {  // the next trip's loads are under way while this trip's atomics run
+      const int64_t o = tidx2(jn);
+      Xn = ld2t<NT>(x2 + o), Vn = ld2t<NT>(v2 + o), Pn = ld2t<NT>(p2 + o);
+      if constexpr (DELTAF) Wn = ld2t<NT>(w2 + o);
+    }
+    ptcldist_one<LDS, DELTAF>(X.x, V.x, P.x, W.x, dg, b, sm);
+    ptcldist_one<LDS, DELTAF>(X.y, V.y, P.y, W.y, dg, b, sm);
+    X = Xn, V = Vn, P = Pn, W = Wn;
+    j = jn;
+  }
+  if ((np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = tidx(np - 1);
     ptcldist_one<LDS, DELTAF>(x[i], v[i], p[i], DELTAF ? w[i] : 0.0, dg, b, sm);
   }
   ptcldist_finish<LDS, DELTAF>(dg, b, sm, scr, out, partial);
@@ -93,21 +125,24 @@ int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu) {
   const size_t bytes = sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo));
   const bool lds = bytes <= 150 * 1024;
   int64_t blocks = lds ? num_cu : static_cast<int64_t>(num_cu) * 2;
-  const int64_t need = (np + 1023) / 1024;
+  const int64_t need = ((np >> 1) + 1023) / 1024;
   if (blocks > need) blocks = need;
   if (blocks < 1) blocks = 1;
   return static_cast<int>(blocks);
 }
 
 hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
-                           int64_t np, double lx, double vmax, int nxo, int nvo, bool deltaf,
+                           int64_t np, const DistGeom &dg, bool deltaf,
                            double *out, double *partial, int num_cu, hipStream_t st) {
+  const int nxo = dg.nxo, nvo = dg.nvo;
   const size_t hist = sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo));
   const bool lds = hist <= 150 * 1024;
   const size_t bytes = (lds ? hist : 0) + 16 * sizeof(double);  // + block_sum scratch
   const int threads = 1024;
   const int blocks = ptcldist_blocks(np, nxo, nvo, num_cu);
-  const DistGeom dg{lx, vmax, nxo, nvo};
+  // x, v, p, w against the 256 MiB Infinity Cache: beyond it the pass streams (PIC1DP_DIAG_NT=0 / 1 insists)
+  bool nt = 32.0 * static_cast<double>(np) > 288.0 * 1048576.0;
+  if (const char *e = std::getenv("PIC1DP_DIAG_NT")) nt = std::atoi(e) != 0;
   auto go = [&](auto kern) -> hipError_t {
     if (lds && bytes > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -118,8 +153,12 @@ hipError_t launch_ptcldist(const double *x, const double *v, const double *p, co
                        partial);
     return hipGetLastError();
   };
-  if (lds) return deltaf ? go(k_ptcldist<true, true>) : go(k_ptcldist<true, false>);
-  return deltaf ? go(k_ptcldist<false, true>) : go(k_ptcldist<false, false>);
+  if (lds) {
+    if (nt) return deltaf ? go(k_ptcldist<true, true, true>) : go(k_ptcldist<true, false, true>);
+    return deltaf ? go(k_ptcldist<true, true, false>) : go(k_ptcldist<true, false, false>);
+  }
+  if (nt) return deltaf ? go(k_ptcldist<false, true, true>) : go(k_ptcldist<false, false, true>);
+  return deltaf ? go(k_ptcldist<false, true, false>) : go(k_ptcldist<false, false, false>);
 }
 
 hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t i0, int64_t n,

@@ -3,6 +3,7 @@
 // one-pass step, the one-hop charge exchange, the opt-in finite-difference solver.  gfx950, wave64.
 #include "device_field.hpp"
 #include "device_math.hpp"
+#include "device_xchg.hpp"
 
 namespace pic1dp {
 
@@ -451,50 +452,16 @@ __global__ void __launch_bounds__(FIELD_THREADS) k_field_solve_pred_sums(const F
 // Two parities suffice: a rank can start exchange e+2 (same parity as e) only after
 // every peer has flagged e+1, which a peer does after it has finished reading e.
 // ---------------------------------------------------------------------------
-#define PIC1DP_SYS __HIP_MEMORY_SCOPE_SYSTEM
+// (the two halves, exchange_post and exchange_wait_sum: device_xchg.hpp -- a one-pass marker launch's tail can run the
+// first one itself, kernels.hpp StepTail)
 
 // n values per rank (n <= x.vstride), this rank's in sV -- every thread has filled the elements
-// threadIdx.x + k * blockDim.x and only ever touches those -- summed over ranks in rank order, in place
-__device__ __forceinline__ void exchange_vectors(const XchgArgs &x, double *sV, int n) {
-  const int nr = x.nranks, par = static_cast<int>(x.epoch & 1);
+// threadIdx.x + k * blockDim.x and only ever touches those -- summed over ranks in rank order, in place.
+// posted: the marker launch's tail has stored this rank's values and flag already; only the wait and the sum are left
+__device__ __forceinline__ void exchange_vectors(const XchgArgs &x, double *sV, int n, bool posted = false) {
   const long long t_in = x.ticks ? wall_clock64() : 0;
-  for (int k = 0; k < nr; ++k) {
-    int q = x.rank + k;  // start with the own area, then the peers in ring order
-    if (q >= nr) q -= nr;
-    double *dst = x.slots[q] + (static_cast<size_t>(par) * nr + x.rank) * x.vstride;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(dst + i, sV[i], __ATOMIC_RELAXED, PIC1DP_SYS);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: this wave's stores have landed
-  __syncthreads();
-  if (threadIdx.x < nr) {
-    const int q = threadIdx.x;
-    __hip_atomic_store(x.flags[q] + par * XCHG_MAX_RANKS + x.rank, x.epoch, __ATOMIC_RELEASE, PIC1DP_SYS);
-    const unsigned long long *fl = x.flags[x.rank] + par * XCHG_MAX_RANKS + q;
-    const long long t0 = wall_clock64();
-    // a run that already timed out once does not wait again: its remaining launches drain at once
-    const long long limit = __hip_atomic_load(x.err, __ATOMIC_RELAXED, PIC1DP_SYS) ? 0 : x.timeout_ticks;
-    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, PIC1DP_SYS) < x.epoch) {
-      __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > limit) {  // give up: report, never hang
-        __hip_atomic_store(x.err, (x.epoch << 8) | static_cast<unsigned long long>(q + 1), __ATOMIC_RELAXED, PIC1DP_SYS);
-        break;
-      }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  __syncthreads();
-  const double *mine = x.slots[x.rank] + static_cast<size_t>(par) * nr * x.vstride;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    double t[XCHG_MAX_RANKS];
-#pragma unroll
-    for (int q = 0; q < XCHG_MAX_RANKS; ++q)
-      t[q] = q < nr ? __hip_atomic_load(mine + static_cast<size_t>(q) * x.vstride + i, __ATOMIC_RELAXED, PIC1DP_SYS) : 0.0;
-    double sum = t[0];
-#pragma unroll
-    for (int q = 1; q < XCHG_MAX_RANKS; ++q)
-      if (q < nr) sum = sum + t[q];
-    sV[i] = sum;
-  }
+  if (!posted) exchange_post(x, sV, n);
+  exchange_wait_sum(x, sV, n);
   if (x.ticks && threadIdx.x == 0) {  // what of this launch was the exchange (the bench's attribution splits it from the solve)
     x.ticks[0] += static_cast<unsigned long long>(wall_clock64() - t_in);
     x.ticks[1] += 1;
@@ -822,12 +789,14 @@ k_field_solve_pair_sums(const FieldArgs f, const XchgArgs x1, const PairArgs pa)
   double *sV = sTab + (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * nx : 0);  // SRC 1: [charge2 | six sums | pad]
   __shared__ double sK[8];
   if constexpr (SRC == 1) {
-    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sV[ix] = charge_local_one(f, ix);
-    if (threadIdx.x < 8) {
-      sV[nx + threadIdx.x] = pred_sum_take(pa.pred, threadIdx.x);
+    if (!pa.posted) {
+      for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sV[ix] = charge_local_one(f, ix);
+      if (threadIdx.x < 8) {
+        sV[nx + threadIdx.x] = pred_sum_take(pa.pred, threadIdx.x);
+      }
+      __syncthreads();  // element i of the packed vector belongs to thread i % blockDim in the exchange
     }
-    __syncthreads();  // element i of the packed vector belongs to thread i % blockDim in the exchange
-    exchange_vectors(x1, sV, nx + 8);
+    exchange_vectors(x1, sV, nx + 8, pa.posted != 0);
     __syncthreads();
     if (threadIdx.x < 8) sK[threadIdx.x] = sV[nx + threadIdx.x];
     for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
@@ -890,10 +859,12 @@ k_field_solve_pair_sums1(const FieldArgs f, const XchgArgs x1, const PairArgs pa
   double *sV = sPart + ((2 * f.npe + 1) & ~1);      // SRC 1: [charge2 | six sums | pad]
   const double *pk = pa.pack;
   if constexpr (SRC == 1) {
-    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sV[ix] = charge_local_one(f, ix);
-    if (threadIdx.x < 8) sV[nx + threadIdx.x] = pred_sum_take(pa.pred, threadIdx.x);
-    __syncthreads();
-    exchange_vectors(x1, sV, nx + 8);
+    if (!pa.posted) {  // (posted: the marker launch's tail has formed and stored this rank's vector, StepTail mode 2)
+      for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sV[ix] = charge_local_one(f, ix);
+      if (threadIdx.x < 8) sV[nx + threadIdx.x] = pred_sum_take(pa.pred, threadIdx.x);
+      __syncthreads();
+    }
+    exchange_vectors(x1, sV, nx + 8, pa.posted != 0);
     __syncthreads();
     pk = sV;
   }
@@ -1176,7 +1147,14 @@ __global__ void __launch_bounds__(64) k_chain_selftest(const double *v, int nrow
     if (static_cast<int>(threadIdx.x) == chain_mfma_lane(r)) out[16 + r] = d;
 }
 hipError_t launch_chain_selftest(const double *v, int nrows, int n, double *out, hipStream_t st) {
-  hipLaunchKernelGGL(k_chain_selftest, dim3(1), dim3(64), sizeof(double) * nrows * ((n + 1) & ~1), st, v, nrows, n, out);
+  const size_t lds = sizeof(double) * nrows * ((n + 1) & ~1);
+  if (lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS, as launch_step_kernel does
+    if (lds > 160 * 1024 - 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chain_selftest),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_chain_selftest, dim3(1), dim3(64), lds, st, v, nrows, n, out);
   return hipGetLastError();
 }
 

@@ -310,7 +310,10 @@ int opt_blocks(int64_t n) {
 }  // namespace
 
 hipError_t opt_hist_block(const OptBlock &b, const OptGrid &g, int64_t np, double *hist, hipStream_t st) {
-  if (np <= 0) return hipMemsetAsync(hist, 0, sizeof(double) * g.nv, st);
+  if (np <= 0) {  // an empty block: zeros, and -- as every other path of this function -- the stream waited for
+    hipError_t e0 = hipMemsetAsync(hist, 0, sizeof(double) * g.nv, st);
+    return e0 != hipSuccess ? e0 : hipStreamSynchronize(st);
+  }
   const size_t n = 2 * static_cast<size_t>(np);
   uint32_t *keys = nullptr;
   double *vals = nullptr;

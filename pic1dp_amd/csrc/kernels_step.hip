@@ -13,6 +13,7 @@
 #include "device_diag.hpp"
 #include "device_field.hpp"
 #include "device_math.hpp"
+#include "device_xchg.hpp"
 #include "step_args.hpp"
 
 #include <cstdio>
@@ -378,7 +379,7 @@ __device__ __forceinline__ void fused_solve(const FusedSolve &fs, const TAB &tab
   }
   if (lead) {  // the accumulators the previous launch read: nobody looks at them any more
     for (int64_t i = threadIdx.x; i < fs.zero_rho_n; i += blockDim.x) fs.zero_rho[i] = 0.0;
-    if (threadIdx.x < 8 * PRED_SUM_COPIES) fs.zero_pred[threadIdx.x] = 0.0;
+    for (int i = threadIdx.x; i < 8 * PRED_SUM_COPIES; i += blockDim.x) fs.zero_pred[i] = 0.0;
   }
   __syncthreads();
   const double ginv = f.grad_inv[0];
@@ -642,6 +643,8 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
       if (lane == 0) glb_add(a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8 + wave, t);
     }
     STAMP(a, 5);
+    if constexpr (!FUSED)  // several ranks: the last workgroup to finish packs / posts this rank's charge (StepTail)
+      if (a.tail.mode) step_tail(a.tail, reinterpret_cast<double *>(smem));
     return;
   }
   // the guard cells nx, nx + 1 are cells 0, 1 (mod nx); then one global atomic per cell and slice
@@ -825,6 +828,8 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   const double mine[6] = {ks.k0c, ks.k1c, ks.k2c, ks.k0s, ks.k1s, ks.k2s};
   block_sum6_add(mine, sScr, a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8);
   STAMP(a, 5);
+  if constexpr (!FUSED)  // several ranks: the last workgroup to finish packs / posts this rank's charge (StepTail)
+    if (a.tail.mode) step_tail(a.tail, reinterpret_cast<double *>(smem));
 }
 
 #ifdef PIC1DP_TUNE_STAMPS

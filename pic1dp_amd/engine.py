@@ -173,7 +173,8 @@ class Pic1dp:
         return k.value
 
     def set_output_fusion(self, on=True):
-        """diagnostics of output_all taken inside the step that precedes it (no extra pass)"""
+        """diagnostics of output_all taken inside the step that precedes it: False / 0 never, True / 1 where it pays
+        (not on a predicted one-pass step, whose prediction k_step_full<DIAG> would cost), 2 always"""
         check(self.L.pic1dp_hip_set_output_fusion(self._ctx, int(on)))
 
     def set_field_solver(self, kind):
@@ -212,6 +213,12 @@ class Pic1dp:
         f = C.c_int32()
         check(self.L.pic1dp_hip_output_due(self._ctx, itermination, C.byref(f)))
         return f.value
+
+    def steps_to_output(self):
+        """iterations of the driver loop (src/pic1dp.F90:78-109) up to and including the one output_all follows"""
+        n = C.c_int32()
+        check(self.L.pic1dp_hip_steps_to_output(self._ctx, C.byref(n)))
+        return n.value
 
     # -- field access -------------------------------------------------------------
     def get_field(self, chargeden=True):

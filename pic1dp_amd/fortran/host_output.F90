@@ -9,8 +9,20 @@ implicit none
 
 integer, parameter :: output_unit_out = 71
 integer(c_int32_t), parameter :: vec_file_classid = 1211214
+! PIC1DP_HOST_PROFILE=1: wall clock of output_all split into the library's part (diagnostics on the GPU, their
+! way to the host) and the file writes; the counterpart of the reference's global_iwt_output timer
+logical :: output_profile = .false.
+real(c_double) :: output_lib_s = 0.0_c_double, output_write_s = 0.0_c_double
+integer :: output_records = 0
 
 contains
+
+function output_wall() result(t)
+  real(c_double) :: t
+  integer(c_int64_t) :: cnt, rate
+  call system_clock(cnt, rate)
+  t = real(cnt, c_double) / real(rate, c_double)
+end function output_wall
 
 subroutine output_init(inp)
   type(pic1dp_input_t), intent(in) :: inp
@@ -39,7 +51,9 @@ subroutine output_all(ctx, inp, verbosity)
   real(c_double) :: time, progress(2)
   character :: cprogress
   integer :: nxv
+  real(c_double) :: t0, t1
 
+  t0 = output_wall()
   nxv = inp%nx_opd * inp%nv_opd
   allocate (mxv(nxv), txv(nxv), pxv(nxv), mv(inp%nv_opd), tv(inp%nv_opd), pv(inp%nv_opd))
   if (ranks_size == 1) then
@@ -54,12 +68,16 @@ subroutine output_all(ctx, inp, verbosity)
       int(size(scal), c_int32_t)), 'output_scalars_from')
   end if
   if (ranks_rank == 0) then
-    write (output_unit_out) scal
     call pic1dp_hip_check(pic1dp_hip_get_field(ctx, e, cd, re, im), 'get_field')
+    t1 = output_wall()
+    output_lib_s = output_lib_s + (t1 - t0)
+    write (output_unit_out) scal
     call output_vec(re)
     call output_vec(im)
     call output_vec(e)
     call output_vec(cd)
+    t0 = output_wall()
+    output_write_s = output_write_s + (t0 - t1)
   end if
   do s = 0, inp%nspecies - 1
     if (ranks_size == 1) then
@@ -77,13 +95,18 @@ subroutine output_all(ctx, inp, verbosity)
         'ptcldist_finish')
     end if
     if (ranks_rank /= 0) cycle
+    t1 = output_wall()
+    output_lib_s = output_lib_s + (t1 - t0)
     write (output_unit_out) mxv
     write (output_unit_out) txv
     write (output_unit_out) pxv
     write (output_unit_out) mv
     write (output_unit_out) tv
     write (output_unit_out) pv
+    t0 = output_wall()
+    output_write_s = output_write_s + (t0 - t1)
   end do
+  output_records = output_records + 1
   if (verbosity == 1) then
     call pic1dp_hip_check(pic1dp_hip_get_time(ctx, itime, time), 'get_time')
     progress(1) = 1e2_c_double * real(itime, c_double) / inp%ntime_max
@@ -135,7 +158,10 @@ subroutine output_progress_optimized(ctx, inp, verbosity)
 end subroutine output_progress_optimized
 
 subroutine output_final
+  real(c_double) :: t0
+  t0 = output_wall()
   close (output_unit_out)
+  output_write_s = output_write_s + (output_wall() - t0)
 end subroutine output_final
 
 end module pic1dp_host_output

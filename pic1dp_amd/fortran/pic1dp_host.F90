@@ -19,7 +19,11 @@
 ! replaced by the fused pic1dp_hip_substep(ctx, global_irk); with PIC1DP_FUSED=2
 ! the whole irk loop is one pic1dp_hip_step(ctx, 1) (fastest: the half-step
 ! state is recomputed instead of stored; the library then advances
-! global_itime / global_time itself, exactly as src/pic1dp.F90:92-93).
+! global_itime / global_time itself, exactly as src/pic1dp.F90:92-93); with
+! PIC1DP_FUSED=3 all the steps up to the next output_all are ONE call,
+! pic1dp_hip_step(ctx, pic1dp_hip_steps_to_output): one launch per time step.
+! PIC1DP_HOST_PROFILE=1 prints the wall clock of the run split into the time loop's steps, output_all's
+! diagnostics and the writes of pic1dp.out (the steps are then waited for, pic1dp_hip_sync, before the clock is read).
 program pic1dp_host
 use iso_c_binding
 use pic1dp_hip
@@ -31,11 +35,12 @@ implicit none
 type(pic1dp_input_t) :: inp
 type(pic1dp_layout_t) :: lay
 type(c_ptr) :: ctx
-integer(c_int32_t) :: global_irk, global_itime, itermination, due, flag_optimized
+integer(c_int32_t) :: global_irk, global_itime, itermination, due, flag_optimized, nbatch
 real(c_double) :: global_time, ms_push, ms_charge, ms_field
+real(c_double) :: t_run0, t_loop0, t_a, steps_s, load_s
 character(len=8) :: buf
 integer :: stat, verbosity
-logical :: fused, whole_step
+logical :: fused, whole_step, batched
 integer(c_signed_char) :: handle(PIC1DP_XCHG_HANDLE_BYTES)
 integer(c_signed_char), allocatable :: handles(:)
 
@@ -57,9 +62,16 @@ if (ranks_rank /= 0) verbosity = 0          ! PetscPrintf prints on rank 0 only 
 if (ranks_rank == 0) call output_init(inp)
 call get_environment_variable('PIC1DP_FUSED', buf, status=stat)
 fused = (stat == 0 .and. buf(1:1) == '1')
-whole_step = (stat == 0 .and. buf(1:1) == '2')
+whole_step = (stat == 0 .and. (buf(1:1) == '2' .or. buf(1:1) == '3'))
+batched = (stat == 0 .and. buf(1:1) == '3')
+call get_environment_variable('PIC1DP_HOST_PROFILE', buf, status=stat)
+output_profile = (stat == 0 .and. buf(1:1) == '1')
+steps_s = 0.0_c_double
 
+t_run0 = output_wall()
 call pic1dp_hip_check(pic1dp_hip_particle_load(ctx), 'particle_load')
+if (output_profile) call pic1dp_hip_check(pic1dp_hip_sync(ctx), 'sync')
+load_s = output_wall() - t_run0
 call pic1dp_hip_check(pic1dp_hip_timers_enable(ctx, 1), 'timers_enable')
 ! output_all is called at the reference's cadence below: steps it follows take its diagnostics along
 call pic1dp_hip_check(pic1dp_hip_set_output_fusion(ctx, 1), 'set_output_fusion')
@@ -75,9 +87,13 @@ if (verbosity == 1) write (*, '(a/a)') 'Info: progress:', 'progrss  itime     ti
 call output_all(ctx, inp, verbosity)
 
 call pic1dp_hip_check(pic1dp_hip_check_termination(ctx, itermination), 'check_termination')
+t_loop0 = output_wall()
 do while (itermination == 0)                 ! main time evolution loop
+  t_a = output_wall()
   if (whole_step) then
-    call pic1dp_hip_check(pic1dp_hip_step(ctx, 1), 'step')
+    nbatch = 1
+    if (batched) call pic1dp_hip_check(pic1dp_hip_steps_to_output(ctx, nbatch), 'steps_to_output')
+    call pic1dp_hip_check(pic1dp_hip_step(ctx, nbatch), 'step')
     call pic1dp_hip_check(pic1dp_hip_get_time(ctx, global_itime, global_time), 'get_time')
   else
     do global_irk = 1, 2
@@ -95,12 +111,24 @@ do while (itermination == 0)                 ! main time evolution loop
     global_time = global_time + inp%dt
     call pic1dp_hip_check(pic1dp_hip_set_time(ctx, global_itime, global_time), 'set_time')
   end if
+  if (output_profile) then
+    call pic1dp_hip_check(pic1dp_hip_sync(ctx), 'sync')
+    steps_s = steps_s + (output_wall() - t_a)
+  end if
   call pic1dp_hip_check(pic1dp_hip_check_termination(ctx, itermination), 'check_termination')
   call pic1dp_hip_check(pic1dp_hip_output_due(ctx, itermination, due), 'output_due')
   if (due == 1) call output_all(ctx, inp, verbosity)
 end do
 
 if (ranks_rank == 0) call output_final
+if (output_profile .and. ranks_rank == 0) then
+  t_a = output_wall()
+  write (*, '(a)') 'Info: host wall clock (s):'
+  write (*, '(a, f10.3, a, f10.3, a, i8, a)') '   particle load', load_s, '   time loop', t_a - t_loop0, &
+    '   (', global_itime, ' steps)'
+  write (*, '(a, f10.3, a, f10.3, a, f10.3, a, i6, a)') '   steps', steps_s, '   output_all: library', output_lib_s, &
+    '   file writes', output_write_s, '   (', output_records, ' records)'
+end if
 if (verbosity >= 1) then
   call pic1dp_hip_check(pic1dp_hip_timer_ms(ctx, PIC1DP_IWT_PUSH_PARTICLE, ms_push), 'timer')
   call pic1dp_hip_check(pic1dp_hip_timer_ms(ctx, PIC1DP_IWT_COLLECT_CHARGE, ms_charge), 'timer')

@@ -51,6 +51,9 @@ def test_exchange_ranks_share_the_gpu(amd, tmp_path, monkeypatch, nproc, mode, k
     # call sites: the initial deposit and one exchange per collect_charge
     expect = 2 + steps if mode == "step" else 1 + 2 * steps
     assert all(int(r["exchanges"]) == expect for r in ranks)
+    # six sums, step(): this rank's half of the exchange -- charge2 and the sums formed, stored into every rank's slots,
+    # flagged -- rides in the tail of the marker launch (kernels.hpp StepTail); the field launch only waits and adds
+    assert all(int(r["tails"]) == (steps if (mode == "step" and kind == 2) else 0) for r in ranks)
     # the exchange areas are fine-grained device memory (coherent across agents inside a kernel),
     # not one of the fall-backs
     assert all(int(r["memkind"]) == 1 for r in ranks)
@@ -81,3 +84,30 @@ def test_exchange_gives_up_on_a_missing_rank(amd, tmp_path):
     e0, e1 = str(ranks[0]["err"]), str(ranks[1]["err"])
     assert e0.startswith("5|") and "rank 1" in e0, e0        # PIC1DP_ERR_COMM on the rank that waited
     assert e1 == ""                                          # the rank that stopped early saw nothing wrong
+
+
+def test_exchange_posted_from_the_marker_launch_equals_the_field_launchs_own(amd, tmp_path, monkeypatch):
+    """with PIC1DP_TAIL=0 the field launch forms, stores and flags this rank's vector itself (as
+    before round 5); with the tail the last workgroup of the marker launch has done so.  Same accumulators, same
+    additions in the same order: with one wave of markers per rank the two runs agree bit for bit; at a marker count
+    whose charge atomics arrive in varying order, to 1e-11.  Three ranks share the box's GPU."""
+    monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
+    steps = 10
+    for n, tol in ((3 * 96, 0.0), (450_000, 1e-11)):
+        kw = dict(nparticle_max=n, nx=64)
+        da, db = tmp_path / ("tail_%d" % n), tmp_path / ("plain_%d" % n)
+        da.mkdir()
+        db.mkdir()
+        monkeypatch.setenv("PIC1DP_TAIL", "1")
+        a = run_ranks(da, 3, kw, steps, "step", 29601 + (n > 1000))
+        monkeypatch.setenv("PIC1DP_TAIL", "0")
+        b = run_ranks(db, 3, kw, steps, "step", 29611 + (n > 1000))
+        assert all(int(r["tails"]) == steps for r in a) and all(int(r["tails"]) == 0 for r in b)
+        for ra, rb in zip(a, b):
+            assert np.array_equal(ra["E"], a[0]["E"]) and np.array_equal(rb["E"], b[0]["E"])
+            if tol == 0.0:
+                for k in ("E", "cd", "hist", "x"):
+                    assert np.array_equal(ra[k], rb[k]), k
+            else:
+                assert np.max(np.abs(ra["hist"] / rb["hist"] - 1.0)) < tol
+                assert np.max(np.abs(ra["x"] - rb["x"])) < 1e-10

@@ -478,6 +478,68 @@ def test_fused_solve_bit_identical_to_the_field_kernel(amd, monkeypatch, name, k
     assert np.array_equal(a.get_field()["chargeden"], b.get_field()["chargeden"])
 
 
+@pytest.mark.parametrize("threads,bpc,osub", [(64, 0, None), (128, 0, None), (256, 0, None), (1024, 0, None), (512, 2, None),
+                                              (0, 0, "1"), (0, 0, "3")],
+                         ids=["t64", "t128", "t256", "t1024", "t512x2", "osub1", "osub3"])
+def test_fused_solve_over_launch_shapes(amd, monkeypatch, threads, bpc, osub):
+    """pic1dp_hip_set_launch / PIC1DP_OSUB together with the solve in the marker launch's prologue.  A
+    launch shape asked for by hand selects the register-sum kernel (k_step_sums<FUSED>) with that workgroup size; the
+    prologue zeroes the rotated accumulator sets with strided stores whatever the size, and a workgroup of one wave --
+    which has no first AND last wave for the prologue's two jobs -- must not fuse at all.  One wave of markers per
+    block: one order of the charge sums, so fused and unfused agree bit for bit over enough steps for every
+    accumulator set to have been read, deposited into and zeroed several times."""
+    kw = dict(nparticle_max=96, nx=32)
+    if osub:
+        monkeypatch.setenv("PIC1DP_OSUB", osub)
+    monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "2")
+    a = engine(amd, monkeypatch, True, 2, **kw)
+    monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "0")
+    b = engine(amd, monkeypatch, True, 2, **kw)
+    for e in (a, b):
+        if threads or bpc:
+            e.set_launch(threads, bpc)
+    nsteps = 40
+    a.step(nsteps)
+    b.step(nsteps)
+    fused = a.kernel_stats(7)[1]
+    if threads == 64:
+        assert fused == 0                      # a one-wave workgroup never carries the solve
+    else:
+        assert fused == nsteps - 1
+    assert b.kernel_stats(7)[1] == 0
+    assert np.array_equal(a.energy_history(), b.energy_history())
+    fa, fb = a.get_field(), b.get_field()
+    for k in ("electric", "chargeden", "mode_re", "mode_im"):
+        assert np.array_equal(fa[k], fb[k]), k
+    assert np.array_equal(a.get_field_half(), b.get_field_half())
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.array_equal(ga[k], gb[k]), k
+    a.interaction_collect_charge()                # nothing stale in any accumulator set
+    b.interaction_collect_charge()
+    assert np.array_equal(a.get_field()["chargeden"], b.get_field()["chargeden"])
+
+
+def test_fused_solve_many_markers_small_workgroups(oracle_mod, amd, monkeypatch):
+    """the 64-thread case of ADVICE r04 at a marker count where every copy of the six sums is deposited into
+    (more workgroups than copies): the run against the oracle, 1e-10 at every step"""
+    kw = dict(nparticle_max=N, nx=96)
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    eo = []
+    for _ in range(40):
+        sim.step(1)
+        eo.append(sim.field_energy())
+    for threads in (64, 128):
+        monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "2")
+        a = engine(amd, monkeypatch, True, 2, **kw)
+        a.set_launch(threads, 0)
+        a.step(40)
+        assert np.max(np.abs(a.energy_history() / np.array(eo) - 1.0)) < 1e-10, threads
+
+
 @pytest.mark.parametrize("nx,env", [(1024, {}), (96, {}), (2500, {}), (1024, {"PIC1DP_PRED_PRIVATE": "0"})],
                          ids=["nx1024_private_slots", "nx96_private_slots", "nx2500_register_sums", "nx1024_register_sums"])
 def test_fused_solve_many_markers(oracle_mod, amd, monkeypatch, nx, env):

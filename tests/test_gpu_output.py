@@ -285,7 +285,7 @@ def test_fortran_host_as_one_of_n_ranks(oracle_mod, amd, tmp_path, nranks, fused
     (dict(nparticle_max=150_001, species_nparticle_init=[140_000]), "step")],
     ids=["default_step", "default_call_sites", "linear", "full_f", "general_constants_carry", "odd_with_tail_slots"])
 def test_output_diagnostics_inside_the_step(amd, kw, mode):
-    """with output fusion on, the step that precedes output_all takes the histograms of
+    """with output fusion insisted on (2), the step that precedes output_all takes the histograms of
     output_ptcldist and the kinetic sums of output_field inside k_step_full (DIAG variant):
     no separate pass over the markers, same numbers as the separate pass
     (src/pic1dp_output.F90:126-151, :239-315) up to the order of the atomics"""
@@ -294,7 +294,7 @@ def test_output_diagnostics_inside_the_step(amd, kw, mode):
     engs = []
     for fuse in (True, False):
         e = amd.Pic1dp(amd.make_input(**base))
-        e.set_output_fusion(fuse)
+        e.set_output_fusion(2 if fuse else 0)
         e.particle_load()
         e.interaction_collect_charge()
         e.field_solve_electric()
@@ -335,3 +335,46 @@ def test_output_diagnostics_inside_the_step(amd, kw, mode):
     ga, gb = fused.particles_download(), plain.particles_download()
     for k in "xvw":
         assert np.max(np.abs(ga[k] - gb[k])) < 1e-10 * max(1.0, np.max(np.abs(gb[k]))), k
+
+
+@pytest.mark.parametrize("mode", ["step", "calls"])
+def test_output_steps_keep_the_prediction(oracle_mod, amd, mode):
+    """with output fusion 'where it pays' (1: what the Fortran host and Pic1dp.run ask for) a
+    predicted one-pass step that output_all follows stays k_step_one -- the diagnostics take a pass of their own, which
+    changes no marker, so the prediction survives and the step after the output is one pass again: ONE first-sub-step
+    pass in the whole run (the first step's), one diagnostics pass per record, and the records against the oracle
+    (src/pic1dp_output.F90:126-151, 239-315)"""
+    kw = dict(nparticle_max=300_000, nx=128, output_interval=0.5)
+    eng = amd.Pic1dp(amd.make_input(**kw))
+    eng.set_output_fusion(1)
+    eng.kernel_stats_enable(True)
+    eng.particle_load()
+    eng.interaction_collect_charge()
+    eng.field_solve_electric()
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    nout = 0
+    for chunk in (10, 10, 10, 10):
+        if mode == "step":
+            eng.step(chunk)
+        else:
+            for _ in range(chunk):
+                for irk in (1, 2):
+                    eng.interaction_push_particle(irk)
+                    eng.interaction_collect_charge()
+                    eng.field_solve_electric()
+                eng.set_time(eng.itime + 1, eng.time + eng.inp.dt)
+        sim.step(chunk)
+        assert eng.output_due()
+        nout += 1
+        a, b = eng.output_scalars(), np.array(sim.output_scalars())
+        assert abs(a[1] / b[1] - 1.0) < 1e-10                       # int E^2 dx
+        assert np.max(np.abs(a[2:4] / b[2:4] - 1.0)) < 1e-9         # sum v^2, total kinetic energy
+        pa, pb = eng.ptcldist(), sim.ptcldist()
+        for k in ("markr_xv", "total_xv", "markr_v", "total_v"):
+            assert relerr(np.asarray(pa[k]).ravel(), np.asarray(pb[k]).ravel()) < 1e-9, k
+    assert eng.kernel_stats(5)[1] == nout            # one diagnostics pass per record
+    assert eng.kernel_stats(3)[1] == 1               # k_step_half: the first step of the run only
+    assert eng.kernel_stats(6)[1] == 40 and eng.kernel_stats(4)[1] == 0    # every step k_step_one, no k_step_full

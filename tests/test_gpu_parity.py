@@ -751,6 +751,52 @@ def test_rccl_allreduce_path_single_rank(oracle_mod, amd, monkeypatch, kind, nx)
     assert abs(eng.field_energy() / sim.field_energy() - 1.0) < ENERGY_RTOL
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(nspecies=2, species_charge=[-1.0, 1.0], species_mass=[1.0, 4.0],
+                                             species_temperature=[1.0, 1.0], species_temperature2=[1.0, 1.0],
+                                             species_density=[0.9, 0.9], species_v0=[5.0, 5.0])],
+                         ids=["one_species", "two_species"])
+def test_rccl_pack_in_the_marker_launch_equals_the_pack_launch(amd, monkeypatch, kw):
+    """on the RCCL path the packing of this rank's charge2 and six sums for the ONE all-reduce of
+    a one-pass step (src/pic1dp_interaction.F90:126-135) is done by the last workgroup of the marker launch to finish
+    (kernels.hpp StepTail) instead of a launch of its own (PIC1DP_TAIL=0).  Same accumulators, the same additions in
+    the same order: bit for bit with one wave of markers per block, 1e-11 where the charge atomics' order varies; with
+    two species the tail rides in the second species' launch."""
+    monkeypatch.setenv("PIC1DP_PRED_KIND", "2")
+    ns = kw.get("nspecies", 1)
+    for n, exact in ((96, True), (300_001, False)):
+        engs = []
+        for tail in ("1", "0"):
+            monkeypatch.setenv("PIC1DP_TAIL", tail)
+            e = amd.Pic1dp(amd.make_input(nparticle_max=n, nx=64, species_nparticle_init=[n] * ns, **kw))
+            e.particle_load()
+            e.comm_init(e.comm_unique_id())
+            e.interaction_collect_charge()
+            e.field_solve_electric()
+            e.step(30)
+            engs.append(e)
+        a, b = engs
+        assert a.kernel_stats(10)[1] == 30 and b.kernel_stats(10)[1] == 0
+        fa, fb = a.get_field(), b.get_field()
+        if exact:
+            assert np.array_equal(a.energy_history(), b.energy_history())
+            for k in ("electric", "chargeden", "mode_re", "mode_im"):
+                assert np.array_equal(fa[k], fb[k]), k
+            for isp in range(ns):
+                ga, gb = a.particles_download(isp), b.particles_download(isp)
+                for k in "xvw":
+                    assert np.array_equal(ga[k], gb[k]), (isp, k)
+        else:
+            assert np.max(np.abs(a.energy_history() / b.energy_history() - 1.0)) < 1e-11
+            assert relerr(fa["electric"], fb["electric"]) < 1e-11
+        # nothing stale in the accumulators or the ticket: the call sites and a further step() go on from here
+        for e in engs:
+            e.interaction_collect_charge()
+        assert relerr(a.get_field()["chargeden"], b.get_field()["chargeden"]) < (1e-15 if exact else 1e-11)
+        for e in engs:
+            e.step(3)
+        assert np.max(np.abs(a.energy_history()[-3:] / b.energy_history()[-3:] - 1.0)) < 1e-11
+
+
 def test_error_behaviour(amd):
     inp = amd.make_input(nparticle_max=1000, nx=16)
     eng = amd.Pic1dp(inp)

@@ -56,7 +56,7 @@ def main():
     memkind, nx = eng.xchg_info()
     np.savez(out + ".rank%d.npz" % rank, e0=e0, hist=eng.energy_history(), E=f["electric"], cd=f["chargeden"],
              fields=np.array(fields), energy=eng.field_energy(), memkind=memkind, exchanges=nx,
-             x=eng.particles_download()["x"])
+             x=eng.particles_download()["x"], tails=eng.kernel_stats(10)[1])
     eng.close()
     dist.barrier()
     dist.destroy_process_group()
