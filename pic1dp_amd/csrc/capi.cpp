@@ -587,6 +587,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->st) (void)hipStreamSynchronize(c->st);
   comm_release(c);
+  optimize_release(c);
   for (auto &S : c->sp) {
     (void)hipFree(S.slab[0]);
     (void)hipFree(S.slab[1]);

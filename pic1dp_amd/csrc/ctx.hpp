@@ -178,6 +178,7 @@ struct pic1dp_ctx {
   DistGeom dist_geom_v{};                  // output_ptcldist's histogram geometry (capi_diag.cpp dist_geom)
   bool dist_geom_ready = false;
   int64_t opt_pcie_bytes = 0;              // bytes marker optimisation events have moved between host and device
+  std::vector<void *> opt_workers;         // streams and staging of the events' block workers (capi_optimize.cpp OptWorker), kept between events
   int64_t diag_passes = 0;                 // separate k_ptcldist passes launched so far
   int64_t fused_solves = 0;                // marker launches whose prologue solved the previous step's field
   int chain_selftest = 0;                  // create()'s verdict on the serial sums through the matrix unit: 1 identical, 0 differs, -1 could not run
@@ -282,6 +283,7 @@ bool xchg_active(const pic1dp_ctx *c);
 XchgArgs next_xchg_args(pic1dp_ctx *c);
 int xchg_check(pic1dp_ctx *c);
 void comm_release(pic1dp_ctx *c);         // communicator and exchange mappings, for destroy
+void optimize_release(pic1dp_ctx *c);     // the optimisation events' workers (streams, pinned and device staging), for destroy
 // ---- capi_optimize.cpp ----
 void optimize_due_at(const pic1dp_ctx *c, double time0, bool due[3]);  // which events a step starting at time0 fires
 void optimize_due(const pic1dp_ctx *c, bool due[3]);

@@ -372,7 +372,9 @@ struct OptGrid {
 };
 constexpr uint32_t OPT_KEY_IMPORTANT = 0xFFFFFFFFu;
 // this block's |delta f|(v) into hist[nv] (device), every bin summed in storage order; synchronises the stream
-hipError_t opt_hist_block(const OptBlock &b, const OptGrid &g, int64_t np, double *hist, hipStream_t st);
+// scratch: device memory of at least opt_hist_scratch_bytes(np, nv) (the sort's items and temporaries)
+size_t opt_hist_scratch_bytes(int64_t np, int nv);
+hipError_t opt_hist_block(const OptBlock &b, const OptGrid &g, int64_t np, double *hist, void *scratch, hipStream_t st);
 hipError_t opt_merge_keys(const OptBlock &b, const OptGrid &g, const double *hist, double limit, int64_t np, uint32_t *keys,
                           hipStream_t st);
 hipError_t opt_remove_vals(const OptBlock &b, const OptGrid &g, const double *hist, double peak, double limit, int by_threshold,
@@ -380,9 +382,10 @@ hipError_t opt_remove_vals(const OptBlock &b, const OptGrid &g, const double *hi
 hipError_t opt_split_flags(const OptBlock &b, const OptGrid &g, const double *hist, double limit, int64_t np, uint8_t *flag,
                            hipStream_t st);
 // holes[nholes]: the positions below np_new whose marker is gone, ascending (gone: the ids listed, or -- gone_bits
-// non-null -- one bit per position); fails when their number is not nholes
+// non-null -- one bit per position); fails when their number is not nholes; scratch: opt_holes_scratch_bytes(np_new)
+size_t opt_holes_scratch_bytes(int64_t np_new);
 hipError_t opt_holes(const uint32_t *gone_ids, int64_t ngone, const uint32_t *gone_bits, int64_t np_new, int64_t nholes,
-                     uint32_t *holes, hipStream_t st);
+                     uint32_t *holes, void *scratch, hipStream_t st);
 // scratch: [4 npairs] doubles.  Indices are block-local, 32 bits (a block holds < 2^32 slots)
 hipError_t opt_merge_apply(const OptBlock &b, const OptGrid &g, const double *hist, double limit, const uint32_t *dst,
                            const uint32_t *idk, int64_t npairs, const uint32_t *move_pos, const uint32_t *move_id, int64_t nmoves,

@@ -309,26 +309,42 @@ int opt_blocks(int64_t n) {
 
 }  // namespace
 
-hipError_t opt_hist_block(const OptBlock &b, const OptGrid &g, int64_t np, double *hist, hipStream_t st) {
+// Device scratch of opt_hist_block / opt_holes comes from the caller (grow-only, one allocation per worker and event):
+// hipMalloc / hipFree per block would synchronise the whole device under the feet of the other blocks' workers.
+namespace {
+size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
+int hist_sort_bits(int nv) {
+  int bits = 1;
+  while ((1u << bits) < static_cast<unsigned>(nv + 1)) ++bits;
+  return bits;
+}
+}  // namespace
+
+size_t opt_hist_scratch_bytes(int64_t np, int nv) {
+  if (np <= 0) return 0;
+  const size_t n = 2 * static_cast<size_t>(np);
+  size_t tmp_bytes = 0;
+  uint32_t *k = nullptr;
+  double *v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k, k, v, v, n, 0, hist_sort_bits(nv), static_cast<hipStream_t>(nullptr));
+  return align256(sizeof(uint32_t) * 2 * n) + align256(sizeof(double) * 2 * n) + align256(tmp_bytes ? tmp_bytes : 16);
+}
+
+hipError_t opt_hist_block(const OptBlock &b, const OptGrid &g, int64_t np, double *hist, void *scratch, hipStream_t st) {
   if (np <= 0) {  // an empty block: zeros, and -- as every other path of this function -- the stream waited for
     hipError_t e0 = hipMemsetAsync(hist, 0, sizeof(double) * g.nv, st);
     return e0 != hipSuccess ? e0 : hipStreamSynchronize(st);
   }
   const size_t n = 2 * static_cast<size_t>(np);
-  uint32_t *keys = nullptr;
-  double *vals = nullptr;
-  void *tmp = nullptr;
-  hipError_t e = hipMalloc(&keys, sizeof(uint32_t) * 2 * n);
-  if (e == hipSuccess) e = hipMalloc(&vals, sizeof(double) * 2 * n);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_opt_hist_items, dim3(opt_blocks(np)), dim3(OPT_THREADS), 0, st, b, g, np, keys, vals);
-    e = hipGetLastError();
-  }
-  int bits = 1;
-  while ((1u << bits) < static_cast<unsigned>(g.nv + 1)) ++bits;
+  char *base = static_cast<char *>(scratch);
+  uint32_t *keys = reinterpret_cast<uint32_t *>(base);
+  double *vals = reinterpret_cast<double *>(base + align256(sizeof(uint32_t) * 2 * n));
+  void *tmp = base + align256(sizeof(uint32_t) * 2 * n) + align256(sizeof(double) * 2 * n);
+  hipLaunchKernelGGL(k_opt_hist_items, dim3(opt_blocks(np)), dim3(OPT_THREADS), 0, st, b, g, np, keys, vals);
+  hipError_t e = hipGetLastError();
+  const int bits = hist_sort_bits(g.nv);
   size_t tmp_bytes = 0;
   if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys + n, vals, vals + n, n, 0, bits, st);
-  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
   if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys + n, vals, vals + n, n, 0, bits, st);  // stable
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_opt_hist_fold, dim3((g.nv + OPT_THREADS - 1) / OPT_THREADS), dim3(OPT_THREADS), 0, st, keys + n, vals + n,
@@ -336,9 +352,6 @@ hipError_t opt_hist_block(const OptBlock &b, const OptGrid &g, int64_t np, doubl
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(tmp);
-  (void)hipFree(vals);
-  (void)hipFree(keys);
   return e;
 }
 
@@ -358,18 +371,29 @@ hipError_t opt_split_flags(const OptBlock &b, const OptGrid &g, const double *hi
   hipLaunchKernelGGL(k_opt_split_flags, dim3(opt_blocks(np)), dim3(OPT_THREADS), 0, st, b, g, hist, limit, np, flag);
   return hipGetLastError();
 }
-hipError_t opt_holes(const uint32_t *gone_ids, int64_t ngone, const uint32_t *gone_bits, int64_t np_new, int64_t nholes,
-                     uint32_t *holes, hipStream_t st) {
-  if (nholes <= 0 || np_new <= 0) return hipSuccess;
+size_t opt_holes_scratch_bytes(int64_t np_new) {
+  if (np_new <= 0) return 0;
+  size_t tmp_bytes = 0;
+  rocprim::counting_iterator<uint32_t> positions(0);
   uint8_t *gone = nullptr;
+  uint32_t *holes = nullptr;
   unsigned *count = nullptr;
-  void *tmp = nullptr;
-  hipError_t e = hipMalloc(&gone, static_cast<size_t>(np_new));
-  if (e == hipSuccess) e = hipMalloc(&count, sizeof(unsigned));
-  if (e == hipSuccess && gone_bits) {
+  (void)rocprim::select(nullptr, tmp_bytes, positions, gone, holes, count, static_cast<size_t>(np_new), static_cast<hipStream_t>(nullptr));
+  return align256(static_cast<size_t>(np_new)) + 256 + align256(tmp_bytes ? tmp_bytes : 16);
+}
+
+hipError_t opt_holes(const uint32_t *gone_ids, int64_t ngone, const uint32_t *gone_bits, int64_t np_new, int64_t nholes,
+                     uint32_t *holes, void *scratch, hipStream_t st) {
+  if (nholes <= 0 || np_new <= 0) return hipSuccess;
+  char *base = static_cast<char *>(scratch);
+  uint8_t *gone = reinterpret_cast<uint8_t *>(base);
+  unsigned *count = reinterpret_cast<unsigned *>(base + align256(static_cast<size_t>(np_new)));
+  void *tmp = base + align256(static_cast<size_t>(np_new)) + 256;
+  hipError_t e = hipSuccess;
+  if (gone_bits) {
     hipLaunchKernelGGL(k_opt_mark_bits, dim3(opt_blocks(np_new)), dim3(OPT_THREADS), 0, st, gone_bits, np_new, gone);
     e = hipGetLastError();
-  } else if (e == hipSuccess) {
+  } else {
     e = hipMemsetAsync(gone, 0, static_cast<size_t>(np_new), st);
     if (e == hipSuccess && ngone > 0) {
       hipLaunchKernelGGL(k_opt_mark_ids, dim3(opt_blocks(ngone)), dim3(OPT_THREADS), 0, st, gone_ids, ngone, np_new, gone);
@@ -379,14 +403,10 @@ hipError_t opt_holes(const uint32_t *gone_ids, int64_t ngone, const uint32_t *go
   size_t tmp_bytes = 0;
   rocprim::counting_iterator<uint32_t> positions(0);
   if (e == hipSuccess) e = rocprim::select(nullptr, tmp_bytes, positions, gone, holes, count, static_cast<size_t>(np_new), st);
-  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
   if (e == hipSuccess) e = rocprim::select(tmp, tmp_bytes, positions, gone, holes, count, static_cast<size_t>(np_new), st);
   unsigned found = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&found, count, sizeof found, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(tmp);
-  (void)hipFree(count);
-  (void)hipFree(gone);
   if (e == hipSuccess && static_cast<int64_t>(found) != nholes) return hipErrorAssert;  // the walk and the marks disagree
   return e;
 }

@@ -4,6 +4,7 @@
 ! with MPI outside the hot path travel through small files in a rendez-vous directory (PIC1DP_RENDEZVOUS -- fresh for
 ! every run: a file an earlier run left there would be taken for this run's; ranks_finalize removes this run's):
 !   ranks_allgather_handles  <->  MPI_Allgather of the 64-byte exchange handles (INTEGRATION.md section 4)
+!   ranks_bcast_bytes        <->  MPI_Bcast of RCCL's 128-byte unique id from rank 0 (PIC1DP_ALLREDUCE=rccl)
 !   ranks_reduce_to_root     <->  MPI_Reduce(..., MPI_SUM, 0, ...) of the diagnostics (src/pic1dp_output.F90:333-356)
 ! The charge sum of the hot path (MPI_Allreduce, src/pic1dp_interaction.F90:130-135) does NOT go through files:
 ! it is the library's one-hop exchange between the GPUs.  With MPI in the image these two routines are the two
@@ -110,6 +111,19 @@ subroutine ranks_allgather_handles(mine, nbytes, all)
     call ranks_fetch(ranks_file('gather', ranks_seq, q), all(q * nbytes + 1 : (q + 1) * nbytes), nbytes)
   end do
 end subroutine ranks_allgather_handles
+
+! MPI_Bcast(buf, nbytes, MPI_BYTE, 0): rank 0 publishes, the others fetch (the file goes with ranks_finalize)
+subroutine ranks_bcast_bytes(buf, nbytes)
+  integer(c_signed_char), intent(inout) :: buf(*)
+  integer, intent(in) :: nbytes
+  ranks_seq = ranks_seq + 1
+  if (ranks_size == 1) return
+  if (ranks_rank == 0) then
+    call ranks_publish(ranks_file('gather', ranks_seq, 0), buf, nbytes)
+  else
+    call ranks_fetch(ranks_file('gather', ranks_seq, 0), buf, nbytes)
+  end if
+end subroutine ranks_bcast_bytes
 
 ! MPI_Reduce(a, a, n, MPI_DOUBLE, MPI_SUM, 0): on rank 0 a becomes the sum over ranks in rank order; the
 ! other ranks only contribute (and go on at once, like MPI_Reduce lets them)

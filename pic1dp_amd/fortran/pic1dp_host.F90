@@ -12,8 +12,13 @@
 !
 ! As the reference, the host runs as one of N processes, one per GPU (src/pic1dp.F90:43-52; `make run` starts
 ! four): rank / size from PIC1DP_RANK / PIC1DP_NRANKS, each rank owns its PETSC_DECIDE block of the markers, the
-! charge is summed over the GPUs inside the library (one-hop exchange; the handles are all-gathered once,
-! host_ranks.F90), and rank 0 alone writes pic1dp.out and the progress lines from diagnostics reduced to it.
+! charge is summed over the GPUs inside the library, and rank 0 alone writes pic1dp.out and the progress lines from
+! diagnostics reduced to it.  How the library sums the charge (MPI_Allreduce, src/pic1dp_interaction.F90:130-135):
+!   PIC1DP_ALLREDUCE=p2p  (default for N > 1) the one-hop exchange; the 64-byte handles are all-gathered once
+!   PIC1DP_ALLREDUCE=rccl an RCCL all-reduce over xGMI: rank 0 draws the communicator's 128-byte unique id
+!                         (pic1dp_hip_comm_unique_id), it is broadcast (host_ranks.F90), every rank joins
+!                         (pic1dp_hip_comm_init) -- also with N = 1, where the one-rank communicator runs every launch of
+!                         the N-rank RCCL step on one GPU.
 !
 ! With PIC1DP_FUSED=1 in the environment the three calls of a sub-step are
 ! replaced by the fused pic1dp_hip_substep(ctx, global_irk); with PIC1DP_FUSED=2
@@ -39,18 +44,27 @@ integer(c_int32_t) :: global_irk, global_itime, itermination, due, flag_optimize
 real(c_double) :: global_time, ms_push, ms_charge, ms_field
 real(c_double) :: t_run0, t_loop0, t_a, steps_s, load_s
 character(len=8) :: buf
+character(len=512) :: dump_path
 integer :: stat, verbosity
-logical :: fused, whole_step, batched
-integer(c_signed_char) :: handle(PIC1DP_XCHG_HANDLE_BYTES)
+logical :: fused, whole_step, batched, use_rccl
+integer(c_signed_char) :: handle(PIC1DP_XCHG_HANDLE_BYTES), comm_id(PIC1DP_COMM_ID_BYTES)
 integer(c_signed_char), allocatable :: handles(:)
 
 call input_fill(inp)
 call ranks_init()                           ! MPI_Comm_rank / MPI_Comm_size, src/pic1dp.F90:50-52
 lay = pic1dp_layout_t(ranks_rank, ranks_size, 0, -1)   ! one process per GPU (device = rank mod visible GPUs)
 call pic1dp_hip_check(pic1dp_hip_create(inp, lay, ctx), 'create')      ! particle_init + field_init
-if (ranks_size > 1) then
-  ! the charge sum over ranks (MPI_Allreduce, src/pic1dp_interaction.F90:130-135) is the library's one-hop
-  ! exchange: every rank's 64-byte handle to every rank, once
+call get_environment_variable('PIC1DP_ALLREDUCE', buf, status=stat)
+use_rccl = (stat == 0 .and. buf(1:4) == 'rccl')
+if (use_rccl) then
+  ! the charge sum over ranks (MPI_Allreduce, src/pic1dp_interaction.F90:130-135) as an RCCL all-reduce: the
+  ! communicator's unique id from rank 0 to every rank (MPI_Bcast), then every rank joins
+  if (ranks_rank == 0) call pic1dp_hip_check(pic1dp_hip_comm_unique_id(comm_id), 'comm_unique_id')
+  call ranks_bcast_bytes(comm_id, PIC1DP_COMM_ID_BYTES)
+  call pic1dp_hip_check(pic1dp_hip_comm_init(ctx, comm_id), 'comm_init')
+  call pic1dp_hip_check(pic1dp_hip_set_allreduce(ctx, 1), 'set_allreduce')
+else if (ranks_size > 1) then
+  ! ... or as the library's one-hop exchange: every rank's 64-byte handle to every rank, once
   allocate (handles(PIC1DP_XCHG_HANDLE_BYTES * ranks_size))
   call pic1dp_hip_check(pic1dp_hip_xchg_create(ctx, handle), 'xchg_create')
   call ranks_allgather_handles(handle, PIC1DP_XCHG_HANDLE_BYTES, handles)
@@ -137,6 +151,27 @@ if (verbosity >= 1) then
   write (*, '(a, f12.3, a, f12.3, a, f12.3)') '   push particle', ms_push, '   collect charge', ms_charge, &
     '   electric field', ms_field
 end if
+call get_environment_variable('PIC1DP_DUMP_MARKERS', dump_path, status=stat)
+if (stat == 0) call dump_markers(trim(dump_path))
 call pic1dp_hip_check(pic1dp_hip_destroy(ctx), 'destroy')   ! particle_final + field_final
 call ranks_finalize()
+
+contains
+
+! PIC1DP_DUMP_MARKERS=<file>: this rank's markers of species 0 at the end of the run, raw native doubles
+! [np as one double | x | v | p | w] -- for tests that compare two runs of the host bit for bit
+subroutine dump_markers(path)
+  character(len=*), intent(in) :: path
+  integer(c_int64_t) :: nalloc, np
+  real(c_double), allocatable :: x(:), v(:), p(:), w(:)
+  integer :: u
+  call pic1dp_hip_check(pic1dp_hip_local_sizes(ctx, 0_c_int32_t, nalloc, np), 'local_sizes')
+  allocate (x(nalloc), v(nalloc), p(nalloc), w(nalloc))
+  call pic1dp_hip_check(pic1dp_hip_particles_download(ctx, 0_c_int32_t, x, v, p, w, nalloc), 'particles_download')
+  open (newunit=u, file=path, access='stream', form='unformatted', status='replace')
+  write (u) real(np, c_double)
+  write (u) x(1 : np), v(1 : np), p(1 : np), w(1 : np)
+  close (u)
+end subroutine dump_markers
+
 end program pic1dp_host

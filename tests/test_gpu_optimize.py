@@ -108,6 +108,17 @@ def aligned_event(oracle_mod, amd, npe, kw, steps_before=5):
     return n_after
 
 
+@pytest.mark.parametrize("threads", ["1", "2", "7"])
+def test_event_walks_on_host_threads_change_nothing(oracle_mod, amd, monkeypatch, threads):
+    """the blocks of an event are walked side by side on host threads (one random stream, one set of
+    keys per block: the reference runs them as separate ranks, src/pic1dp_particle.F90:411-746) -- whatever the number
+    of threads, every block bit for bit what the oracle's routines leave (seven blocks; one, two, seven workers)"""
+    monkeypatch.setenv("PIC1DP_OPT_THREADS", threads)
+    kw = dict(nparticle_max=70000, species_nparticle_init=[42000], nx=32, nv=64, nmerge=1, tmerge=[0.3], thshmerge=[0.3],
+              nremove=1, tremove=[0.3], typeremove=2, nsplit=1, tsplit=[0.3], thshsplit=[0.6])
+    aligned_event(oracle_mod, amd, 7, kw)
+
+
 def random_event_case(rng):
     nmax = int(rng.integers(3000, 70000))
     ninit = int(nmax * rng.uniform(0.35, 1.0))

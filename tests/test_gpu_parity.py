@@ -388,6 +388,30 @@ def test_field_solve_bit_exact(oracle_mod, amd, nx, modes, npe):
     assert abs(eng.field_energy() - oracle_mod.lib().orc_field_energy(C.byref(sim.inp), E)) <= 64 * EPS * abs(eng.field_energy())
 
 
+@pytest.mark.parametrize("chain", ["1", "0"], ids=["matrix_unit_chain", "one_lane_chain"])
+@pytest.mark.parametrize("npe", [1, 2])
+def test_engine_two_virtual_ranks_nx128_chain_on_and_off(oracle_mod, amd, monkeypatch, npe, chain):
+    """The configuration of round 4's mid-round red run (gpurun_out/r4o, profiles/README.md: `field_energy_end = nan` out
+    of bench.py's two-rank rehearsal AND out of the one-process engine with two virtual ranks, nx 128, 3e6 markers, while
+    the serial sums through the matrix unit were going in) as a direct test of the engine: every field energy of a run
+    finite and within 1e-10 of the oracle's npe-rank run, the solve of one charge density bit-identical to the oracle's --
+    with the create()-time self-test deciding for the matrix unit and with the one-lane chains insisted on -- and the
+    npe-rank order never routed through the matrix unit (its rows are rank blocks, not the one-rank sum)."""
+    monkeypatch.setenv("PIC1DP_CHAIN_MFMA", chain)
+    sim, eng = pair(oracle_mod, amd, npe=npe, nparticle_max=300_000, nx=128)
+    verdict, used = eng.kernel_stats(9)
+    assert used == (1 if (chain == "1" and verdict == 1.0) else 0)
+    t, eo, eg = run_both(sim, eng, 40)
+    assert np.all(np.isfinite(eg)) and np.all(eg > 0.0)
+    assert np.max(np.abs(eg / eo - 1.0)) < ENERGY_RTOL
+    rho = np.random.default_rng(128).standard_normal(128) * 1e-3
+    E, re, im = oracle_mod.Field(sim.inp).solve(rho, npe)
+    eng.set_chargeden(rho)
+    eng.field_solve_electric()
+    f = eng.get_field()
+    assert np.array_equal(f["mode_re"], re) and np.array_equal(f["mode_im"], im) and np.array_equal(f["electric"], E)
+
+
 def test_field_solve_full_spectrum(oracle_mod, amd):
     """every mode 1..nx/2-1 kept (the many-mode kernels).  The solve is
     then the spectral integral of a zero-mean chargeden without its Nyquist part:

@@ -9,7 +9,7 @@ import pic1dp_amd  # noqa: E402
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**8
 nx = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=n, nx=nx))
-eng.set_output_fusion(os.environ.get("FUSE", "1") == "1")
+eng.set_output_fusion(int(os.environ.get("FUSE", "1")))     # 0 own pass, 1 where it pays, 2 always inside the step
 eng.particle_load()
 eng.interaction_collect_charge()
 eng.field_solve_electric()
