@@ -234,8 +234,10 @@ int pic1dp_hip_solve_field(pic1dp_ctx *ctx);
  * collect_charge, solve_field the push is only noted and the collect_charge
  * that follows runs one whole-step kernel for both; from the second step on the
  * collect_charge after push(1) touches no marker at all -- the previous step's
- * kernel has predicted its charge (DESIGN.md 3.2a) -- so a step is ONE pass over
- * the markers (56-72 instead of 184 bytes per marker and step).  Whatever looks at the markers in between first gets the
+ * kernel has predicted its charge (DESIGN.md 3.2) -- so a step is ONE pass over
+ * the markers (56 instead of 184 bytes per marker and step), and on one rank the
+ * solve_field after the second collect_charge solves both fields of the step in one
+ * launch: two launches per time step.  Whatever looks at the markers in between first gets the
  * ordinary kernels run, so every observable state is the eager one, bit for
  * bit.  PIC1DP_LAZY_CALLS=0 in the environment: one kernel per call, at once. */
 int pic1dp_hip_push(pic1dp_ctx *ctx, int32_t irk);
@@ -243,9 +245,13 @@ int pic1dp_hip_push(pic1dp_ctx *ctx, int32_t irk);
  * right after the push of sub-step irk): when global_time + dt has reached the
  * next entry of tmerge / tremove / tsplit and irk == 2, runs particle_merge /
  * particle_remove / particle_split (:411-715) on every owned reference block and
- * sets *flag_optimized = 1.  These routines are sequential and consume the
- * block's random stream, so they run on the host (download, apply, upload);
- * they are off the timed path and disabled by default.  pic1dp_hip_step calls
+ * sets *flag_optimized = 1.  The markers stay on the device: the |delta f|(v)
+ * histogram is folded there in the reference's order of additions, one small key per
+ * marker (1-8 B) goes to the host, which walks the keys exactly as these sequential
+ * routines walk the markers (visiting order, swap-with-last, the block's random
+ * stream; the blocks side by side on host threads), and the decisions are applied on
+ * the device (PIC1DP_OPT_HOST=1: the pass on host copies of the
+ * markers, kept as the cross-check).  Off the timed path and disabled by default.  pic1dp_hip_step calls
  * this itself.  Needs markers loaded by pic1dp_hip_particle_load (the blocks'
  * generators continue from the load), delta-f only like the reference. */
 int pic1dp_hip_particle_optimize(pic1dp_ctx *ctx, int32_t irk, int32_t *flag_optimized);
@@ -488,7 +494,10 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
  * *ms = that self-test's verdict (1 identical, 0 differs, -1 it could not run: the chains then);
  * which = 10: *launches = marker launches so far whose last workgroup packed this rank's charge
  * for the sum over ranks or posted it into the peers' exchange slots itself (several ranks: no
- * separate packing launch in front of the all-reduce; PIC1DP_TAIL=0 keeps that launch), *ms = 0 */
+ * separate packing launch in front of the all-reduce; PIC1DP_TAIL=0 keeps that launch), *ms = 0;
+ * which = 11: *launches = pic1dp_hip_solve_field calls of a first sub-step that launched nothing
+ * because the solve_field before them had solved both fields in one launch (one rank, the three
+ * call sites: two launches per time step; PIC1DP_CALL_PAIR=0: three), *ms = 0 */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

@@ -406,6 +406,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   c->d_rho_sp = c->d_rho_all;
   if (const char *e = std::getenv("PIC1DP_FUSE_SOLVE")) c->fuse_solve = std::max(0, std::min(2, std::atoi(e)));
   if (const char *e = std::getenv("PIC1DP_TAIL")) c->tail_on = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PIC1DP_CALL_PAIR")) c->call_pair = std::atoi(e) != 0;
   HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&c->d_ticket), 64));
   HIP_TRY_C(hipMemsetAsync(c->d_ticket, 0, 64, c->st));
   for (int s = 0; s < ns; ++s) {
@@ -881,6 +882,7 @@ int pic1dp_hip_chargeden_state(pic1dp_ctx *c, int32_t *kept_mode_only) {
 int pic1dp_hip_get_field(pic1dp_ctx *c, double *E, double *cd, double *re, double *im) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
+  if (int rc = settle_field_view(c)) return rc;
   if (int rc = materialize_cd(c)) return rc;
   if (cd && c->cd_kept_mode_only)
     if (int rc = rebuild_half_step_chargeden(c)) return rc;
@@ -898,6 +900,7 @@ int pic1dp_hip_set_electric(pic1dp_ctx *c, const double *E) {
   CHECK_CTX(c);
   if (!E) return fail(PIC1DP_ERR_ARG, "null array");
   HIP_TRY(hipSetDevice(c->device));
+  if (int rc = settle_half_pair(c)) return rc;   // (d_E0 keeps the step-start field a noted push(1) saw)
   if (c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2)
     if (int rc = materialize(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
@@ -911,6 +914,10 @@ int pic1dp_hip_set_chargeden(pic1dp_ctx *c, const double *cd) {
   if (!cd) return fail(PIC1DP_ERR_ARG, "null array");
   HIP_TRY(hipSetDevice(c->device));
   if (int rc = materialize_cd(c)) return rc;  // pending deposits are consumed, then overwritten
+  if (c->cd_lazy == 5) {                      // (a half-step field waiting to be adopted: the host's charge density rules now)
+    if (int rc = settle_half_pair(c)) return rc;
+    c->cd_lazy = 0;
+  }
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(c->d_chargeden, cd, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
   c->cd_kept_mode_only = false;
@@ -921,6 +928,7 @@ int pic1dp_hip_field_energy(pic1dp_ctx *c, double *energy) {
   CHECK_CTX(c);
   if (!energy) return fail(PIC1DP_ERR_ARG, "null output");
   HIP_TRY(hipSetDevice(c->device));
+  if (int rc = settle_field_view(c)) return rc;
   double *slot = c->d_scratch + kEnergyBlocks * 3;
   HIP_TRY(launch_field_energy(c->d_E, c->in.nx, c->in.lx, static_cast<double>(c->in.nx), slot, c->st));
   HIP_TRY(hipStreamSynchronize(c->st));
@@ -1020,7 +1028,12 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 10) return fail(PIC1DP_ERR_ARG, "which must be 0..10");
+  if (which < 0 || which > 11) return fail(PIC1DP_ERR_ARG, "which must be 0..11");
+  if (which == 11) {  // call sites: solve_field calls of a half step that launched nothing (the pair solve before them had it)
+    if (ms) *ms = 0.0;
+    if (launches) *launches = c->call_pair_skips;
+    return 0;
+  }
   if (which == 10) {  // marker launches whose last workgroup packed / posted this rank's charge (kernels.hpp StepTail)
     if (ms) *ms = 0.0;
     if (launches) *launches = c->tail_launches;

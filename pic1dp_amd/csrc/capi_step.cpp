@@ -117,6 +117,7 @@ static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer);
 // field_chargeden (and d_charge, and zeroed accumulators) as collect_charge would have left them at once
 int pic1dp_host::materialize_cd(pic1dp_ctx *c) {
   const int pending = c->cd_lazy;
+  if (pending == 5) return 0;  // (a half-step FIELD waiting to be adopted by solve_field, ctx.hpp half_pair: no charge to settle)
   c->cd_lazy = 0;
   if (pending == 0) return 0;
   if (pending == 4) {  // the six sums of a predicted push(1): the kept mode's content of chargeden, directly
@@ -175,7 +176,35 @@ static int enqueue_wrap_only(pic1dp_ctx *c) {
   return 0;
 }
 
+// Call sites (ctx.hpp half_pair): the half-step field the pair solve left in d_Ehn / d_mode_h, and the step-start
+// field still in field_electric, put where the eager calls would have them -- d_E0 <- E, and, once the host has called
+// solve_field for the half step, E <- the half-step field with its kept modes.  Everything that looks at the field, or
+// leaves the sequence push(1), collect_charge, solve_field, push(2), collect_charge, comes through here first.
+int pic1dp_host::settle_half_pair(pic1dp_ctx *c) {
+  if (!c->half_pair) return 0;
+  const size_t nx = c->in.nx;
+  HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * nx, hipMemcpyDeviceToDevice, c->st));
+  const bool solved = c->half_solved;
+  c->half_pair = c->half_solved = false;
+  // solve_field has been called for the half step: field_electric has to BE the half-step field now (field_version was
+  // bumped when it was called); not yet called: it stays pending (cd_lazy 5) and copies when it comes
+  if (solved) return adopt_half_field(c);
+  return 0;
+}
+// for readers of the field only: nothing to do until the host has called solve_field for the half step -- until then
+// field_electric is the step-start field, which is what d_E holds
+int pic1dp_host::settle_field_view(pic1dp_ctx *c) { return c->half_pair && c->half_solved ? settle_half_pair(c) : 0; }
+// field_electric and its kept modes <- the half-step field the pair solve left in d_Ehn / d_mode_h
+int pic1dp_host::adopt_half_field(pic1dp_ctx *c) {
+  const size_t nx = c->in.nx, nm = c->in.nmode;
+  HIP_TRY(hipMemcpyAsync(c->d_E, c->d_Ehn, sizeof(double) * nx, hipMemcpyDeviceToDevice, c->st));
+  HIP_TRY(hipMemcpyAsync(c->fa.mode_re, c->d_mode_h, sizeof(double) * nm, hipMemcpyDeviceToDevice, c->st));
+  HIP_TRY(hipMemcpyAsync(c->fa.mode_im, c->d_mode_h + nm, sizeof(double) * nm, hipMemcpyDeviceToDevice, c->st));
+  return 0;
+}
+
 int pic1dp_host::materialize(pic1dp_ctx *c) {
+  if (int rc = settle_half_pair(c)) return rc;
   const int lz = c->lz;
   c->lz = LZ_CLEAN;
   if (lz == LZ_CLEAN) return 0;
@@ -197,8 +226,18 @@ static int deposit_or_step(pic1dp_ctx *c) {
     return 0;
   }
   if (c->lz == LZ_PUSH2) {
+    if (c->half_pair && !c->half_solved)  // (push(2) without the solve_field of the half step: it sees the old field)
+      if (int rc = settle_half_pair(c)) return rc;
     c->state_version++;
     const bool diag = diag_in_step(c) && output_follows(c);
+    if (c->half_pair) {  // the half-step field came out of the previous step's pair solve (ctx.hpp): E0 is still in d_E
+      c->half_pair = c->half_solved = false;
+      std::swap(c->d_Eh, c->d_Ehn);
+      c->eh_modes = 2;  // its kept mode: d_mode_h
+      if (int rc = step_particles(c, true, c->d_E, c->d_Eh, diag, !diag)) return rc;
+      c->lz = LZ_CLEAN;
+      return 0;
+    }
     // Eh = d_E: the kept modes describe it when the mode-filter solve wrote it last
     c->eh_modes = (c->field_solver == 0 && c->modes_field_version == c->field_version) ? 1 : 0;
     if (int rc = step_particles(c, true, c->d_E0, c->d_E, diag, !diag)) return rc;
@@ -216,6 +255,20 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   // (step_particles); "collect charge" then covers the reduction and scaling only
   // after a noted push(1) whose charge the previous step's kernel has predicted (k_step_one): no
   // pass over the markers at all -- combine, reduce, scale
+  if (c->half_pair && !(c->lz == LZ_PUSH2 && c->half_solved))  // out of sequence: memory as the eager calls leave it
+    if (int rc = settle_half_pair(c)) return rc;
+  // after a noted push(1) whose half-step FIELD the previous solve_field has already solved (the pair, below): nothing
+  // to launch at all
+  // (the six sums of one kept mode: with the tiles collect_charge owes the host the whole half-step charge density)
+  if (c->lz == LZ_PUSH1 && c->call_pair && c->lazy_calls && c->lay.nranks == 1 && c->comm == nullptr && predict_capable(c) &&
+      c->pred_kind == 2 && c->in.nmode == 1 && c->eh_version == c->state_version && c->eh_field_version == c->field_version) {
+    c->lz = LZ_HALF;
+    c->half_pair = true;
+    c->half_solved = false;
+    c->cd_lazy = 5;               // what the solve_field that follows has to do: adopt the half-step field
+    c->cd_kept_mode_only = true;  // (field_chargeden is not the half step's: asking for it rebuilds, get_field)
+    return 0;
+  }
   if (c->lz == LZ_PUSH1 && pred_usable(c)) {
     HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
     c->lz = LZ_HALF;
@@ -262,6 +315,11 @@ int pic1dp_hip_set_field_solver(pic1dp_ctx *c, int32_t kind) {
   if (kind != 0 && kind != 1) return fail(PIC1DP_ERR_ARG, "field solver must be 0 (reference mode filter) or 1 (finite differences)");
   if (kind == 1 && (c->in.nx < 3 || c->in.nx > 4096))
     return fail(PIC1DP_ERR_ARG, "the finite-difference solver needs 3 <= nx <= 4096");
+  if (c->cd_lazy == 5 && kind != c->field_solver) {  // a half-step field of the OTHER solver waits to be adopted (ctx.hpp
+    HIP_TRY(hipSetDevice(c->device));                // half_pair): the half-step charge is deposited for real instead
+    if (int rc = rebuild_half_step_chargeden(c)) return rc;
+    c->cd_lazy = 0;
+  }
   c->field_solver = kind;
   return 0;
 }
@@ -269,6 +327,16 @@ int pic1dp_hip_set_field_solver(pic1dp_ctx *c, int32_t kind) {
 int pic1dp_hip_solve_field(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
+  if (c->half_pair) {
+    if (c->lz == LZ_HALF && !c->half_solved && c->cd_lazy == 5) {  // the half-step field is solved already (the pair below)
+      c->half_solved = true;
+      c->cd_lazy = 0;
+      c->call_pair_skips++;
+      field_written(c, true);  // from now on field_electric IS the half-step field, as far as anybody can tell
+      return 0;
+    }
+    if (int rc = settle_half_pair(c)) return rc;
+  }
   // a noted push has to see the field of its own moment
   if (c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2)
     if (int rc = materialize(c)) return rc;
@@ -276,7 +344,22 @@ int pic1dp_hip_solve_field(pic1dp_ctx *c) {
   FieldArgs f = c->fa;
   const int pending = c->cd_lazy;  // what collect_charge left to this launch
   c->cd_lazy = 0;
-  if (pending == 3 && c->field_solver == 0) {
+  // One rank, behind the collect_charge of push(2) whose kernel has predicted the next half-step charge: BOTH fields in
+  // one launch, as pic1dp_hip_step solves them -- the next step's push(1), collect_charge, solve_field then launch nothing
+  // and a time step through the three call sites is two launches (round 5; three and a copy before)
+  if (pending == 2 && c->call_pair && c->lazy_calls && c->field_solver == 0 && c->lz == LZ_CLEAN && pred_usable(c) &&
+      c->pred_kind == 2 && c->in.nmode == 1) {
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, c->pair_plain, 0};
+    HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));
+    field_written(c, true);
+    c->pred_version = 0;  // consumed
+    c->eh_version = c->state_version;
+    c->eh_field_version = c->field_version;
+    return tm.end();
+  }
+  if (pending == 5) {  // (the fast path above was left by an inspection in between: the field is adopted by copying)
+    if (int rc = adopt_half_field(c)) return rc;
+  } else if (pending == 3 && c->field_solver == 0) {
     HIP_TRY(launch_field_solve_pred(f, c->d_pred, c->in.nmode, c->st));
   } else if (pending == 4 && c->field_solver == 0) {
     HIP_TRY(launch_field_solve_pred_sums(f, c->pred_tab, c->d_pred, c->st));
@@ -947,6 +1030,7 @@ int pic1dp_host::rebuild_half_step_chargeden(pic1dp_ctx *c) {
   // content and pic1dp_hip_chargeden_state says so
   if (c->lay.nranks > 1 || c->comm != nullptr) return 0;
   if (c->lz != LZ_HALF && c->lz != LZ_PUSH2) return 0;
+  if (int rc = settle_half_pair(c)) return rc;
   const bool push2_noted = c->lz == LZ_PUSH2;
   if (int rc = enqueue_push(c, 1, false, c->d_E0)) return rc;
   c->lz = LZ_CLEAN;  // memory now holds the half-step state (x not yet wrapped): the deposit wraps and stores it

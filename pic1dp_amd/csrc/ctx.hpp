@@ -132,6 +132,16 @@ struct pic1dp_ctx {
   // below): a push is only noted; the collect_charge that follows runs the
   // whole-step kernel instead of push + deposit.
   int lazy_calls = 1;            // PIC1DP_LAZY_CALLS=0: every call launches its own kernel at once
+  // Call sites, one rank: the solve_field that follows the collect_charge of push(2) solves BOTH fields in one launch
+  // (the pair kernels of pic1dp_hip_step) -- the new state's into field_electric, the next step's half-step field from the
+  // prediction into d_Ehn / d_mode_h.  The next push(1) / collect_charge / solve_field then launch nothing: half_pair says
+  // that the half-step field lies in d_Ehn (field_electric still holds the step-start field, d_E0 is not filled),
+  // half_solved that the host has called solve_field for it -- what it may look at from then on is the half-step field,
+  // so every inspection first settles (capi_step.cpp settle_half_pair: copies, memory as the eager calls leave it).
+  // PIC1DP_CALL_PAIR=0: the three launches per step of rounds 2-4.
+  int call_pair = 1;
+  bool half_pair = false, half_solved = false;
+  int64_t call_pair_skips = 0;   // solve_field calls of a half step served without a launch (kernel_stats 11)
   // collect_charge leaves its last step to the solve_field that follows (one launch less per sub-step):
   // 0 field_chargeden is current; 1 d_charge holds the summed charge1, its scaling is pending; 2 (one rank) the
   // species accumulators hold the deposits, species sum and scaling pending; 3 (one rank, mode-filter solve, few
@@ -283,6 +293,9 @@ bool xchg_active(const pic1dp_ctx *c);
 XchgArgs next_xchg_args(pic1dp_ctx *c);
 int xchg_check(pic1dp_ctx *c);
 void comm_release(pic1dp_ctx *c);         // communicator and exchange mappings, for destroy
+int settle_half_pair(pic1dp_ctx *c);      // call sites: the half-step field the pair solve left aside becomes field_electric (ctx.hpp half_pair)
+int settle_field_view(pic1dp_ctx *c);     // ... for readers of the field only
+int adopt_half_field(pic1dp_ctx *c);
 void optimize_release(pic1dp_ctx *c);     // the optimisation events' workers (streams, pinned and device staging), for destroy
 // ---- capi_optimize.cpp ----
 void optimize_due_at(const pic1dp_ctx *c, double time0, bool due[3]);  // which events a step starting at time0 fires

@@ -633,3 +633,87 @@ def test_one_pass_three_and_four_kept_modes_against_oracle(oracle_mod, amd, monk
     assert np.max(np.abs(g["x"] - sim.gather("x"))) < 1e-9 and np.max(np.abs(g["v"] - sim.gather("v"))) < 1e-9
     if kw.get("deltaf", 1):
         assert np.max(np.abs(g["w"] - sim.gather("w"))) < 1e-9 * max(1.0, np.max(np.abs(sim.gather("w"))))
+
+
+@pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
+def test_call_sites_two_launches_per_step(oracle_mod, amd, monkeypatch, kind):
+    """through the three call sites (src/pic1dp.F90:80-89), one rank, the solve_field behind the second
+    collect_charge solves BOTH fields of the step in one launch -- as pic1dp_hip_step does -- and the next step's push(1),
+    collect_charge, solve_field launch nothing: marker kernel + one field launch per time step (three launches and a copy
+    before; PIC1DP_CALL_PAIR=0).  With one wave of markers per block (one order of the charge sums) the three ways of
+    stepping -- call sites with the pair, call sites without, pic1dp_hip_step -- agree bit for bit; at a realistic count
+    every step's field energy is the oracle's to 1e-10."""
+    def calls(e, n):
+        for _ in range(n):
+            for irk in (1, 2):
+                e.interaction_push_particle(irk)
+                e.particle_optimize(irk)
+                e.interaction_collect_charge()
+                e.field_solve_electric()
+    nsteps = 30
+    kw = dict(nparticle_max=96, nx=32)
+    monkeypatch.setenv("PIC1DP_CALL_PAIR", "1")
+    a = engine(amd, monkeypatch, True, kind, **kw)
+    monkeypatch.setenv("PIC1DP_CALL_PAIR", "0")
+    b = engine(amd, monkeypatch, True, kind, **kw)
+    monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "0")
+    c = engine(amd, monkeypatch, True, kind, **kw)
+    a.kernel_stats_enable(True)
+    calls(a, nsteps)
+    calls(b, nsteps)
+    c.step(nsteps)
+    # (the pair serves the six sums of one kept mode -- the default; with the tiles collect_charge owes the host the
+    # whole half-step charge density, which the lean pair kernel never forms: three launches as before)
+    assert a.kernel_stats(11)[1] == (nsteps - 1 if kind == 2 else 0) and b.kernel_stats(11)[1] == 0
+    assert a.kernel_stats(3)[1] == 1 and a.kernel_stats(6)[1] == nsteps       # one first-sub-step pass in the whole run
+    fa, fb, fc = a.get_field(), b.get_field(), c.get_field()
+    ga, gb, gc = a.particles_download(), b.particles_download(), c.particles_download()
+    # with the pair the call sites ARE pic1dp_hip_step's launches: bit for bit.  Without it the half-step field comes out
+    # of the kept mode's content of the predicted charge density, solved again (k_field_solve_pred_sums): the same field
+    # to rounding (tiles: the pair is not used, and pic1dp_hip_step's lean pair kernel groups the predicted charge otherwise)
+    for k in ("electric", "mode_re", "mode_im", "chargeden"):
+        if kind == 2:
+            assert np.array_equal(fa[k], fc[k]), k
+        else:
+            assert np.array_equal(fa[k], fb[k]), k
+        assert relerr(fa[k], fb[k]) < 1e-12 and relerr(fa[k], fc[k]) < 1e-12, k
+    for k in "xvw":
+        if kind == 2:
+            assert np.array_equal(ga[k], gc[k]), k
+        else:
+            assert np.array_equal(ga[k], gb[k]), k
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-12 * max(1.0, np.max(np.abs(gb[k]))), k
+    # what the host sees between the sub-steps is the half-step field, whichever way it was solved
+    for e in (a, b):
+        e.interaction_push_particle(1)
+        e.interaction_collect_charge()
+    assert np.array_equal(a.get_field(chargeden=False)["electric"], fa["electric"])    # solve_field not yet called
+    for e in (a, b):
+        e.field_solve_electric()
+    ha, hb = a.get_field(chargeden=False), b.get_field(chargeden=False)
+    for k in ("electric", "mode_re", "mode_im"):
+        assert relerr(ha[k], hb[k]) < 1e-12, k
+    assert relerr(ha["electric"], fa["electric"]) > 1e-3         # (it IS another field)
+    for e in (a, b):
+        e.interaction_push_particle(2)
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+    assert relerr(a.get_field()["electric"], b.get_field()["electric"]) < 1e-12
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-12 * max(1.0, np.max(np.abs(gb[k]))), k
+    # a realistic marker count against the oracle
+    kw = dict(nparticle_max=N, nx=96)
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    monkeypatch.setenv("PIC1DP_CALL_PAIR", "1")
+    e = engine(amd, monkeypatch, True, kind, **kw)
+    for it in range(40):
+        sim.step(1)
+        calls(e, 1)
+        if it % 7 == 3:        # looked at only now and then: the fast path runs in between
+            assert abs(e.field_energy() / sim.field_energy() - 1.0) < 1e-10, it
+    assert abs(e.field_energy() / sim.field_energy() - 1.0) < 1e-10
+    assert e.kernel_stats(11)[1] == (39 if kind == 2 else 0)

@@ -412,9 +412,14 @@ def test_fortran_host_with_rccl(amd, tmp_path, fused):
             res[how] = (output.OutputData(str(wd / "pic1dp.out")), m, open(str(wd / "pic1dp.out"), "rb").read())
         (da, ma, ra), (db, mb, rb) = res["plain"], res["rccl"]
         assert da.ntime == 3 and db.ntime == 3
-        if exact:
+        if exact and fused == "3":
             assert np.array_equal(ma, mb)                       # x, v, p, w of every marker
             assert ra == rb                                     # and pic1dp.out byte for byte
+        elif exact:
+            # (through the call sites the plain one-rank run takes its half-step field from the pair solve, the RCCL run
+            # from the kept mode's content of the predicted charge density solved again: the same field to rounding)
+            assert np.max(np.abs(ma - mb)) < 1e-12 * np.max(np.abs(ma))
+            assert np.max(np.abs(da.scalars[:, 1] / db.scalars[:, 1] - 1.0)) < 1e-12
         else:
             assert np.max(np.abs(da.scalars[:, 1] / db.scalars[:, 1] - 1.0)) < 1e-10
             assert np.max(np.abs(da.scalars[:, 2:] / db.scalars[:, 2:] - 1.0)) < 1e-9
