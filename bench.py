@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--nx", type=int, default=0)
     ap.add_argument("--strong-total", type=int, default=10**8, help="markers of the strong_1e8_total object")
     ap.add_argument("--no-strong", action="store_true")
+    ap.add_argument("--rehearse-with-host", action="store_true",
+                    help="(tests) --allreduce auto also rehearses the host-staged sum, so that the choice by rehearsal "
+                         "can run where RCCL cannot (ranks sharing one GPU)")
     ap.add_argument("--allreduce", default="auto", choices=["auto", "rccl", "p2p", "host"],
                     help="charge sum over GPUs: RCCL all-reduce, the one-hop exchange, or host-staged gloo "
                          "(testing); auto = RCCL for the headline, the exchange measured beside it")
@@ -219,6 +222,8 @@ class Job:
                         self.p2p_why = "the exchange area of some rank is plain device memory (memkind 3)"
                 self.have_p2p = self.p2p_why is None
             want = a.allreduce
+            if want == "auto" and getattr(a, "auto_choice", None):      # main()'s rehearsal has timed the kinds
+                want = a.auto_choice
             if want == "auto":
                 want = "rccl" if self.have_rccl else ("p2p" if self.have_p2p else "host")
             if want == "rccl" and not self.have_rccl:
@@ -411,6 +416,57 @@ def launch_ranks(n, cmd=None):
     return min(worst, 255)
 
 
+def rehearse_charge_sums(a, phys, rank, world, device, dist, shared, steps=60):
+    """time a short run of the strong-scaling share with every charge sum that comes up; every rank returns the same
+    dict: ms per step per kind (max over ranks), what failed, and the kind chosen (None: leave it to availability)"""
+    import torch
+    from pic1dp_amd import parallel
+    out = {"markers_total": int(a.strong_total), "steps": steps, "ms_per_step": {}, "failed": {}, "chosen": None}
+    n_tot = max(int(a.strong_total), 2 * world)
+    rj = Job(a, "rehearsal", pic1dp_amd.make_input(nparticle_max=n_tot, **phys), rank, world, device, dist, shared)
+    kinds = [k for k, ok in (("rccl", rj.have_rccl), ("p2p", rj.have_p2p)) if ok]
+    if a.rehearse_with_host:
+        kinds.append("host")
+    out["unavailable"] = {"rccl": rj.rccl_why, "one-hop exchange": rj.p2p_why}
+    if len(kinds) < 2:
+        rj.eng.close()
+        out["why"] = "fewer than two kinds of charge sum came up: nothing to choose between"
+        return out
+    rj.init_field()
+    for kind in kinds:
+        rj.use(kind)
+        dist.barrier()
+        err = None
+        try:
+            rj.run(15)
+            rj.eng.sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            rj.run(steps)
+            rj.eng.sync()
+            el = time.perf_counter() - t0
+        except pic1dp_amd.Pic1dpError as e:
+            err, el = str(e), 0.0
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if not parallel.agree(dist, err is None):
+            out["failed"][kind] = err or "failed on another rank"
+            break                      # (an engine whose exchange failed cannot go on: the kinds not yet timed stay untimed)
+        out["ms_per_step"][kind] = float(t.item()) / steps * 1e3
+    try:
+        rj.eng.close()
+    except pic1dp_amd.Pic1dpError:
+        pass
+    timed_kinds = {k: v for k, v in out["ms_per_step"].items() if k != "host" or a.rehearse_with_host}
+    if timed_kinds:
+        out["chosen"] = min(timed_kinds, key=timed_kinds.get)
+        out["why"] = ("the shortest step of the rehearsal (%s)"
+                      % ", ".join("%s %.4f ms" % (k, v) for k, v in sorted(timed_kinds.items(), key=lambda kv: kv[1])))
+    else:
+        out["why"] = "no kind completed the rehearsal"
+    return out
+
+
 def main():
     if os.environ.get("PIC1DP_BENCH_TRACE"):     # debugging aid: dump all stacks after N seconds and exit
         import faulthandler
@@ -465,6 +521,18 @@ def main():
     if shared and a.allreduce == "rccl":
         sys.exit("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank; --allreduce auto, p2p or "
                  "host rehearses the control flow on fewer)" % (world, ndev))
+
+    # --allreduce auto on several ranks: which charge sum?  Not by preference but by REHEARSAL: a
+    # scratch job of the strong-scaling share's size (10^8 markers in total over the ranks: where a step is short enough
+    # for the sum to matter) is stepped with every kind that came up -- RCCL's all-reduce behind the marker launch's
+    # packing tail, and the one-hop exchange posted from that tail --, max over ranks, and the shorter step wins.  On a
+    # scratch job because an exchange that fails (a peer that never delivers: bounded wait, PIC1DP_ERR_COMM) leaves
+    # an engine that cannot go on; the headline job is created afterwards with the kind chosen.
+    a.auto_choice = None
+    rehearsal = None
+    if world > 1 and a.allreduce == "auto":
+        rehearsal = rehearse_charge_sums(a, phys, rank, world, device, dist, shared)
+        a.auto_choice = rehearsal.get("chosen")
 
     # every rank owns one reference block of the global array (PETSC_DECIDE split)
     job = Job(a, "headline", pic1dp_amd.make_input(nparticle_max=total, **phys), rank, world, device, dist, shared)
@@ -779,6 +847,7 @@ def main():
                                "sub-step" % world,
                 "path": path, "allreduce": headline_kind, "rccl_ranks": world if headline_kind == "rccl" else 0,
                 "charge_sum_not_used_because": {"rccl": job.rccl_why, "one-hop exchange": job.p2p_why} if world > 1 else None,
+                "charge_sum_chosen_by": rehearsal,
                 "exchange_memkind": {0: None, 1: "fine-grained", 2: "uncached", 3: "plain"}[job.xchg_memkind],
                 "marker_layout": "x, v, w, p interleaved in 32 KiB tiles in one slab per species",
                 "timed_blocks": repeats,

@@ -169,3 +169,25 @@ def test_bench_two_ranks_share_the_gpu(amd, config, particles, allreduce, self_l
         assert s["particles_total"] == strong_total and s["same_run_as_headline"] is False and s["value"] > 0
         e = virtual_rank_energy(amd, dict(nparticle_max=strong_total, **phys), 2, nsteps)
         assert abs(s["field_energy_end"] / e - 1.0) < 1e-10
+
+
+def test_bench_auto_chooses_the_charge_sum_by_rehearsal(amd):
+    """with several kinds of charge sum up, `--allreduce auto` steps a scratch job of the
+    strong-scaling share's size with each and takes the one whose step is shorter (max over ranks), saying so in
+    config.charge_sum_chosen_by.  On a multi-GPU node the kinds are RCCL and the one-hop exchange; two ranks sharing this
+    box's GPU cannot run RCCL, so the test lets the host-staged sum stand in as the second kind (--rehearse-with-host):
+    the same code path, the same collective decisions."""
+    d = run_bench(["--gpus", "2", "--config", "c3", "--particles", "600000", "--nx", "128", "--steps", "4", "--warmup", "2",
+                   "--strong-total", "800000", "--allreduce", "auto", "--rehearse-with-host", "--no-cpu-baseline"],
+                  nproc=2, self_launch=True)
+    r = d["config"]["charge_sum_chosen_by"]
+    assert set(r["ms_per_step"]) == {"p2p", "host"} and not r["failed"]
+    assert all(v > 0 for v in r["ms_per_step"].values())
+    assert r["chosen"] == min(r["ms_per_step"], key=r["ms_per_step"].get) and r["chosen"] in r["why"]
+    assert d["config"]["allreduce"].startswith("one-hop" if r["chosen"] == "p2p" else "host-staged")
+    assert r["markers_total"] == 800000
+    # and without a second kind there is nothing to rehearse: the one that came up is taken
+    d = run_bench(["--gpus", "2", "--config", "c3", "--particles", "600000", "--nx", "128", "--steps", "4", "--warmup", "2",
+                   "--strong-total", "800000", "--allreduce", "auto", "--no-cpu-baseline"], nproc=2, self_launch=True)
+    r = d["config"]["charge_sum_chosen_by"]
+    assert r["chosen"] is None and "nothing to choose" in r["why"] and d["config"]["allreduce"].startswith("one-hop")
