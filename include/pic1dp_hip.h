@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PIC1DP_ABI_VERSION 4
+#define PIC1DP_ABI_VERSION 5
 #define PIC1DP_MAX_SPECIES 8
 #define PIC1DP_MAX_MODES 4096 /* up to the full spectrum nx/2 of the largest grid */
 #define PIC1DP_MAX_INIT_MODES 16

@@ -15,7 +15,7 @@ MAX_MODES = 4096
 MAX_INIT_MODES = 16
 COMM_ID_BYTES = 128
 XCHG_HANDLE_BYTES = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_OPT = 32
 
 ERR_NAMES = {1: "ARG", 2: "HIP", 3: "NODEVICE", 4: "STATE", 5: "COMM", 6: "RNG", 7: "NOMEM"}

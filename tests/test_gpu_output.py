@@ -425,3 +425,49 @@ def test_fortran_host_with_rccl(amd, tmp_path, fused):
             assert np.max(np.abs(da.scalars[:, 2:] / db.scalars[:, 2:] - 1.0)) < 1e-9
             assert relerr(da.electric[-1], db.electric[-1]) < 1e-10
             assert np.max(np.abs(ma - mb)) < 1e-9
+
+
+def test_fortran_host_default_workload_slice(oracle_mod, amd, tmp_path):
+    """BASELINE configs[0]'s workload -- the reference's default input, src/pic1dp_input.F90:35,109,113,
+    128,250: 6.4e6 markers, nx 192, dt 0.05, output_all every 0.5 -- through the shipped Fortran host as the reference
+    driver runs it (src/pic1dp.F90:78-109; pic1dp.out layout src/pic1dp_output.F90:74-92,173-186), its first 1 000 steps
+    (the whole 10 000 with 1 001 records: tools/default_run.py, profiles/r05/default_run_10000_steps.log): 101 records, 44 +
+    101 x 103 000 bytes, through the three call sites and as whole steps batched up to each output; the two against each
+    other over the whole slice, the first 50 steps against the oracle, and the growth of the linear phase under way."""
+    exe = fortran_host_exe()
+    from pic1dp_amd import output
+    inp = amd.make_input(time_max=50.0)
+    outs = {}
+    for fused in ("0", "3"):
+        wd = tmp_path / ("fused" + fused)
+        wd.mkdir()
+        env = dict(os.environ, PIC1DP_TIME_MAX="50.0", PIC1DP_FUSED=fused, PIC1DP_HOST_PROFILE="1")
+        for k in ("PIC1DP_NPARTICLE", "PIC1DP_NX"):
+            env.pop(k, None)
+        r = subprocess.run([exe], cwd=str(wd), env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert r.stdout.count("%") == 101 and "101 records)" in r.stdout
+        path = str(wd / "pic1dp.out")
+        assert os.path.getsize(path) == output.header_bytes(inp) + 101 * output.record_bytes(inp) == 44 + 101 * 103000
+        outs[fused] = output.OutputData(path)
+        os.remove(path)
+    a, b = outs["0"], outs["3"]
+    assert a.ntime == b.ntime == 101 and a.nx == 192
+    assert list(a.scalars[:, 0]) == accumulated_times(0.05, list(range(0, 1001, 10)))
+    assert np.max(np.abs(a.scalars[:, 1] / b.scalars[:, 1] - 1.0)) < 1e-10          # int E^2 dx, t <= 50: the linear phase
+    assert np.max(np.abs(a.scalars[:, 2:4] / b.scalars[:, 2:4] - 1.0)) < 1e-10
+    sim = oracle_mod.Sim(oracle_mod.make_input(time_max=50.0))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    want = [sim.output_scalars()]
+    for _ in range(5):
+        sim.step(10)
+        want.append(sim.output_scalars())
+    want = np.array(want)
+    for d in (a, b):
+        assert np.max(np.abs(d.scalars[:6, 1] / want[:, 1] - 1.0)) < 1e-10
+        assert np.max(np.abs(d.scalars[:6, 2:4] / want[:, 2:4] - 1.0)) < 1e-9
+    assert relerr(a.electric[5], sim.get_field()[0]) < 1e-10
+    g2 = a.growthrate_energy_fit(15.0, 45.0)
+    assert abs(g2 / 0.16766 - 1.0) < 0.03, g2

@@ -62,12 +62,17 @@ def one_process(n, nx, npe, steps, comm, tail):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--particles", type=float, default=1.25e7)
+    ap.add_argument("--whole", type=float, default=1e8)
     ap.add_argument("--nx", type=int, default=1024)
     ap.add_argument("--npe", type=int, default=8)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--no-two-ranks", action="store_true")
     a = ap.parse_args()
     n = int(a.particles)
+    # the denominator of the strong-scaling figure: the whole 1e8 markers on ONE GPU, same box, same run
+    whole, _, _, _ = one_process(int(a.whole), a.nx, a.npe, 100, False, True)
+    print("0. the whole %d markers on this one GPU (npe-%d order, one launch per step where the rule allows): %s ms per step"
+          % (int(a.whole), a.npe, " ".join("%.4f" % b for b in whole)), flush=True)
     print("A. one process, %d markers, nx %d, %d-rank summation order; ms per step: five blocks of %d steps, sorted"
           % (n, a.nx, a.npe, a.steps), flush=True)
     rows = []
@@ -81,6 +86,17 @@ def main():
         print("   %-62s %s  | device us per step: marker %.1f  pack %.1f  all-reduce %.1f  field %.1f | tails %d | int E^2 dx %.15e"
               % (name, " ".join("%.4f" % b for b in blocks), attr["marker_us"], attr["pack_us"], attr["allreduce_us"],
                  attr["field_us"], tails, energy), flush=True)
+    t1 = whole[len(whole) // 2]
+    print("   strong-scaling budget 1 -> 8 GPUs from these medians (whole / share):", flush=True)
+    for name, blocks, attr in rows:
+        ts = blocks[len(blocks) // 2]
+        extra = ""
+        if "RCCL" in name:
+            ar = attr["allreduce_us"]
+            # >= 6x needs share <= whole / 6: how long may the 8-GPU all-reduce take beyond the one-rank one measured here?
+            room = (t1 / 6.0 - ts) * 1e3
+            extra = "  | 6x allows the all-reduce %.1f us more than the one-rank communicator's %.1f us" % (room, ar)
+        print("      %-62s %.4f / %.4f = %.2fx%s" % (name, t1, ts, t1 / ts, extra), flush=True)
     if a.no_two_ranks:
         return
     print("B. two processes share the GPU, one-hop exchange (bench.py --gpus 2 --allreduce p2p), %d markers each" % n, flush=True)
