@@ -672,6 +672,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
                                  : c->d_pred + static_cast<size_t>(s) * (1 + 2 * c->in.nmode) * c->in.nx;
       a.pred_nm = c->in.nmode;
       a.pred_private = priv ? 1 : 0;
+      a.dyn_tail = c->pred_kind == 2 ? c->dyn_tail : 0;  // (k_step_one<PRIV>, k_step_sums)
       if (c->pred_kind == 2) {
         a.eh_re = c->eh_modes == 2 ? c->d_mode_h : c->fa.mode_re;
         a.eh_im = c->eh_modes == 2 ? c->d_mode_h + 1 : c->fa.mode_im;

@@ -238,6 +238,7 @@ struct StepArgs {
   const double *eh_re, *eh_im;
   FusedSolve fused;  // pred_kind 2 only: the prologue solves the previous step's field (E0, Eh, eh_re / eh_im unused)
   StepTail tail;     // pred_kind 2 only, several ranks: the last workgroup packs / posts this rank's charge (mode 0: no)
+  int dyn_tail;      // k_step_one<PRIV>, k_step_sums: sixteenths of a workgroup's chunks that its waves draw from an LDS counter (0: all dealt)
 };
 constexpr int PRED_MAX_MODES = 4;  // kept modes k_step_one's prediction tiles are instantiated for (1 .. 4)
 // pred_kind 2: the six sums (padded to 8) are kept in this many copies -- workgroup b of the marker kernel adds into

@@ -563,8 +563,10 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     sE0[nx] = a.E0[0];
     sEh[nx] = a.Eh[0];
   }
+  unsigned *sDraw = reinterpret_cast<unsigned *>(sP + 6 * PRIV_THREADS);  // PRIV: the chunk counter of the drawn tail
   if constexpr (PRIV) {
     for (int k = 0; k < 6; ++k) sP[k * PRIV_THREADS + threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) *sDraw = 0u;
   } else {
     for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
   }
@@ -582,7 +584,35 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   double2 *t2 = reinterpret_cast<double2 *>(a.t2);
-  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+  // The workgroup's pairs: row k = pairs (blockIdx + k gridDim) blockDim ..., dealt to its threads (static grid stride).
+  // Tuning (PIC1DP_DYN_TAIL): the last dyn_tail / 16 of the rows are not dealt but DRAWN -- every wave
+  // takes the next 64-pair chunk of them from a counter in the LDS (one ds_add_rtn_u32 per chunk, no device-scope traffic),
+  // so that the waves that run ahead take more and the workgroup meets its final barrier together.
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  int dealt = first < npair ? static_cast<int>((npair - first + stride - 1) / stride) : 0;  // rows of this workgroup
+  int drawn_total = 0;
+  if constexpr (PRIV) {
+    if (a.dyn_tail > 0) {
+      const int drawn_rows = (dealt * a.dyn_tail) >> 4;
+      dealt -= drawn_rows;
+      drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
+    }
+  }
+  int64_t j = first + threadIdx.x;
+  for (int k = 0;; ++k, j += stride) {
+    if constexpr (PRIV) {
+      if (k >= dealt) {
+        int c = 0;
+        if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(sDraw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= drawn_total) break;
+        const int waves = static_cast<int>(blockDim.x >> 6);
+        j = first + static_cast<int64_t>(dealt + c / waves) * stride + (c % waves) * 64 + (threadIdx.x & 63);
+      }
+    } else {
+      if (k >= dealt) break;
+    }
+    if (j >= npair) continue;
     const int64_t o = tidx2(j);
     const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);
@@ -748,6 +778,8 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   double *sB = sA + ne;
   double *sR0 = sB + ne;
   double *sScr = sR0 + ((nx * a.g.rcopies + 2) & ~1);  // [6][16] reduction scratch
+  unsigned *sDraw = reinterpret_cast<unsigned *>(sScr);  // the chunk counter of the drawn tail: the head of the scratch,
+                                                         // which the reductions need only behind the loop's barrier
   if constexpr (!FUSED) {
     for (int i = threadIdx.x; i < nx; i += blockDim.x) {
       sE0[i] = a.E0[i];
@@ -770,6 +802,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
     im_h = *a.eh_im;
   }
   zero_rho(sR0, a.g);
+  if (threadIdx.x == 0) *sDraw = 0u;
   __syncthreads();
   STAMP(a, 1);
   const ModeField sEh{sA, sB, re_h, im_h};
@@ -786,7 +819,27 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   double2 *t2 = reinterpret_cast<double2 *>(a.t2);
-  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+  // the workgroup's rows of pairs: the first ones dealt to its threads, the last dyn_tail / 16 drawn by its waves from the
+  // LDS counter (k_step_one has the same loop and the reason)
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  int dealt = first < npair ? static_cast<int>((npair - first + stride - 1) / stride) : 0;
+  int drawn_total = 0;
+  if (a.dyn_tail > 0) {
+    const int drawn_rows = (dealt * a.dyn_tail) >> 4;
+    dealt -= drawn_rows;
+    drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
+  }
+  int64_t j = first + threadIdx.x;
+  for (int k = 0;; ++k, j += stride) {
+    if (k >= dealt) {
+      int c = 0;
+      if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(sDraw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      c = __builtin_amdgcn_readfirstlane(c);
+      if (c >= drawn_total) break;
+      const int waves = static_cast<int>(blockDim.x >> 6);
+      j = first + static_cast<int64_t>(dealt + c / waves) * stride + (c % waves) * 64 + (threadIdx.x & 63);
+    }
+    if (j >= npair) continue;
     const int64_t o = tidx2(j);
     const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0), T = make_double2(0.0, 0.0);

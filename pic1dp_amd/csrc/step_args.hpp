@@ -28,6 +28,7 @@ struct StepArgsDev {
   double snx, pred_k;           // k_step_one's prediction: nx / lx, and dt/2 Z/m
   FusedSolve fused;             // kernels.hpp: the prologue solves the previous step's field
   StepTail tail;                // kernels.hpp: the last workgroup packs / posts this rank's charge
+  int dyn_tail;                 // k_step_one<PRIV>: sixteenths of a workgroup's chunks drawn from an LDS counter
 #ifdef PIC1DP_TUNE_STAMPS  // tuning build (tools/stamp_probe.sh): [gridDim][8] wall-clock stamps of the phases of a workgroup
   unsigned long long *stamps;
 #endif

@@ -34,6 +34,7 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.pred_k = a.dt_half * a.s.Z / a.s.m;
   d.fused = a.fused;
   d.tail = a.tail;
+  d.dyn_tail = a.dyn_tail;
   // full-f evaluates no f0 derivative: one instantiation (in the DIST 0 unit) serves every distribution
   if (!a.deltaf) return launch_step_dist<0>(d, a.deltaf, a.linear, full, lc, st);
   switch (a.iptcldist) {

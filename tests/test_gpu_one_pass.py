@@ -717,3 +717,30 @@ def test_call_sites_two_launches_per_step(oracle_mod, amd, monkeypatch, kind):
             assert abs(e.field_energy() / sim.field_energy() - 1.0) < 1e-10, it
     assert abs(e.field_energy() / sim.field_energy() - 1.0) < 1e-10
     assert e.kernel_stats(11)[1] == (39 if kind == 2 else 0)
+
+
+@pytest.mark.parametrize("drawn", ["4", "16"])
+def test_chunks_drawn_from_the_lds_counter(oracle_mod, amd, monkeypatch, drawn):
+    """tuning knob PIC1DP_DYN_TAIL: the last n/16 of a workgroup's 64-pair chunks are drawn by its
+    waves from an LDS counter instead of dealt -- every pair exactly once whoever takes it: the run against the oracle
+    (1e-10 at every step) and the markers against the default engine's (the same arithmetic per marker: only the order of
+    the charge atomics moves)"""
+    kw = dict(nparticle_max=1_500_001, nx=512)
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    eo = []
+    for _ in range(25):
+        sim.step(1)
+        eo.append(sim.field_energy())
+    monkeypatch.setenv("PIC1DP_DYN_TAIL", drawn)
+    a = engine(amd, monkeypatch, True, 2, **kw)
+    monkeypatch.setenv("PIC1DP_DYN_TAIL", "0")
+    b = engine(amd, monkeypatch, True, 2, **kw)
+    a.step(25)
+    b.step(25)
+    assert np.max(np.abs(a.energy_history() / np.array(eo) - 1.0)) < 1e-10
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
