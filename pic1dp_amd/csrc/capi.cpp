@@ -599,6 +599,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
                     c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred_all, c->d_cd_h, c->d_mode_h, c->d_Ehn, c->d_pack};
   for (double *b : bufs) (void)hipFree(b);
   (void)hipFree(c->d_ticket);
+  (void)hipHostFree(c->h_pin);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -887,13 +888,21 @@ int pic1dp_hip_get_field(pic1dp_ctx *c, double *E, double *cd, double *re, doubl
   if (int rc = materialize_cd(c)) return rc;
   if (cd && c->cd_kept_mode_only)
     if (int rc = rebuild_half_step_chargeden(c)) return rc;
-  HIP_TRY(hipStreamSynchronize(c->st));
+  // the four small vectors through the pinned staging, on the engine's stream, ONE wait (four synchronous copies from
+  // pageable memory cost ~55 us: tools/output_host_cost.py)
   const size_t nx = c->in.nx, nm = c->in.nmode;
+  double *h = nullptr;
+  if (int rc = pinned(c, 2 * nx + 2 * nm, &h)) return rc;
+  if (E) HIP_TRY(hipMemcpyAsync(h, c->d_E, sizeof(double) * nx, hipMemcpyDeviceToHost, c->st));
+  if (cd) HIP_TRY(hipMemcpyAsync(h + nx, c->d_chargeden, sizeof(double) * nx, hipMemcpyDeviceToHost, c->st));
+  if (re) HIP_TRY(hipMemcpyAsync(h + 2 * nx, c->d_mode_re, sizeof(double) * nm, hipMemcpyDeviceToHost, c->st));
+  if (im) HIP_TRY(hipMemcpyAsync(h + 2 * nx + nm, c->d_mode_im, sizeof(double) * nm, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(hipStreamSynchronize(c->st));
   if (int rc = xchg_check(c)) return rc;
-  if (E) HIP_TRY(hipMemcpy(E, c->d_E, sizeof(double) * nx, hipMemcpyDeviceToHost));
-  if (cd) HIP_TRY(hipMemcpy(cd, c->d_chargeden, sizeof(double) * nx, hipMemcpyDeviceToHost));
-  if (re) HIP_TRY(hipMemcpy(re, c->d_mode_re, sizeof(double) * nm, hipMemcpyDeviceToHost));
-  if (im) HIP_TRY(hipMemcpy(im, c->d_mode_im, sizeof(double) * nm, hipMemcpyDeviceToHost));
+  if (E) std::memcpy(E, h, sizeof(double) * nx);
+  if (cd) std::memcpy(cd, h + nx, sizeof(double) * nx);
+  if (re) std::memcpy(re, h + 2 * nx, sizeof(double) * nm);
+  if (im) std::memcpy(im, h + 2 * nx + nm, sizeof(double) * nm);
   return 0;
 }
 
@@ -932,9 +941,12 @@ int pic1dp_hip_field_energy(pic1dp_ctx *c, double *energy) {
   if (int rc = settle_field_view(c)) return rc;
   double *slot = c->d_scratch + kEnergyBlocks * 3;
   HIP_TRY(launch_field_energy(c->d_E, c->in.nx, c->in.lx, static_cast<double>(c->in.nx), slot, c->st));
+  double *h = nullptr;
+  if (int rc = pinned(c, 1, &h)) return rc;
+  HIP_TRY(hipMemcpyAsync(h, slot, sizeof(double), hipMemcpyDeviceToHost, c->st));
   HIP_TRY(hipStreamSynchronize(c->st));
   if (int rc = xchg_check(c)) return rc;
-  HIP_TRY(hipMemcpy(energy, slot, sizeof(double), hipMemcpyDeviceToHost));
+  *energy = h[0];
   return 0;
 }
 

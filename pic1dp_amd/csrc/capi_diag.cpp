@@ -13,6 +13,20 @@ size_t dist_len(const pic1dp_input &in) {
 
 int diag_max_blocks(const pic1dp_ctx *c) { return 2 * c->num_cu; }
 
+int pinned(pic1dp_ctx *c, size_t ndoubles, double **out) {
+  if (ndoubles > c->h_pin_doubles) {
+    HIP_TRY(hipStreamSynchronize(c->st));  // (nothing in flight into the old buffer)
+    (void)hipHostFree(c->h_pin);
+    c->h_pin = nullptr;
+    c->h_pin_doubles = 0;
+    const size_t want = ndoubles + ndoubles / 4 + 64;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_pin), sizeof(double) * want, hipHostMallocDefault));
+    c->h_pin_doubles = want;
+  }
+  *out = c->h_pin;
+  return 0;
+}
+
 // the histogram geometry with its constant divisors vouched for, formed once per context
 const DistGeom &dist_geom(pic1dp_ctx *c) {
   if (!c->dist_geom_ready) {
@@ -62,25 +76,24 @@ int ensure_diag(pic1dp_ctx *c, int isp) {
   // collect: partial kinetic sums of the pass (k_ptcldist, or k_step_full's DIAG variant), workgroup order
   double *sums = &c->diag_sums[3 * static_cast<size_t>(isp)];
   sums[0] = sums[1] = sums[2] = 0.0;
-  std::vector<double> part(3 * static_cast<size_t>(std::max(diag_max_blocks(c), kEnergyBlocks)));
+  // the pass's partial sums and those of the tail slots (the reference sums the whole local vector, VecSum; slots beyond
+  // np live in set 0) through the pinned staging: both transfers enqueued, ONE wait
   const int blocks = c->diag_blocks[isp];
-  if (blocks > 0) {
-    HIP_TRY(hipStreamSynchronize(c->st));
-    HIP_TRY(hipMemcpy(part.data(), part_dev, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost));
-    for (int b = 0; b < blocks; ++b)
-      for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
-  }
-  // the reference sums the whole local vector (VecSum); slots beyond np live in set 0
   const int64_t ntail = S.nalloc - S.np;
-  if (ntail > 0) {
-    const int tb = static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256));
+  const int tb = ntail > 0 ? static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256)) : 0;
+  double *part = nullptr;
+  if (int rc = pinned(c, 3 * static_cast<size_t>(blocks + tb) + 8, &part)) return rc;
+  if (blocks > 0) HIP_TRY(hipMemcpyAsync(part, part_dev, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost, c->st));
+  if (tb > 0) {
     HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, ntail, c->d_scratch, tb,
                                c->st));
-    HIP_TRY(hipStreamSynchronize(c->st));
-    HIP_TRY(hipMemcpy(part.data(), c->d_scratch, sizeof(double) * tb * 3, hipMemcpyDeviceToHost));
-    for (int b = 0; b < tb; ++b)
-      for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
+    HIP_TRY(hipMemcpyAsync(part + 3 * blocks, c->d_scratch, sizeof(double) * tb * 3, hipMemcpyDeviceToHost, c->st));
   }
+  if (blocks + tb > 0) HIP_TRY(hipStreamSynchronize(c->st));
+  for (int b = 0; b < blocks; ++b)
+    for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
+  for (int b = 0; b < tb; ++b)
+    for (int k = 0; k < 3; ++k) sums[k] += part[3 * blocks + b * 3 + k];
   c->diag_pending[isp] = 0;
   return 0;
 }
@@ -213,10 +226,11 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *c, int32_t isp, int32_t finish, double *mark
   } else if (finish && c->lay.nranks > 1) {
     return fail(PIC1DP_ERR_STATE, "nranks > 1 but no communicator: take finish = 0 and reduce the local sums on the host");
   }
-  std::vector<double> h(ntot);
+  double *h = nullptr;
+  if (int rc = pinned(c, ntot, &h)) return rc;
+  HIP_TRY(hipMemcpyAsync(h, hist, sizeof(double) * ntot, hipMemcpyDeviceToHost, c->st));
   HIP_TRY(hipStreamSynchronize(c->st));
-  HIP_TRY(hipMemcpy(h.data(), hist, sizeof(double) * ntot, hipMemcpyDeviceToHost));
-  double *mxv = h.data(), *txv = mxv + nxv, *pxv = txv + nxv, *mv = pxv + nxv, *tv = mv + nvo, *pv = tv + nvo;
+  double *mxv = h, *txv = mxv + nxv, *pxv = txv + nxv, *mv = pxv + nxv, *tv = mv + nvo, *pv = tv + nvo;
   if (finish) finish_ptcldist(in, isp, mxv, txv, pxv, mv, tv, pv);
   auto give = [&](double *dst, const double *src, size_t n) {
     if (dst) std::memcpy(dst, src, sizeof(double) * n);

@@ -186,6 +186,8 @@ struct pic1dp_ctx {
   std::vector<char> diag_pending;          // [nspecies] a pass ran, its partial sums are still on the device
   std::vector<int> diag_blocks;            // [nspecies] workgroups of that pass
   int fuse_output = 0;                     // take the diagnostics inside k_step_full on steps output_all follows
+  double *h_pin = nullptr;                 // pinned host staging of the small device-to-host transfers (output_all's calls:
+  size_t h_pin_doubles = 0;                // pageable copies cost a synchronous call each, ~20 us; grow-only, capi_diag.cpp pinned)
   DistGeom dist_geom_v{};                  // output_ptcldist's histogram geometry (capi_diag.cpp dist_geom)
   bool dist_geom_ready = false;
   int64_t opt_pcie_bytes = 0;              // bytes marker optimisation events have moved between host and device
@@ -306,6 +308,7 @@ bool optimize_due_any(const pic1dp_ctx *c);
 int diag_buffers(pic1dp_ctx *c);
 int diag_max_blocks(const pic1dp_ctx *c);
 const DistGeom &dist_geom(pic1dp_ctx *c);
+int pinned(pic1dp_ctx *c, size_t ndoubles, double **out);   // the context's pinned staging with room for ndoubles
 size_t dist_len(const pic1dp_input &in);
 
 }  // namespace pic1dp_host
