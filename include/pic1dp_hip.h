@@ -497,7 +497,11 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
  * separate packing launch in front of the all-reduce; PIC1DP_TAIL=0 keeps that launch), *ms = 0;
  * which = 11: *launches = pic1dp_hip_solve_field calls of a first sub-step that launched nothing
  * because the solve_field before them had solved both fields in one launch (one rank, the three
- * call sites: two launches per time step; PIC1DP_CALL_PAIR=0: three), *ms = 0 */
+ * call sites: two launches per time step; PIC1DP_CALL_PAIR=0: three), *ms = 0;
+ * which = 12: *launches = diagnostics passes (k_ptcldist) whose (x, v) histograms were summed as
+ * 64-bit fixed-point numbers in the LDS (1.9x the atomic rate of double sums; scaled by the
+ * species' max |p|, max |w| of the pass before; PIC1DP_DIAG_FX=0: always doubles), *ms = how many
+ * of them met a marker beyond those bounds and were repeated with double sums */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

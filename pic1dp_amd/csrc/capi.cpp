@@ -4,6 +4,8 @@
 // One context = one process = one GPU = one HIP stream.  Every compute entry
 // point only enqueues kernels (and at most one RCCL all-reduce) on that stream;
 // nothing in the time loop synchronises with the host.
+#include <algorithm>
+
 #include "ctx.hpp"
 
 namespace pic1dp_host {
@@ -408,6 +410,8 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   if (const char *e = std::getenv("PIC1DP_FUSE_SOLVE")) c->fuse_solve = std::max(0, std::min(2, std::atoi(e)));
   if (const char *e = std::getenv("PIC1DP_TAIL")) c->tail_on = std::atoi(e) != 0;
   if (const char *e = std::getenv("PIC1DP_CALL_PAIR")) c->call_pair = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PIC1DP_DIAG_FX")) c->diag_fx = std::atoi(e) != 0;
+  if (const char *e = std::getenv("PIC1DP_DIAG_FX_MARGIN")) c->diag_fx_margin_w = std::atof(e);
   HIP_TRY_C(hipMalloc(reinterpret_cast<void **>(&c->d_ticket), 64));
   HIP_TRY_C(hipMemsetAsync(c->d_ticket, 0, 64, c->st));
   for (int s = 0; s < ns; ++s) {
@@ -714,6 +718,8 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   (void)hipHostFree(stage);
   if (rc) return rc;
   c->rng_ready = true;
+  std::fill(c->diag_max_p.begin(), c->diag_max_p.end(), 0.0);  // (new markers: the fixed-point diagnostics' bounds are void)
+  std::fill(c->diag_max_w.begin(), c->diag_max_w.end(), 0.0);
   c->cur = 0;
   c->loaded = true;
   c->itime = 0;
@@ -755,6 +761,8 @@ int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, con
   S.np = np;
   if (c->nblk == 1) c->blk_np[isp][0] = np;
   c->rng_ready = false;  // the host's loader owns the random stream now
+  std::fill(c->diag_max_p.begin(), c->diag_max_p.end(), 0.0);
+  std::fill(c->diag_max_w.begin(), c->diag_max_w.end(), 0.0);
   c->loaded = true;
   return 0;
 }
@@ -1041,7 +1049,12 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 11) return fail(PIC1DP_ERR_ARG, "which must be 0..11");
+  if (which < 0 || which > 12) return fail(PIC1DP_ERR_ARG, "which must be 0..12");
+  if (which == 12) {  // diagnostics passes with 64-bit fixed-point histogram sums; *ms: of them, repeated in doubles (overflow)
+    if (ms) *ms = static_cast<double>(c->diag_fx_repeats);
+    if (launches) *launches = c->diag_fx_passes;
+    return 0;
+  }
   if (which == 11) {  // call sites: solve_field calls of a half step that launched nothing (the pair solve before them had it)
     if (ms) *ms = 0.0;
     if (launches) *launches = c->call_pair_skips;

@@ -47,53 +47,94 @@ int diag_buffers(pic1dp_ctx *c) {
     c->diag_sums.assign(3 * static_cast<size_t>(ns), 0.0);
     c->diag_pending.assign(ns, 0);
     c->diag_blocks.assign(ns, 0);
+    c->diag_stride.assign(ns, 3);
+    c->diag_max_p.assign(ns, 0.0);
+    c->diag_max_w.assign(ns, 0.0);
   }
   if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * dist_len(in) * (ns + 1)));
-  if (!c->d_diag_part) HIP_TRY(hipMalloc(&c->d_diag_part, sizeof(double) * 3 * diag_max_blocks(c) * ns));
+  if (!c->d_diag_part) HIP_TRY(hipMalloc(&c->d_diag_part, sizeof(double) * 6 * diag_max_blocks(c) * ns));
+  return 0;
+}
+
+// the diagnostics' own pass over species isp (k_ptcldist) into its cached histograms; fixed: 64-bit fixed-point sums where
+// the species' max |p|, max |w| are known from the pass before (with a margin: p changes with load / upload / events only,
+// w grows by a few per cent between two records), else -- and whenever `fixed` is false -- double sums
+static int run_diag_pass(pic1dp_ctx *c, int isp, bool fixed, bool *was_fixed) {
+  const pic1dp_input &in = c->in;
+  Species &S = c->sp[isp];
+  const PSet &A = S.set[c->cur];
+  const size_t ntot = dist_len(in);
+  double *hist = c->d_dist + ntot * isp;
+  double *part_dev = c->d_diag_part + static_cast<size_t>(6) * diag_max_blocks(c) * isp;
+  HIP_TRY(hipMemsetAsync(hist, 0, sizeof(double) * ntot, c->st));
+  c->diag_blocks[isp] = 0;
+  c->diag_stride[isp] = 6;
+  *was_fixed = false;
+  if (S.np <= 0) return 0;
+  double bp = 0.0, bw = 0.0;
+  if (fixed && c->diag_fx && c->diag_max_p[isp] > 0.0 && (in.deltaf != 1 || c->diag_max_w[isp] > 0.0)) {
+    bp = 2.0 * c->diag_max_p[isp];
+    bw = c->diag_fx_margin_w * c->diag_max_w[isp];
+  }
+  c->diag_blocks[isp] = ptcldist_blocks(S.np, in.nx_opd, in.nv_opd, c->num_cu);
+  HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, dist_geom(c), in.deltaf == 1, bp, bw, hist, part_dev, c->num_cu, c->st,
+                          was_fixed));
+  c->diag_passes++;
+  if (*was_fixed) c->diag_fx_passes++;
   return 0;
 }
 
 int ensure_diag(pic1dp_ctx *c, int isp) {
   const pic1dp_input &in = c->in;
   if (int rc = diag_buffers(c)) return rc;
-  const size_t ntot = dist_len(in);
   Species &S = c->sp[isp];
-  double *part_dev = c->d_diag_part + static_cast<size_t>(3) * diag_max_blocks(c) * isp;
+  double *part_dev = c->d_diag_part + static_cast<size_t>(6) * diag_max_blocks(c) * isp;
+  bool was_fixed = false;
   if (c->diag_version[isp] != c->state_version) {  // no pass has seen these markers yet: run one
-    const PSet &A = S.set[c->cur];
-    double *hist = c->d_dist + ntot * isp;
-    HIP_TRY(hipMemsetAsync(hist, 0, sizeof(double) * ntot, c->st));
-    c->diag_blocks[isp] = 0;
-    if (S.np > 0) {
-      c->diag_blocks[isp] = ptcldist_blocks(S.np, in.nx_opd, in.nv_opd, c->num_cu);
-      HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, dist_geom(c), in.deltaf == 1, hist, part_dev, c->num_cu, c->st));
-      c->diag_passes++;
-    }
+    if (int rc = run_diag_pass(c, isp, true, &was_fixed)) return rc;
     c->diag_pending[isp] = 1;
     c->diag_version[isp] = c->state_version;
   }
   if (!c->diag_pending[isp]) return 0;
   // collect: partial kinetic sums of the pass (k_ptcldist, or k_step_full's DIAG variant), workgroup order
   double *sums = &c->diag_sums[3 * static_cast<size_t>(isp)];
-  sums[0] = sums[1] = sums[2] = 0.0;
   // the pass's partial sums and those of the tail slots (the reference sums the whole local vector, VecSum; slots beyond
   // np live in set 0) through the pinned staging: both transfers enqueued, ONE wait
-  const int blocks = c->diag_blocks[isp];
   const int64_t ntail = S.nalloc - S.np;
   const int tb = ntail > 0 ? static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256)) : 0;
-  double *part = nullptr;
-  if (int rc = pinned(c, 3 * static_cast<size_t>(blocks + tb) + 8, &part)) return rc;
-  if (blocks > 0) HIP_TRY(hipMemcpyAsync(part, part_dev, sizeof(double) * blocks * 3, hipMemcpyDeviceToHost, c->st));
-  if (tb > 0) {
-    HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, ntail, c->d_scratch, tb,
-                               c->st));
-    HIP_TRY(hipMemcpyAsync(part + 3 * blocks, c->d_scratch, sizeof(double) * tb * 3, hipMemcpyDeviceToHost, c->st));
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int blocks = c->diag_blocks[isp], stride = c->diag_stride[isp];
+    sums[0] = sums[1] = sums[2] = 0.0;
+    double *part = nullptr;
+    if (int rc = pinned(c, static_cast<size_t>(stride) * blocks + 3 * static_cast<size_t>(tb) + 8, &part)) return rc;
+    if (blocks > 0) HIP_TRY(hipMemcpyAsync(part, part_dev, sizeof(double) * blocks * stride, hipMemcpyDeviceToHost, c->st));
+    if (tb > 0) {
+      HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, ntail, c->d_scratch, tb,
+                                 c->st));
+      HIP_TRY(hipMemcpyAsync(part + static_cast<size_t>(stride) * blocks, c->d_scratch, sizeof(double) * tb * 3,
+                             hipMemcpyDeviceToHost, c->st));
+    }
+    if (blocks + tb > 0) HIP_TRY(hipStreamSynchronize(c->st));
+    double maxp = 0.0, maxw = 0.0, over = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+      for (int k = 0; k < 3; ++k) sums[k] += part[b * stride + k];
+      if (stride >= 6) {
+        maxp = std::max(maxp, part[b * stride + 3]);
+        maxw = std::max(maxw, part[b * stride + 4]);
+        over = std::max(over, part[b * stride + 5]);
+      }
+    }
+    for (int b = 0; b < tb; ++b)
+      for (int k = 0; k < 3; ++k) sums[k] += part[static_cast<size_t>(stride) * blocks + b * 3 + k];
+    if (stride >= 6 && blocks > 0) {  // what the next pass of this species may scale its fixed-point sums with
+      c->diag_max_p[isp] = maxp;
+      c->diag_max_w[isp] = maxw;
+    }
+    if (!(was_fixed && over > 0.0)) break;
+    // a marker beyond the bounds the fixed-point pass was scaled for (it skipped that marker): once more, in doubles
+    c->diag_fx_repeats++;
+    if (int rc = run_diag_pass(c, isp, false, &was_fixed)) return rc;
   }
-  if (blocks + tb > 0) HIP_TRY(hipStreamSynchronize(c->st));
-  for (int b = 0; b < blocks; ++b)
-    for (int k = 0; k < 3; ++k) sums[k] += part[b * 3 + k];
-  for (int b = 0; b < tb; ++b)
-    for (int k = 0; k < 3; ++k) sums[k] += part[3 * blocks + b * 3 + k];
   c->diag_pending[isp] = 0;
   return 0;
 }

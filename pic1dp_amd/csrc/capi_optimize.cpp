@@ -497,6 +497,8 @@ int pic1dp_hip_particle_optimize(pic1dp_ctx *c, int32_t irk, int32_t *flag_optim
   for (int b = 0; b < nb; ++b)
     if (c->blk_alloc[b] >= (int64_t{1} << 32) - 2) on_host = true;
   if (int rc = on_host ? optimize_on_host(c, due) : optimize_on_device(c, due)) return rc;
+  std::fill(c->diag_max_p.begin(), c->diag_max_p.end(), 0.0);  // (merged / rescaled / split weights: the fixed-point
+  std::fill(c->diag_max_w.begin(), c->diag_max_w.end(), 0.0);  //  diagnostics' bounds are void)
   if (flag_optimized) *flag_optimized = 1;
   return tm.end();
 }

@@ -718,7 +718,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       const size_t ntot = dist_len(c->in);
       a.dg = dist_geom(c);
       a.dist_out = c->d_dist + ntot * s;
-      a.dist_partial = c->d_diag_part + static_cast<size_t>(3) * diag_max_blocks(c) * s;
+      a.dist_partial = c->d_diag_part + static_cast<size_t>(6) * diag_max_blocks(c) * s;
       HIP_TRY(hipMemsetAsync(a.dist_out, 0, sizeof(double) * ntot, c->st));
       lc.lds += step_diag_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nx_opd, c->in.nv_opd);
       lc.threads = 1024;
@@ -726,6 +726,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
       lc.blocks = static_cast<int>(std::max<int64_t>(1, std::min(blocks, need)));
       c->diag_blocks[s] = lc.blocks;
+      c->diag_stride[s] = 3;       // (the kinetic sums only: no maxima from this kernel)
       c->diag_pending[s] = 1;
       c->diag_version[s] = c->state_version;  // the caller has bumped it for this step already
     }

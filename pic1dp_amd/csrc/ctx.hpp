@@ -185,6 +185,14 @@ struct pic1dp_ctx {
   double *d_diag_part = nullptr;           // [nspecies][3 * diag_max_blocks] per-workgroup partial sums of the pass
   std::vector<char> diag_pending;          // [nspecies] a pass ran, its partial sums are still on the device
   std::vector<int> diag_blocks;            // [nspecies] workgroups of that pass
+  std::vector<int> diag_stride;            // [nspecies] doubles per workgroup in its partial sums: 3 (k_step_full<DIAG>) or 6 (k_ptcldist)
+  // k_ptcldist with 64-bit fixed-point histogram sums (device_diag.hpp DistScale): max |p| and max |w| of the species as
+  // the last pass saw them (0: unknown -- the next pass sums in doubles and finds out); PIC1DP_DIAG_FX=0: always doubles
+  std::vector<double> diag_max_p, diag_max_w;
+  std::vector<uint64_t> diag_max_p_version;   // state_version-independent stamp: p changes with load / upload / events only
+  int diag_fx = 1;
+  double diag_fx_margin_w = 16.0;   // bound on |w| = this x the last pass's max |w| (PIC1DP_DIAG_FX_MARGIN: tests)
+  int64_t diag_fx_passes = 0, diag_fx_repeats = 0;   // fixed-point passes so far; passes repeated in doubles after an overflow
   int fuse_output = 0;                     // take the diagnostics inside k_step_full on steps output_all follows
   double *h_pin = nullptr;                 // pinned host staging of the small device-to-host transfers (output_all's calls:
   size_t h_pin_doubles = 0;                // pageable copies cost a synchronous call each, ~20 us; grow-only, capi_diag.cpp pinned)

@@ -353,11 +353,12 @@ hipError_t launch_tile_gather(const double *arr, int64_t i0, double *dst, int64_
 hipError_t launch_tile_copy(double *dst, const double *src, int64_t n, hipStream_t st);
 // raw (x,v) and v histograms of output_ptcldist into out =
 // [markr_xv | total_xv | pertb_xv | markr_v | total_v | pertb_v] (accumulated)
-// In the same pass: partial[blocks][3] = per-workgroup sums of v^2, v^2 p, v^2 w
-// over all np markers (nullptr: not wanted); blocks = ptcldist_blocks(...)
+// In the same pass: partial[blocks][6] = per-workgroup sums of v^2, v^2 p, v^2 w over all np markers, max |p|, max |w|,
+// and whether a marker exceeded the bounds of a fixed-point pass; blocks = ptcldist_blocks(...).
+// bound_p, bound_w > 0: the (x, v) histograms as 64-bit fixed-point sums in the LDS (device_diag.hpp DistScale)
 hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
-                           int64_t np, const DistGeom &dg, bool deltaf,
-                           double *out, double *partial, int num_cu, hipStream_t st);
+                           int64_t np, const DistGeom &dg, bool deltaf, double bound_p, double bound_w,
+                           double *out, double *partial, int num_cu, hipStream_t st, bool *fixed_point);
 int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu);
 // ---- marker optimisation events (kernels_opt.hip; host side of the sequential part: optimize.hpp plan_*) ----
 // one reference rank block of a species inside the species' packed (tiled) arrays: block-local marker i lies at global

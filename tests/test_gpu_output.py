@@ -471,3 +471,72 @@ def test_fortran_host_default_workload_slice(oracle_mod, amd, tmp_path):
     assert relerr(a.electric[5], sim.get_field()[0]) < 1e-10
     g2 = a.growthrate_energy_fit(15.0, 45.0)
     assert abs(g2 / 0.16766 - 1.0) < 0.03, g2
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(linear=1), dict(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0]),
+                                dict(nparticle_max=150_001, species_nparticle_init=[140_000])],
+                         ids=["default", "linear", "full_f", "odd_with_tail_slots"])
+def test_fixed_point_histograms_equal_the_double_sums(oracle_mod, amd, monkeypatch, kw):
+    """round 5: from the second record on k_ptcldist sums the (x, v) histograms as 64-bit fixed-point numbers in the LDS
+    (ds_add_u64 runs 1.9x the rate of ds_add_f64 at random bins; scale per plane from the species' max |p|, max |w| of the
+    pass before) -- a term rounded once to 2^-44 of its plane's bound, the sums exact and independent of the atomics'
+    order: against the double sums (PIC1DP_DIAG_FX=0) 1e-12 of the largest bin, against the oracle as before; markers
+    beyond the bounds (the weights scaled up behind the library's back) make the pass repeat in doubles"""
+    base = dict(nparticle_max=300_000, nx=128, output_interval=0.5)
+    base.update(kw)
+    engs = []
+    for fx in ("1", "0"):
+        monkeypatch.setenv("PIC1DP_DIAG_FX", fx)
+        e = amd.Pic1dp(amd.make_input(**base))
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+        engs.append(e)
+    a, b = engs
+    sim = oracle_mod.Sim(oracle_mod.make_input(**base))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    for rec in range(4):
+        pa, pb, po = a.ptcldist(), b.ptcldist(), sim.ptcldist()
+        for k in pa:
+            scale = max(np.max(np.abs(pb[k])), 1e-300)
+            assert np.max(np.abs(pa[k] - pb[k])) <= 1e-12 * scale, (rec, k)
+            if rec > 0 or True:
+                assert relerr(np.asarray(pa[k]).ravel(), np.asarray(po[k]).ravel()) < 1e-9, (rec, k)
+        assert np.allclose(a.output_scalars(), b.output_scalars(), rtol=1e-12, atol=0.0)
+        for e in (a, b):
+            e.step(10)
+        sim.step(10)
+    fx_passes, repeats = a.kernel_stats(12)[1], a.kernel_stats(12)[0]
+    assert fx_passes == 3 and repeats == 0 and b.kernel_stats(12)[1] == 0        # the first record: bounds unknown, doubles
+    # an upload voids the bounds: the next record is summed in doubles, the one after in fixed point again
+    g = a.particles_download()
+    npv = a.local_sizes()[1]
+    a.particles_upload(g["x"], g["v"], g["p"], g["w"], np_valid=npv)
+    b.particles_upload(g["x"], g["v"], g["p"], g["w"], np_valid=npv)
+    pa, pb = a.ptcldist(), b.ptcldist()
+    assert a.kernel_stats(12)[1] == 3
+    for k in pa:
+        assert np.max(np.abs(pa[k] - pb[k])) <= 1e-12 * max(np.max(np.abs(pb[k])), 1e-300), k
+
+
+def test_fixed_point_histograms_repeat_in_doubles_on_overflow(amd, monkeypatch):
+    """a marker beyond the bounds a fixed-point pass was scaled for (here: the margin on max |w| set below one, so that the
+    largest weights of the very next record exceed it) makes the pass report it and the library repeat the pass with
+    double sums: the record is right either way"""
+    monkeypatch.setenv("PIC1DP_DIAG_FX_MARGIN", "0.5")
+    a = amd.Pic1dp(amd.make_input(nparticle_max=300_000, nx=128))
+    monkeypatch.setenv("PIC1DP_DIAG_FX", "0")
+    b = amd.Pic1dp(amd.make_input(nparticle_max=300_000, nx=128))
+    for e in (a, b):
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+    for rec in range(3):
+        pa, pb = a.ptcldist(), b.ptcldist()
+        for k in pa:
+            assert np.max(np.abs(pa[k] - pb[k])) <= 1e-12 * max(np.max(np.abs(pb[k])), 1e-300), (rec, k)
+        for e in (a, b):
+            e.step(10)
+    assert a.kernel_stats(12)[1] == 2 and a.kernel_stats(12)[0] == 2.0     # both fixed-point passes overflowed and were repeated

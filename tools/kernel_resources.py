@@ -17,6 +17,8 @@ r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std
                     "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("PIC1DP_EXTRA_FLAGS", "").split() + DIST_FLAG,
                    capture_output=True, text=True)
 blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+if r.returncode != 0 or not blocks:
+    sys.exit("compile failed:\n" + r.stderr[-3000:])
 names = [b.split()[0] for b in blocks]
 dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
