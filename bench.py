@@ -209,7 +209,17 @@ class Job:
                                          "only, the others wait for the process group's 300 s timeout and the job ends "
                                          "without a line\n" % world)
                         sys.stderr.flush()
-                    self.rccl_why = parallel.bootstrap_comm(self.eng, dist)
+                    # RCCL prints a version banner on STDOUT when its first communicator comes up: stdout is for the one
+                    # JSON line (as with gloo's note in main())
+                    sys.stdout.flush()
+                    saved_stdout = os.dup(1)
+                    os.dup2(2, 1)
+                    try:
+                        self.rccl_why = parallel.bootstrap_comm(self.eng, dist)
+                    finally:
+                        sys.stdout.flush()
+                        os.dup2(saved_stdout, 1)
+                        os.close(saved_stdout)
                 self.have_rccl = self.rccl_why is None
             if a.allreduce in ("auto", "p2p", "host"):   # "host": connected too, to be measured beside it
                 self.p2p_why = parallel.bootstrap_exchange(self.eng, dist)
