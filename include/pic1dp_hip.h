@@ -393,6 +393,15 @@ int pic1dp_hip_ptcldist(pic1dp_ctx *ctx, int32_t ispecies, int32_t finish,
                         double *markr_xv, double *total_xv, double *pertb_xv,
                         double *markr_v, double *total_v, double *pertb_v);
 
+/* output_all in ONE call (src/pic1dp_output.F90:100-189, 196-477; call sites src/pic1dp.F90:74,107): what
+ * pic1dp_hip_output_scalars, pic1dp_hip_get_field and pic1dp_hip_ptcldist(finish = 1) of every species hand out,
+ * with the diagnostics passes and every transfer enqueued together and ONE wait (the separate calls wait
+ * three times and more per record).  scalars: [2 + 3 nspecies]; electric, chargeden: [nx]; mode_re, mode_im:
+ * [nmode]; dist: [nspecies][3 nx_opd nv_opd + 3 nv_opd] = markr_xv | total_xv | pertb_xv | markr_v | total_v |
+ * pertb_v of each species in turn.  Any pointer but scalars may be NULL.  On several ranks the call composes the
+ * separate ones (RCCL communicator: they reduce; no communicator: an error, as pic1dp_hip_ptcldist). */
+int pic1dp_hip_output_all(pic1dp_ctx *ctx, double *scalars, int32_t nscalars, double *electric, double *chargeden,
+                          double *mode_re, double *mode_im, double *dist);
 /* ---- split-phase diagnostics for a host that owns the reductions (MPI) ----
  * output_all sums its diagnostics over the ranks (VecSum / MPI_Reduce, src/pic1dp_output.F90:126-151,333-356).
  * With an RCCL communicator output_scalars and ptcldist(finish = 1) do that themselves; a host with its own

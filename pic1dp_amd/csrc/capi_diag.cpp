@@ -174,12 +174,11 @@ int pic1dp_hip_output_scalars(pic1dp_ctx *c, double *out, int32_t n) {
   return pic1dp_hip_output_scalars_from(c, sums.data(), out, n);
 }
 
-int pic1dp_hip_output_scalars_from(pic1dp_ctx *c, const double *sums, double *out, int32_t n) {
-  CHECK_CTX(c);
+// realbuf of output_field (src/pic1dp_output.F90:117-175) from the kinetic sums over all ranks and int E^2 dx
+static void fill_scalars(const pic1dp_ctx *c, const double *sums, double energy, double *out) {
   const int ns = c->in.nspecies;
-  if (!sums || !out || n != 2 + 3 * ns) return fail(PIC1DP_ERR_ARG, "sums must hold 3*nspecies and out 2 + 3*nspecies doubles");
   out[0] = c->time;
-  if (int rc = pic1dp_hip_field_energy(c, &out[1])) return rc;
+  out[1] = energy;
   const pic1dp_input &in = c->in;
   for (int s = 0; s < ns; ++s) {
     double marker = sums[3 * s], total = sums[3 * s + 1], pert;
@@ -198,6 +197,15 @@ int pic1dp_hip_output_scalars_from(pic1dp_ctx *c, const double *sums, double *ou
     out[3 + 3 * s] = total;
     out[4 + 3 * s] = pert;
   }
+}
+
+int pic1dp_hip_output_scalars_from(pic1dp_ctx *c, const double *sums, double *out, int32_t n) {
+  CHECK_CTX(c);
+  const int ns = c->in.nspecies;
+  if (!sums || !out || n != 2 + 3 * ns) return fail(PIC1DP_ERR_ARG, "sums must hold 3*nspecies and out 2 + 3*nspecies doubles");
+  double energy = 0.0;
+  if (int rc = pic1dp_hip_field_energy(c, &energy)) return rc;
+  fill_scalars(c, sums, energy, out);
   return 0;
 }
 
@@ -294,5 +302,133 @@ int pic1dp_hip_ptcldist_finish(pic1dp_ctx *c, int32_t isp, double *markr_xv, dou
   return 0;
 }
 
+
+// Everything output_all writes (src/pic1dp_output.F90:100-189, 196-477) in ONE call and one wait: the diagnostics passes of
+// all species, int E^2 dx, and every transfer to the host enqueued behind them on the engine's stream through the pinned
+// staging (the separate calls wait three times and more per record: 0.16 ms of host time that is most of what a record
+// costs at 6.4e6 markers).  dist: [nspecies][3 nx_opd nv_opd + 3 nv_opd] as output_ptcldist writes them (finished), or null.
+// Several ranks: composed of the separate calls, which own the reductions.
+int pic1dp_hip_output_all(pic1dp_ctx *c, double *scalars, int32_t nscal, double *E, double *cd, double *re, double *im,
+                          double *dist) {
+  CHECK_CTX(c);
+  const pic1dp_input &in = c->in;
+  const int ns = in.nspecies;
+  if (!scalars || nscal != 2 + 3 * ns) return fail(PIC1DP_ERR_ARG, "scalars must hold 2 + 3*nspecies doubles");
+  const size_t nx = in.nx, nm = in.nmode, ntot = dist_len(in), nxv = static_cast<size_t>(in.nx_opd) * in.nv_opd;
+  if (c->comm || c->lay.nranks > 1) {
+    if (int rc = pic1dp_hip_output_scalars(c, scalars, nscal)) return rc;
+    if (int rc = pic1dp_hip_get_field(c, E, cd, re, im)) return rc;
+    for (int s = 0; s < ns && dist; ++s) {
+      double *d = dist + ntot * s;
+      if (int rc = pic1dp_hip_ptcldist(c, s, 1, d, d + nxv, d + 2 * nxv, d + 3 * nxv, d + 3 * nxv + in.nv_opd,
+                                       d + 3 * nxv + 2 * in.nv_opd))
+        return rc;
+    }
+    return 0;
+  }
+  if (int rc = require_loaded(c)) return rc;
+  if (int rc = settle_field_view(c)) return rc;
+  if (int rc = materialize_cd(c)) return rc;
+  if (cd && c->cd_kept_mode_only)
+    if (int rc = rebuild_half_step_chargeden(c)) return rc;
+  if (int rc = diag_buffers(c)) return rc;
+  // the pinned record: [E | cd | re | im | energy + pad] then per species [partial sums | tail sums | histograms]
+  std::vector<size_t> off_part(ns), off_tail(ns), off_hist(ns);
+  std::vector<int> tb(ns, 0);
+  std::vector<char> fixed(ns, 0);
+  size_t off = 2 * nx + 2 * nm + 8;
+  for (int s = 0; s < ns; ++s) {  // launch what has not seen these markers yet
+    if (c->diag_version[s] != c->state_version) {
+      bool was_fixed = false;
+      if (int rc = run_diag_pass(c, s, true, &was_fixed)) return rc;
+      fixed[s] = was_fixed;
+      c->diag_pending[s] = 1;
+      c->diag_version[s] = c->state_version;
+    }
+    const int64_t ntail = c->sp[s].nalloc - c->sp[s].np;
+    tb[s] = c->diag_pending[s] && ntail > 0 ? static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256)) : 0;
+    off_part[s] = off;
+    off += static_cast<size_t>(6) * diag_max_blocks(c);
+    off_tail[s] = off;
+    off += static_cast<size_t>(3) * kEnergyBlocks;
+    off_hist[s] = off;
+    off += ntot;
+  }
+  double *h = nullptr;
+  if (int rc = pinned(c, off, &h)) return rc;
+  double *slot = c->d_scratch + kEnergyBlocks * 3;
+  HIP_TRY(launch_field_energy(c->d_E, in.nx, in.lx, static_cast<double>(in.nx), slot, c->st));
+  HIP_TRY(hipMemcpyAsync(h, c->d_E, sizeof(double) * nx, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(hipMemcpyAsync(h + nx, c->d_chargeden, sizeof(double) * nx, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(hipMemcpyAsync(h + 2 * nx, c->d_mode_re, sizeof(double) * nm, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(hipMemcpyAsync(h + 2 * nx + nm, c->d_mode_im, sizeof(double) * nm, hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(hipMemcpyAsync(h + 2 * nx + 2 * nm, slot, sizeof(double), hipMemcpyDeviceToHost, c->st));
+  for (int s = 0; s < ns; ++s) {
+    Species &S = c->sp[s];
+    if (c->diag_pending[s]) {
+      const int blocks = c->diag_blocks[s], stride = c->diag_stride[s];
+      double *part_dev = c->d_diag_part + static_cast<size_t>(6) * diag_max_blocks(c) * s;
+      if (blocks > 0)
+        HIP_TRY(hipMemcpyAsync(h + off_part[s], part_dev, sizeof(double) * blocks * stride, hipMemcpyDeviceToHost, c->st));
+      if (tb[s] > 0) {  // the reference sums the whole local vector (VecSum); slots beyond np live in set 0
+        HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, S.nalloc - S.np, c->d_scratch,
+                                   tb[s], c->st));
+        HIP_TRY(hipMemcpyAsync(h + off_tail[s], c->d_scratch, sizeof(double) * tb[s] * 3, hipMemcpyDeviceToHost, c->st));
+      }
+    }
+    if (dist) HIP_TRY(hipMemcpyAsync(h + off_hist[s], c->d_dist + ntot * s, sizeof(double) * ntot, hipMemcpyDeviceToHost, c->st));
+  }
+  HIP_TRY(hipStreamSynchronize(c->st));
+  if (int rc = xchg_check(c)) return rc;
+  std::vector<double> sums(3 * static_cast<size_t>(ns));
+  for (int s = 0; s < ns; ++s) {
+    double *acc = &c->diag_sums[3 * static_cast<size_t>(s)];
+    if (c->diag_pending[s]) {
+      const int blocks = c->diag_blocks[s], stride = c->diag_stride[s];
+      const double *part = h + off_part[s], *tail = h + off_tail[s];
+      acc[0] = acc[1] = acc[2] = 0.0;
+      double maxp = 0.0, maxw = 0.0, over = 0.0;
+      for (int b = 0; b < blocks; ++b) {
+        for (int k = 0; k < 3; ++k) acc[k] += part[b * stride + k];
+        if (stride >= 6) {
+          maxp = std::max(maxp, part[b * stride + 3]);
+          maxw = std::max(maxw, part[b * stride + 4]);
+          over = std::max(over, part[b * stride + 5]);
+        }
+      }
+      for (int b = 0; b < tb[s]; ++b)
+        for (int k = 0; k < 3; ++k) acc[k] += tail[b * 3 + k];
+      if (stride >= 6 && blocks > 0) {
+        c->diag_max_p[s] = maxp;
+        c->diag_max_w[s] = maxw;
+      }
+      c->diag_pending[s] = 0;
+      if (fixed[s] && over > 0.0) {  // a marker beyond the fixed-point bounds: this species once more, in doubles (rare)
+        c->diag_fx_repeats++;
+        bool was_fixed = false;
+        if (int rc = run_diag_pass(c, s, false, &was_fixed)) return rc;
+        c->diag_pending[s] = 1;
+        if (int rc = ensure_diag(c, s)) return rc;
+        if (dist) {
+          HIP_TRY(hipMemcpyAsync(h + off_hist[s], c->d_dist + ntot * s, sizeof(double) * ntot, hipMemcpyDeviceToHost, c->st));
+          HIP_TRY(hipStreamSynchronize(c->st));
+        }
+      }
+    }
+    for (int k = 0; k < 3; ++k) sums[3 * s + k] = c->diag_sums[3 * static_cast<size_t>(s) + k];
+    if (!in.deltaf) sums[3 * s + 2] = sums[3 * s + 1];
+  }
+  fill_scalars(c, sums.data(), h[2 * nx + 2 * nm], scalars);
+  if (E) std::memcpy(E, h, sizeof(double) * nx);
+  if (cd) std::memcpy(cd, h + nx, sizeof(double) * nx);
+  if (re) std::memcpy(re, h + 2 * nx, sizeof(double) * nm);
+  if (im) std::memcpy(im, h + 2 * nx + nm, sizeof(double) * nm);
+  for (int s = 0; s < ns && dist; ++s) {
+    double *d = h + off_hist[s];
+    finish_ptcldist(in, s, d, d + nxv, d + 2 * nxv, d + 3 * nxv, d + 3 * nxv + in.nv_opd, d + 3 * nxv + 2 * in.nv_opd);
+    std::memcpy(dist + ntot * s, d, sizeof(double) * ntot);
+  }
+  return 0;
+}
 
 }  // extern "C"

@@ -292,6 +292,25 @@ class Pic1dp:
         check(self.L.pic1dp_hip_ptcldist(self._ctx, ispecies, int(finish), *[_ptr(a) for a in out]))
         return dict(zip(names, out))
 
+    def output_all(self):
+        """everything output_all writes in one call and one wait: (scalars, field dict, [per-species ptcldist dicts])"""
+        inp = self.inp
+        ns, nx, nm = inp.nspecies, inp.nx, inp.nmode
+        nxv, nvo = inp.nx_opd * inp.nv_opd, inp.nv_opd
+        ntot = 3 * nxv + 3 * nvo
+        scal = np.empty(2 + 3 * ns)
+        E, cd, re, im = np.empty(nx), np.empty(nx), np.empty(nm), np.empty(nm)
+        dist = np.empty(ns * ntot)
+        check(self.L.pic1dp_hip_output_all(self._ctx, _ptr(scal), scal.size, _ptr(E), _ptr(cd), _ptr(re), _ptr(im), _ptr(dist)))
+        names = ("markr_xv", "total_xv", "pertb_xv", "markr_v", "total_v", "pertb_v")
+        per = []
+        for s in range(ns):
+            d = dist[s * ntot:(s + 1) * ntot]
+            parts = [d[0:nxv], d[nxv:2 * nxv], d[2 * nxv:3 * nxv], d[3 * nxv:3 * nxv + nvo], d[3 * nxv + nvo:3 * nxv + 2 * nvo],
+                     d[3 * nxv + 2 * nvo:]]
+            per.append(dict(zip(names, parts)))
+        return scal, dict(electric=E, chargeden=cd, mode_re=re, mode_im=im), per
+
     # -- split-phase diagnostics (a host that owns the reductions) --------------------
     def output_scalars_from(self, sums):
         """realbuf of output_field from the kinetic sums (energy_sums per species) summed over ranks"""

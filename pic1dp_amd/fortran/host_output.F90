@@ -46,27 +46,40 @@ subroutine output_all(ctx, inp, verbosity)
   integer(c_int32_t), intent(in) :: verbosity
   real(c_double) :: scal(2 + 3 * inp%nspecies), sums(3 * inp%nspecies)
   real(c_double) :: e(inp%nx), cd(inp%nx), re(inp%nmode), im(inp%nmode)
-  real(c_double), allocatable :: mxv(:), txv(:), pxv(:), mv(:), tv(:), pv(:)
+  real(c_double), allocatable :: mxv(:), txv(:), pxv(:), mv(:), tv(:), pv(:), dist(:)
   integer(c_int32_t) :: s, itime
   real(c_double) :: time, progress(2)
   character :: cprogress
-  integer :: nxv
+  integer :: nxv, ntot
   real(c_double) :: t0, t1
 
   t0 = output_wall()
   nxv = inp%nx_opd * inp%nv_opd
-  allocate (mxv(nxv), txv(nxv), pxv(nxv), mv(inp%nv_opd), tv(inp%nv_opd), pv(inp%nv_opd))
   if (ranks_size == 1) then
-    call pic1dp_hip_check(pic1dp_hip_output_scalars(ctx, scal, int(size(scal), c_int32_t)), 'output_scalars')
+    ! one rank: everything the record holds in ONE call and one wait (pic1dp_hip_output_all)
+    ntot = 3 * nxv + 3 * inp%nv_opd
+    allocate (dist(ntot * inp%nspecies))
+    call pic1dp_hip_check(pic1dp_hip_output_all(ctx, scal, int(size(scal), c_int32_t), e, cd, re, im, dist), 'output_all')
+    t1 = output_wall()
+    output_lib_s = output_lib_s + (t1 - t0)
+    write (output_unit_out) scal
+    call output_vec(re)
+    call output_vec(im)
+    call output_vec(e)
+    call output_vec(cd)
+    write (output_unit_out) dist        ! per species: markr_xv, total_xv, pertb_xv, markr_v, total_v, pertb_v -- the file's order
+    t0 = output_wall()
+    output_write_s = output_write_s + (t0 - t1)
+    output_records = output_records + 1
   else
-    ! VecSum over ranks (src/pic1dp_output.F90:126-151): local sums, reduced to rank 0, finished there
-    do s = 0, inp%nspecies - 1
-      call pic1dp_hip_check(pic1dp_hip_energy_sums(ctx, s, sums(3 * s + 1 : 3 * s + 3)), 'energy_sums')
-    end do
-    call ranks_reduce_to_root(sums, 3 * inp%nspecies)
-    if (ranks_rank == 0) call pic1dp_hip_check(pic1dp_hip_output_scalars_from(ctx, sums, scal, &
-      int(size(scal), c_int32_t)), 'output_scalars_from')
-  end if
+  allocate (mxv(nxv), txv(nxv), pxv(nxv), mv(inp%nv_opd), tv(inp%nv_opd), pv(inp%nv_opd))
+  ! VecSum over ranks (src/pic1dp_output.F90:126-151): local sums, reduced to rank 0, finished there
+  do s = 0, inp%nspecies - 1
+    call pic1dp_hip_check(pic1dp_hip_energy_sums(ctx, s, sums(3 * s + 1 : 3 * s + 3)), 'energy_sums')
+  end do
+  call ranks_reduce_to_root(sums, 3 * inp%nspecies)
+  if (ranks_rank == 0) call pic1dp_hip_check(pic1dp_hip_output_scalars_from(ctx, sums, scal, &
+    int(size(scal), c_int32_t)), 'output_scalars_from')
   if (ranks_rank == 0) then
     call pic1dp_hip_check(pic1dp_hip_get_field(ctx, e, cd, re, im), 'get_field')
     t1 = output_wall()
@@ -80,20 +93,16 @@ subroutine output_all(ctx, inp, verbosity)
     output_write_s = output_write_s + (t0 - t1)
   end if
   do s = 0, inp%nspecies - 1
-    if (ranks_size == 1) then
-      call pic1dp_hip_check(pic1dp_hip_ptcldist(ctx, s, 1_c_int32_t, mxv, txv, pxv, mv, tv, pv), 'ptcldist')
-    else
-      ! MPI_Reduce of the six histograms to rank 0 (:333-356), which scales and writes them
-      call pic1dp_hip_check(pic1dp_hip_ptcldist(ctx, s, 0_c_int32_t, mxv, txv, pxv, mv, tv, pv), 'ptcldist')
-      call ranks_reduce_to_root(mxv, nxv)
-      call ranks_reduce_to_root(txv, nxv)
-      call ranks_reduce_to_root(pxv, nxv)
-      call ranks_reduce_to_root(mv, int(inp%nv_opd))
-      call ranks_reduce_to_root(tv, int(inp%nv_opd))
-      call ranks_reduce_to_root(pv, int(inp%nv_opd))
-      if (ranks_rank == 0) call pic1dp_hip_check(pic1dp_hip_ptcldist_finish(ctx, s, mxv, txv, pxv, mv, tv, pv), &
-        'ptcldist_finish')
-    end if
+    ! MPI_Reduce of the six histograms to rank 0 (:333-356), which scales and writes them
+    call pic1dp_hip_check(pic1dp_hip_ptcldist(ctx, s, 0_c_int32_t, mxv, txv, pxv, mv, tv, pv), 'ptcldist')
+    call ranks_reduce_to_root(mxv, nxv)
+    call ranks_reduce_to_root(txv, nxv)
+    call ranks_reduce_to_root(pxv, nxv)
+    call ranks_reduce_to_root(mv, int(inp%nv_opd))
+    call ranks_reduce_to_root(tv, int(inp%nv_opd))
+    call ranks_reduce_to_root(pv, int(inp%nv_opd))
+    if (ranks_rank == 0) call pic1dp_hip_check(pic1dp_hip_ptcldist_finish(ctx, s, mxv, txv, pxv, mv, tv, pv), &
+      'ptcldist_finish')
     if (ranks_rank /= 0) cycle
     t1 = output_wall()
     output_lib_s = output_lib_s + (t1 - t0)
@@ -107,6 +116,7 @@ subroutine output_all(ctx, inp, verbosity)
     output_write_s = output_write_s + (t0 - t1)
   end do
   output_records = output_records + 1
+  end if
   if (verbosity == 1) then
     call pic1dp_hip_check(pic1dp_hip_get_time(ctx, itime, time), 'get_time')
     progress(1) = 1e2_c_double * real(itime, c_double) / inp%ntime_max

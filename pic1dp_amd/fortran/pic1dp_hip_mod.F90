@@ -253,6 +253,19 @@ interface
     integer(c_int32_t), intent(out) :: flag
     integer(c_int) :: ierr
   end function pic1dp_hip_output_due
+  function pic1dp_hip_output_all(ctx, scalars, nscalars, electric, chargeden, mode_re, mode_im, dist) &
+      bind(C, name="pic1dp_hip_output_all") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    real(c_double), intent(inout) :: scalars(*)
+    integer(c_int32_t), value :: nscalars
+    real(c_double), intent(inout) :: electric(*)
+    real(c_double), intent(inout) :: chargeden(*)
+    real(c_double), intent(inout) :: mode_re(*)
+    real(c_double), intent(inout) :: mode_im(*)
+    real(c_double), intent(inout) :: dist(*)
+    integer(c_int) :: ierr
+  end function pic1dp_hip_output_all
   function pic1dp_hip_steps_to_output(ctx, nsteps) bind(C, name="pic1dp_hip_steps_to_output") result(ierr)
     import
     type(c_ptr), value :: ctx

@@ -46,15 +46,17 @@ class OutputWriter:
     def write_record(self, engine):
         """output_all minus the progress line: one record from the engine's
         current state.  Returns int E^2 dx (what output_progress prints)."""
-        scal = engine.output_scalars()
+        if hasattr(engine, "output_all"):             # one call, one wait (pic1dp_hip_output_all)
+            scal, fld, dists = engine.output_all()
+        else:                                         # (any object with the three calls of the record)
+            scal, fld = engine.output_scalars(), engine.get_field()
+            dists = [engine.ptcldist(s, finish=True) for s in range(self.inp.nspecies)]
         self.f.write(_be(scal, np.float64))
-        fld = engine.get_field()
         self._vec(fld["mode_re"])
         self._vec(fld["mode_im"])
         self._vec(fld["electric"])
         self._vec(fld["chargeden"])
-        for s in range(self.inp.nspecies):
-            d = engine.ptcldist(s, finish=True)
+        for d in dists:
             for k in ("markr_xv", "total_xv", "pertb_xv", "markr_v", "total_v", "pertb_v"):
                 self.f.write(_be(d[k], np.float64))
         self.nrecords += 1

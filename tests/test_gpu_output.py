@@ -540,3 +540,43 @@ def test_fixed_point_histograms_repeat_in_doubles_on_overflow(amd, monkeypatch):
         for e in (a, b):
             e.step(10)
     assert a.kernel_stats(12)[1] == 2 and a.kernel_stats(12)[0] == 2.0     # both fixed-point passes overflowed and were repeated
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(linear=1), dict(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0]),
+                                dict(nparticle_max=150_001, species_nparticle_init=[140_000]),
+                                dict(nspecies=2, species_charge=[-1.0, 1.0], species_mass=[1.0, 4.0], species_temperature=[1.0, 1.0],
+                                     species_temperature2=[1.0, 1.0], species_density=[0.9, 0.9], species_v0=[5.0, 5.0],
+                                     species_nparticle_init=[120_000, 90_000])],
+                         ids=["default", "linear", "full_f", "odd_with_tail_slots", "two_species"])
+def test_output_all_in_one_call_equals_the_separate_calls(amd, kw):
+    """pic1dp_hip_output_all -- the record of output_all (src/pic1dp_output.F90:100-189, 196-477) in one call and one wait
+    -- against output_scalars + get_field + ptcldist of every species on a twin engine: the same numbers (the passes'
+    atomics in another order: 1e-12), over several records and with steps in between"""
+    base = dict(nparticle_max=200_000, nx=96, output_interval=0.5)
+    base.update(kw)
+    a, b = amd.Pic1dp(amd.make_input(**base)), amd.Pic1dp(amd.make_input(**base))
+    for e in (a, b):
+        e.set_output_fusion(1)
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+    ns = base.get("nspecies", 1)
+    for rec in range(3):
+        scal, fld, dists = a.output_all()
+        want_scal, want_fld = b.output_scalars(), b.get_field()
+        tol = 1e-11 * np.abs(want_scal)
+        for isp in range(ns):                     # the perturbed kinetic sum cancels heavily: against the scale of its terms
+            tol[4 + 3 * isp] = max(tol[4 + 3 * isp], 1e-12 * abs(want_scal[3 + 3 * isp]))
+        assert np.all(np.abs(scal - want_scal) <= tol), (rec, scal, want_scal)
+        for k in ("electric", "chargeden", "mode_re", "mode_im"):
+            assert relerr(fld[k], want_fld[k]) < 1e-11, (rec, k)
+        for isp in range(ns):
+            want = b.ptcldist(isp)
+            for k in want:
+                assert np.max(np.abs(dists[isp][k] - want[k])) <= 1e-11 * max(np.max(np.abs(want[k])), 1e-300), (rec, isp, k)
+        # asked for again without a step in between: served from the cached pass
+        passes = a.kernel_stats(5)[1]
+        scal2, _, _ = a.output_all()
+        assert a.kernel_stats(5)[1] == passes and np.array_equal(scal2, scal)
+        for e in (a, b):
+            e.step(10)

@@ -24,8 +24,16 @@ for _ in range(REPS):
         t0 = time.perf_counter()
         fn()
         acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+t_all = 0.0
+for _ in range(REPS):
+    eng.step(1)
+    eng.sync()
+    t0 = time.perf_counter()
+    eng.output_all()
+    t_all += time.perf_counter() - t0
 tot = 0.0
 for k, v in acc.items():
     print("%-16s %8.1f us per call" % (k, v / REPS * 1e6))
     tot += v
 print("%-16s %8.1f us per output_all  (%d markers, nx %d)" % ("sum", tot / REPS * 1e6, n, nx))
+print("%-16s %8.1f us: pic1dp_hip_output_all, the three in one call and one wait" % ("output_all", t_all / REPS * 1e6))
