@@ -92,7 +92,7 @@ def build(force=False, verbose=False):
 def _build_locked(verbose):
     # tuning builds: PIC1DP_EXTRA_FLAGS="-DPIC1DP_NT=0" PIC1DP_LIB_OUT=/path/variant.so
     # (load one with PIC1DP_LIB=/path/variant.so); their objects go to a directory of their own
-    out = os.environ.get("PIC1DP_LIB_OUT") or LIB
+    out = os.path.abspath(os.environ.get("PIC1DP_LIB_OUT") or LIB)   # (the link runs in csrc/)
     extra = os.environ.get("PIC1DP_EXTRA_FLAGS", "").split()
     variant = out != LIB
     objdir = OBJDIR if not variant else OBJDIR + "." + os.path.basename(out)

@@ -558,8 +558,12 @@ static LaunchCfg pred_launch(const pic1dp_ctx *c, int64_t np, bool priv, int64_t
                 : (c->pred_kind == 2 ? step_sums_lds_bytes(c->in.nx, c->grid.rcopies)
                                      : step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode));
   bool two = 2 * (lc.lds + kStaticLds) <= kCuLds;  // both workgroups resident: each also holds the static exp table
-  int th2 = 768;   // (= STEP_PRIVATE_THREADS: the private sums' slot stride is a compile-time constant)
+  int th2 = 768;
   int th1 = 1024;
+  if (priv) {  // the private sums' slot stride is a compile-time constant: exactly that many threads
+    th2 = th1 = STEP_PRIVATE_THREADS;
+    if (STEP_PRIVATE_THREADS > 768) two = false;
+  }
   if (c->pred_kind == 2 && !priv) {
     // k_step_sums keeps its registers: four waves per SIMD with the exp-bearing distributions (one
     // workgroup of 1024 per CU), eight with the others, which saturate the memory system with far fewer
@@ -693,6 +697,23 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
         S.t2_version = c->state_version;
       }
       lc = pred_launch(c, S.np, priv, nullptr);
+#ifdef PIC1DP_TUNE_SUMS2  // timing experiment only: the solve still reads the tiles' layout
+      if (c->pred_kind == 1 && c->in.nmode == 2 && a.t2 == nullptr && std::getenv("PIC1DP_SUMS2")) {
+#ifndef PIC1DP_PRIV2_THREADS
+#define PIC1DP_PRIV2_THREADS 512
+#endif
+        const size_t ne = static_cast<size_t>((c->in.nx + 2) & ~1);
+        a.sums2 = 1;
+        a.dyn_tail = c->dyn_tail;
+        lc.threads = PIC1DP_PRIV2_THREADS;
+        lc.lds = sizeof(double) * (2 * ne + (static_cast<size_t>(c->in.nx) + 1) * 4 +
+                                   ((static_cast<size_t>(c->in.nx) * c->grid.rcopies + 2) & ~static_cast<size_t>(1)) +
+                                   20 * static_cast<size_t>(PIC1DP_PRIV2_THREADS) + 16);
+        const int bpc = 2 * (lc.lds + kStaticLds) <= kCuLds ? 2 : 1;
+        const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
+        lc.blocks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(static_cast<int64_t>(c->num_cu) * bpc, need)));
+      }
+#endif
       if (tail_mode != 0 && s == tail_species && !a.fused.on) {
         StepTail &t = a.tail;
         t.mode = tail_mode;

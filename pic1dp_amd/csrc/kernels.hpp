@@ -239,6 +239,9 @@ struct StepArgs {
   FusedSolve fused;  // pred_kind 2 only: the prologue solves the previous step's field (E0, Eh, eh_re / eh_im unused)
   StepTail tail;     // pred_kind 2 only, several ranks: the last workgroup packs / posts this rank's charge (mode 0: no)
   int dyn_tail;      // k_step_one<PRIV>, k_step_sums: sixteenths of a workgroup's chunks that its waves draw from an LDS counter (0: all dealt)
+#ifdef PIC1DP_TUNE_SUMS2
+  int sums2;         // tuning build: two kept modes as twenty private sums (marker kernel only, tools/ab_sums2.sh)
+#endif
 };
 constexpr int PRED_MAX_MODES = 4;  // kept modes k_step_one's prediction tiles are instantiated for (1 .. 4)
 // pred_kind 2: the six sums (padded to 8) are kept in this many copies -- workgroup b of the marker kernel adds into
@@ -259,7 +262,10 @@ inline size_t step_one_lds_bytes(int nx, int rcopies, int nm) {
 }
 // dynamic LDS of k_step_one<PRIV>: E0, Eh tiles, the one mode's tables cell by cell (nx + 1 cells of 2), rho copies,
 // six private sums per thread, reduction scratch
-constexpr int STEP_PRIVATE_THREADS = 768;  // k_step_one<PRIV> is launched with exactly this many threads per workgroup
+#ifndef PIC1DP_PRIV_THREADS
+#define PIC1DP_PRIV_THREADS 768  // (tuning builds: 1024 = one workgroup of sixteen waves per CU, tools/ab_variant_libs.sh)
+#endif
+constexpr int STEP_PRIVATE_THREADS = PIC1DP_PRIV_THREADS;  // k_step_one<PRIV> is launched with exactly this many threads per workgroup
 inline size_t step_one_private_lds_bytes(int nx, int rcopies, int threads = STEP_PRIVATE_THREADS) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
   return sizeof(double) * (2 * ne + (static_cast<size_t>(nx) + 1) * 2 +

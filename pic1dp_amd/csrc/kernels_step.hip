@@ -462,7 +462,7 @@ __device__ __forceinline__ void fused_solve(const FusedSolve &fs, const TAB &tab
 // accumulators (126 VGPRs) -- the slots cost no registers: six waves per SIMD as before.
 // sS: this thread's slot of sum 0; sum k lies k * PRIV_THREADS further (the kernel is launched with exactly that many
 // threads).  K = [k0c k1c k2c k0s k1s k2s] as k_step_sums.
-constexpr int PRIV_THREADS = 768;
+constexpr int PRIV_THREADS = STEP_PRIVATE_THREADS;
 template <int DIST, int MODE, int POW2>
 __device__ __forceinline__ double pred_one_private(const One &n, double p, int ix, double wl, const double *sAB, double *sS,
                                                    const StepArgsDev &a) {
@@ -521,12 +521,105 @@ __device__ __forceinline__ double pred_one_private(const One &n, double p, int i
   return t2;
 }
 
+#ifdef PIC1DP_TUNE_SUMS2
+// Tuning build -DPIC1DP_TUNE_SUMS2 (tools/ab_sums2.sh): the sums form for TWO kept modes -- the
+// projections of the predicted charge on both modes' tables, 2 x 2 x (1 + 2 x 2) = 20 sums per rank, in thread-private
+// slots of a workgroup of PRIV2_THREADS.  K[b][0] = sum q T_b(x'), K[b][1 + a] = sum c T_a(x) T_b(x') with
+// T = [A_0 B_0 A_1 B_1].  Only the marker kernel exists (its timing is what the experiment asks for): the solve still
+// reads the tiles' layout, so the fields of such a run mean nothing.
+#ifndef PIC1DP_PRIV2_THREADS
+#define PIC1DP_PRIV2_THREADS 512
+#endif
+constexpr int PRIV2_THREADS = PIC1DP_PRIV2_THREADS;
+template <int DIST, int MODE, int POW2>
+__device__ __forceinline__ double pred_one_private2(const One &n, double p, int ix, double wl, const double *sAB, double *sS,
+                                                    const StepArgsDev &a) {
+  constexpr int stride = PRIV2_THREADS;
+  const int nx = a.g.nx;
+  double t2 = 0.0;
+  double u[4] = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (MODE != MODE_FULLF) {
+    const double tmp1 = (MODE == MODE_DF_LIN) ? p : (p - n.w);
+    if constexpr (POW2 == 0) {
+      if (a.s.fastc) {
+        DivFast dv;
+        t2 = dlnf0<DIST, POW2>(n.v, a.s, dv);
+        if (!dv.ok()) {
+          DivTrue dt;
+          t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+        }
+      } else {
+        DivTrue dt;
+        t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+      }
+    } else {
+      DivTrue dt;
+      t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
+    }
+    const double c = tmp1 * t2 * (a.pred_k * a.s.Z);
+    const double *gl = sAB + 4 * ix;
+    const double wlr = 1.0 - wl;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const double2 tl = *reinterpret_cast<const double2 *>(gl + 2 * m), tr = *reinterpret_cast<const double2 *>(gl + 4 + 2 * m);
+      u[2 * m] = c * fma(tr.x, wlr, tl.x * wl);
+      u[2 * m + 1] = c * fma(tr.y, wlr, tl.y * wl);
+    }
+  }
+  const double xh = fma(a.dt_half, n.v, n.x);
+  const double sh = xh * a.snx;
+  const double fh = floor(sh);
+  int ih = static_cast<int>(fh);
+  const double wr = sh - fh, wh = 1.0 - wr;
+  ih = ih < 0 ? ih + nx : ih;
+  ih = ih >= nx ? ih - nx : ih;
+  if (static_cast<unsigned>(ih) >= static_cast<unsigned>(nx)) {
+    ih = ih % nx;
+    if (ih < 0) ih += nx;
+  }
+  const double *hl = sAB + 4 * ih;
+  const double q = a.s.Z * (MODE == MODE_FULLF ? p : n.w);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const double2 ul = *reinterpret_cast<const double2 *>(hl + 2 * m), ur = *reinterpret_cast<const double2 *>(hl + 4 + 2 * m);
+    const double T[2] = {fma(ur.x, wr, ul.x * wh), fma(ur.y, wr, ul.y * wh)};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double *s = sS + (5 * (2 * m + h)) * stride;
+      lds_add(s, q * T[h]);
+      if constexpr (MODE != MODE_FULLF) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds_add(s + (1 + k) * stride, u[k] * T[h]);
+      }
+    }
+  }
+  return t2;
+}
+#endif
+
+// the private sums of one marker: six for one kept mode (tuning build: twenty for two)
+template <int DIST, int MODE, int POW2, int NM>
+__device__ __forceinline__ double priv_sums(const One &n, double p, int ix, double wl, const double *sAB, double *sS,
+                                            const StepArgsDev &a) {
+#ifdef PIC1DP_TUNE_SUMS2
+  if constexpr (NM == 2) return pred_one_private2<DIST, MODE, POW2>(n, p, ix, wl, sAB, sS, a);
+#endif
+  return pred_one_private<DIST, MODE, POW2>(n, p, ix, wl, sAB, sS, a);
+}
+
 // T2: 0 no carry of -f0'/f0; 1 this step evaluates it, the next step's value is stored; 2 this
 // step's value is loaded (stored by the previous k_step_one), the next step's stored
 // NM: kept modes of the prediction tiles (1 .. 4); PRIV (NM = 1): six sums in thread-private slots instead
 template <int DIST, int MODE, int POW2, bool NT, int T2, int NM, bool PRIV = false, bool FUSED = false>
 __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
   static_assert(!FUSED || PRIV, "the fused solve serves the six-sum prediction");
+#ifdef PIC1DP_TUNE_SUMS2
+  constexpr int NS = NM == 2 ? 20 : 6, PT = NM == 2 ? PRIV2_THREADS : PRIV_THREADS;  // private sums, threads they are laid out for
+  static_assert(!FUSED || NM == 1, "");
+#else
+  constexpr int NS = 6, PT = PRIV_THREADS;
+  static_assert(!PRIV || NM == 1, "six sums: one kept mode");
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   STAMP(a, 0);
   STAMP_HWID(a);
@@ -563,9 +656,9 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     sE0[nx] = a.E0[0];
     sEh[nx] = a.Eh[0];
   }
-  unsigned *sDraw = reinterpret_cast<unsigned *>(sP + 6 * PRIV_THREADS);  // PRIV: the chunk counter of the drawn tail
+  unsigned *sDraw = reinterpret_cast<unsigned *>(sP + NS * PT);  // PRIV: the chunk counter of the drawn tail
   if constexpr (PRIV) {
-    for (int k = 0; k < 6; ++k) sP[k * PRIV_THREADS + threadIdx.x] = 0.0;
+    for (int k = 0; k < NS; ++k) sP[k * PT + threadIdx.x] = 0.0;
     if (threadIdx.x == 0) *sDraw = 0u;
   } else {
     for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
@@ -625,13 +718,13 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     const One n0 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.x, V.x, W.x, P.x, sE0, sEh, sR, a, T.x, &i0, &l0);
     double u0, u1;
     if constexpr (PRIV)
-      u0 = pred_one_private<DIST, MODE, POW2>(n0, P.x, i0, l0, sAB, sP + threadIdx.x, a);
+      u0 = priv_sums<DIST, MODE, POW2, NM>(n0, P.x, i0, l0, sAB, sP + threadIdx.x, a);
     else
       u0 = pred_one<DIST, MODE, POW2, NM>(n0, P.x, i0, l0, sAB, sP, a);
     PAIR_FENCE();
     const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y, &i1, &l1);
     if constexpr (PRIV)
-      u1 = pred_one_private<DIST, MODE, POW2>(n1, P.y, i1, l1, sAB, sP + threadIdx.x, a);
+      u1 = priv_sums<DIST, MODE, POW2, NM>(n1, P.y, i1, l1, sAB, sP + threadIdx.x, a);
     else
       u1 = pred_one<DIST, MODE, POW2, NM>(n1, P.y, i1, l1, sAB, sP, a);
     st2t<NT>(x2 + o, n0.x, n1.x);
@@ -651,7 +744,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     if constexpr (HAS_W) a.w[i] = n.w;
     double u;
     if constexpr (PRIV)
-      u = pred_one_private<DIST, MODE, POW2>(n, p, ic, lc, sAB, sP + threadIdx.x, a);
+      u = priv_sums<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP + threadIdx.x, a);
     else
       u = pred_one<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP, a);
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
@@ -664,6 +757,19 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   if constexpr (PRIV) {  // the six sums: wave k adds up the slots of sum k (12 reads per lane, a wave reduction), one
                          // global atomic each -- no barrier beyond the one above
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef PIC1DP_TUNE_SUMS2
+    if constexpr (NM == 2) {
+      for (int k = wave; k < NS; k += PT / 64) {
+        const double *s = sP + k * PT + lane;
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < PT / 64; ++j) t += s[64 * j];
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (lane == 0) glb_add(a.pred + (blockIdx.x % PRED_SUM_COPIES) * 24 + k, t);
+      }
+      return;
+    }
+#endif
     if (wave < 6) {
       const double *s = sP + wave * PRIV_THREADS + lane;
       double t = 0.0;
@@ -955,6 +1061,15 @@ hipError_t launch_step_one(const StepArgsDev &d, int t2m, const LaunchCfg &lc, h
     return d.nt ? launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, NM>, d, lc, st)
                 : launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, NM>, d, lc, st);
   }
+#ifdef PIC1DP_TUNE_SUMS2
+  if constexpr (NM == 2) {
+    if (d.sums2) {
+      if (t2m != 0) return hipErrorInvalidValue;
+      return d.nt ? launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 2, true>, d, lc, st)
+                  : launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 2, true>, d, lc, st);
+    }
+  }
+#endif
   if (d.nt) {
     if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, NM>, d, lc, st);
     if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, NM>, d, lc, st);

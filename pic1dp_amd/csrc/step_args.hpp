@@ -29,6 +29,9 @@ struct StepArgsDev {
   FusedSolve fused;             // kernels.hpp: the prologue solves the previous step's field
   StepTail tail;                // kernels.hpp: the last workgroup packs / posts this rank's charge
   int dyn_tail;                 // k_step_one<PRIV>: sixteenths of a workgroup's chunks drawn from an LDS counter
+#ifdef PIC1DP_TUNE_SUMS2  // tuning build (tools/ab_sums2.sh): two kept modes as twenty private sums (marker kernel only)
+  int sums2;
+#endif
 #ifdef PIC1DP_TUNE_STAMPS  // tuning build (tools/stamp_probe.sh): [gridDim][8] wall-clock stamps of the phases of a workgroup
   unsigned long long *stamps;
 #endif
