@@ -699,9 +699,6 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       lc = pred_launch(c, S.np, priv, nullptr);
 #ifdef PIC1DP_TUNE_SUMS2  // timing experiment only: the solve still reads the tiles' layout
       if (c->pred_kind == 1 && c->in.nmode == 2 && a.t2 == nullptr && std::getenv("PIC1DP_SUMS2")) {
-#ifndef PIC1DP_PRIV2_THREADS
-#define PIC1DP_PRIV2_THREADS 512
-#endif
         const size_t ne = static_cast<size_t>((c->in.nx + 2) & ~1);
         a.sums2 = 1;
         a.dyn_tail = c->dyn_tail;

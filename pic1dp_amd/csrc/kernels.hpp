@@ -265,6 +265,9 @@ inline size_t step_one_lds_bytes(int nx, int rcopies, int nm) {
 #ifndef PIC1DP_PRIV_THREADS
 #define PIC1DP_PRIV_THREADS 768  // (tuning builds: 1024 = one workgroup of sixteen waves per CU, tools/ab_variant_libs.sh)
 #endif
+#if defined(PIC1DP_TUNE_SUMS2) && !defined(PIC1DP_PRIV2_THREADS)
+#define PIC1DP_PRIV2_THREADS 512  // (tuning build: workgroup of the twenty-sum kernel for two kept modes, tools/ab_sums2.sh)
+#endif
 constexpr int STEP_PRIVATE_THREADS = PIC1DP_PRIV_THREADS;  // k_step_one<PRIV> is launched with exactly this many threads per workgroup
 inline size_t step_one_private_lds_bytes(int nx, int rcopies, int threads = STEP_PRIVATE_THREADS) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);

@@ -527,9 +527,6 @@ __device__ __forceinline__ double pred_one_private(const One &n, double p, int i
 // slots of a workgroup of PRIV2_THREADS.  K[b][0] = sum q T_b(x'), K[b][1 + a] = sum c T_a(x) T_b(x') with
 // T = [A_0 B_0 A_1 B_1].  Only the marker kernel exists (its timing is what the experiment asks for): the solve still
 // reads the tiles' layout, so the fields of such a run mean nothing.
-#ifndef PIC1DP_PRIV2_THREADS
-#define PIC1DP_PRIV2_THREADS 512
-#endif
 constexpr int PRIV2_THREADS = PIC1DP_PRIV2_THREADS;
 template <int DIST, int MODE, int POW2>
 __device__ __forceinline__ double pred_one_private2(const One &n, double p, int ix, double wl, const double *sAB, double *sS,
