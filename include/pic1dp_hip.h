@@ -525,6 +525,13 @@ int pic1dp_hip_kernel_bytes(pic1dp_ctx *ctx, int32_t which, double *read_bytes,
                             double *written_bytes, double *carry_bytes, char *name,
                             int32_t name_len);
 
+/* Debugging aid: checks the relations between the flags of the library's internal state machine (lazy call sites,
+ * prediction, call-site pair, accumulator sets: DESIGN.md 3.9) that have to hold between any two calls, whatever the
+ * calls were.  deep != 0 also synchronises and looks at device memory (accumulator sets nobody owes anything to are
+ * zero).  PIC1DP_ERR_STATE + pic1dp_hip_last_error() name the relation that does not hold.  Replaces nothing in the
+ * reference; the randomised call-sequence tests call it after every call. */
+int pic1dp_hip_check_state(pic1dp_ctx *ctx, int32_t deep);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,7 @@ SIGNATURES = {
     "pic1dp_hip_check_termination": [_P, C.POINTER(C.c_int32)],
     "pic1dp_hip_output_due": [_P, C.c_int32, C.POINTER(C.c_int32)],
     "pic1dp_hip_steps_to_output": [_P, C.POINTER(C.c_int32)],
+    "pic1dp_hip_check_state": [_P, C.c_int32],
     "pic1dp_hip_output_all": [_P, _P, C.c_int32, _P, _P, _P, _P, _P],
     "pic1dp_hip_get_field": [_P, _P, _P, _P, _P],
     "pic1dp_hip_chargeden_state": [_P, C.POINTER(C.c_int32)],

@@ -1017,6 +1017,89 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// pic1dp_hip_check_state: the relations between the flags of the state machine above (the table of
+// invariants) checked at an API boundary -- between two calls of the library every one of them has to hold, whatever the
+// calls were.  deep != 0 also looks at device memory (one stream synchronisation and small copies): the accumulator sets
+// nobody owes anything to are zero, the tail's ticket is back at zero.  A debugging aid and what the randomised call-
+// sequence tests call after EVERY call (tests/test_gpu_fuzz.py); nothing on the hot path calls it.
+// ---------------------------------------------------------------------------
+int pic1dp_hip_check_state(pic1dp_ctx *c, int32_t deep) {
+  CHECK_CTX(c);
+#define INVARIANT(cond)                                                                                   \
+  do {                                                                                                    \
+    if (!(cond))                                                                                          \
+      return fail(PIC1DP_ERR_STATE, "state invariant violated: %s (lz %d cd_lazy %d half_pair %d half_solved %d)", #cond, \
+                  c->lz, c->cd_lazy, int(c->half_pair), int(c->half_solved));                             \
+  } while (0)
+  const bool one_rank = c->lay.nranks == 1 && c->comm == nullptr;
+  INVARIANT(c->lz >= LZ_CLEAN && c->lz <= LZ_PUSH2);
+  INVARIANT(c->lz == LZ_CLEAN || c->lazy_calls);                     // a push is only noted by the lazy call sites
+  INVARIANT(c->lz == LZ_CLEAN || c->loaded);
+  INVARIANT(c->cd_lazy >= 0 && c->cd_lazy <= 5);
+  INVARIANT(c->cd_lazy == 0 || c->lazy_calls);
+  INVARIANT(c->cd_lazy < 2 || one_rank);                             // species sum / prediction left to solve_field: one rank
+  INVARIANT(c->cd_lazy != 3 || c->pred_kind == 1);                   // tiles to combine
+  INVARIANT(c->cd_lazy != 4 || c->pred_kind == 2);                   // six sums to turn into the kept mode's chargeden
+  // the call sites' pair (ctx.hpp half_pair)
+  INVARIANT(!c->half_solved || c->half_pair);
+  INVARIANT(!c->half_pair || (c->lz == LZ_HALF || c->lz == LZ_PUSH2));
+  INVARIANT(!c->half_pair || (one_rank && c->call_pair && c->pred_kind == 2 && c->in.nmode == 1));
+  // (5 outlives half_pair when an inspection settles before solve_field has been called: the field is then adopted by copying)
+  INVARIANT(c->cd_lazy != 5 || (!c->half_solved && c->pred_kind == 2 && c->in.nmode == 1));
+  INVARIANT(!c->half_pair || (c->eh_version == c->state_version));   // the field in d_Ehn belongs to the state in memory
+  INVARIANT(!c->cd_kept_mode_only || c->pred_kind == 2);
+  // whole-step path: nothing of a step() is left over between calls
+  INVARIANT(!c->fused_pending);
+  INVARIANT(c->fuse_args.on == 0);
+  INVARIANT(c->fused_dirty == -1);
+  INVARIANT(c->tail_done == 0);
+  INVARIANT(c->acc_idx >= 0 && c->acc_idx < 3);
+  // versions only ever point backwards
+  INVARIANT(c->pred_version <= c->state_version);
+  INVARIANT(c->eh_version <= c->state_version);
+  INVARIANT(c->eh_field_version <= c->field_version);
+  INVARIANT(c->modes_field_version <= c->field_version);
+  INVARIANT(c->eh_modes >= 0 && c->eh_modes <= 2);
+  for (int s = 0; s < c->in.nspecies; ++s) {
+    if (static_cast<size_t>(s) < c->diag_version.size()) INVARIANT(c->diag_version[s] <= c->state_version);  // (sized by the first diagnostics call)
+    INVARIANT(c->sp[s].t2_version <= c->state_version);
+  }
+  INVARIANT(!c->charge_pending_pred || c->charge_pending);
+  if (!deep) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  unsigned ticket = 0;
+  HIP_TRY(hipMemcpy(&ticket, c->d_ticket, sizeof ticket, hipMemcpyDeviceToHost));
+  INVARIANT(ticket == 0u);
+  // accumulators: the sets the marker kernels do not deposit into are zero; the current one holds something only while
+  // a collect_charge has left its end to solve_field (cd_lazy 2, 3: deposits; with a usable prediction: the six sums / tiles)
+  auto nonzero = [](const std::vector<double> &v, size_t off, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+      if (v[off + i] != 0.0) return true;  // (NaN != 0: a poisoned accumulator counts)
+    return false;
+  };
+  std::vector<double> h(3 * c->rho_set_doubles);
+  HIP_TRY(hipMemcpy(h.data(), c->d_rho_all, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 3; ++k) {
+    const bool nz = nonzero(h, k * c->rho_set_doubles, c->rho_set_doubles);
+    if (k != c->acc_idx) INVARIANT(!nz && "a species accumulator set that is not the current one holds deposits");
+    else if (c->cd_lazy != 2 && c->cd_lazy != 3 && !c->charge_pending) INVARIANT(!nz && "deposits nobody is going to sum");
+  }
+  if (c->d_pred_all && c->pred_set_doubles) {
+    h.assign(3 * c->pred_set_doubles, 0.0);
+    HIP_TRY(hipMemcpy(h.data(), c->d_pred_all, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) {
+      const bool nz = nonzero(h, k * c->pred_set_doubles, c->pred_set_doubles);
+      if (k != c->acc_idx) INVARIANT(!nz && "a prediction accumulator set that is not the current one holds sums");
+      else if (c->pred_version == 0 && c->cd_lazy != 3 && c->cd_lazy != 4 && !c->charge_pending)
+        INVARIANT(!nz && "prediction sums that belong to no state");
+    }
+  }
+#undef INVARIANT
+  return 0;
+}
+
 int pic1dp_hip_set_step_mode(pic1dp_ctx *c, int32_t mode) {
   CHECK_CTX(c);
   if (mode != 0 && mode != 1) return fail(PIC1DP_ERR_ARG, "step mode must be 0 or 1");

@@ -220,6 +220,12 @@ class Pic1dp:
         check(self.L.pic1dp_hip_steps_to_output(self._ctx, C.byref(n)))
         return n.value
 
+    def check_state(self, deep=True):
+        """debugging aid: the relations between the flags of the library's state machine that hold between any two
+        calls; deep also looks at the device's accumulator sets.  Raises Pic1dpError naming the
+        relation that does not hold."""
+        check(self.L.pic1dp_hip_check_state(self._ctx, 1 if deep else 0))
+
     # -- field access -------------------------------------------------------------
     def get_field(self, chargeden=True):
         """field_electric, field_chargeden, field_mode_re / _im (src/pic1dp_field.F90:27-31).  chargeden=False

@@ -272,6 +272,12 @@ interface
     integer(c_int32_t), intent(out) :: nsteps
     integer(c_int) :: ierr
   end function pic1dp_hip_steps_to_output
+  function pic1dp_hip_check_state(ctx, deep) bind(C, name="pic1dp_hip_check_state") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: deep
+    integer(c_int) :: ierr
+  end function pic1dp_hip_check_state
   function pic1dp_hip_get_field(ctx, electric, chargeden, mode_re, mode_im) bind(C, name="pic1dp_hip_get_field") result(ierr)
     import
     type(c_ptr), value :: ctx

@@ -22,10 +22,35 @@ def oracle_mod():
     return oracle
 
 
+def _check_state_after_every_call(cls):
+    """every public method of the engine is followed by pic1dp_hip_check_state (host side only: no device work, no
+    synchronisation): the relations between the flags of the library's state machine are asserted at
+    every API boundary of every test, not only where a wrong result would show"""
+    import functools
+    import inspect
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def call(self, *a, **k):
+            out = fn(self, *a, **k)
+            if getattr(self, "_ctx", None):
+                self.check_state(False)
+            return out
+        return call
+
+    for name, fn in list(vars(cls).items()):
+        if name.startswith("_") or name in ("check_state", "close") or not inspect.isfunction(fn):
+            continue
+        setattr(cls, name, wrap(fn))
+    cls._state_checked = True
+
+
 @pytest.fixture(scope="session")
 def amd():
     """the product package; importing it loads libpic1dp_hip.so or fails loudly"""
     import pic1dp_amd
+    if not getattr(pic1dp_amd.Pic1dp, "_state_checked", False):
+        _check_state_after_every_call(pic1dp_amd.Pic1dp)
     return pic1dp_amd
 
 

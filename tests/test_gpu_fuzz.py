@@ -22,6 +22,26 @@ def seeds(n):
     return range(_BASE, _BASE + n * _MULT)
 
 
+class Checked:
+    """an engine whose every call is followed by pic1dp_hip_check_state(deep): the relations between the flags of the
+    state machine and the zeroness of the accumulator sets nobody owes anything to, asserted at
+    every API boundary of a random call sequence"""
+
+    def __init__(self, eng):
+        self._eng = eng
+
+    def __getattr__(self, name):
+        attr = getattr(self._eng, name)
+        if not callable(attr) or name in ("check_state", "close"):
+            return attr
+
+        def call(*a, **k):
+            out = attr(*a, **k)
+            self._eng.check_state(True)
+            return out
+        return call
+
+
 def random_case(rng):
     nsp = int(rng.integers(1, 4))
     nx = int(rng.choice([2, 3, 17, 64, 100, 192, 255, 512, 1000, 2048]))
@@ -115,7 +135,7 @@ def test_random_call_sequences_lazy_equals_eager(amd, monkeypatch, seed):
     engines = []
     for lazy in ("1", "0"):
         monkeypatch.setenv("PIC1DP_LAZY_CALLS", lazy)
-        e = amd.Pic1dp(amd.make_input(**kw))
+        e = Checked(amd.Pic1dp(amd.make_input(**kw)))
         e.particle_load()
         e.interaction_collect_charge()
         e.field_solve_electric()
@@ -196,10 +216,10 @@ def test_random_call_sequences_predicted_equals_two_pass(amd, monkeypatch, seed,
     if rng.random() < 0.3:
         kw.update(species_temperature=[1.3], species_temperature2=[0.7], species_mass=[1.1])
     monkeypatch.setenv("PIC1DP_PRED_KIND", str(kind))
-    a = amd.Pic1dp(amd.make_input(**kw))
+    a = Checked(amd.Pic1dp(amd.make_input(**kw)))
     monkeypatch.setenv("PIC1DP_LAZY_CALLS", "0")
     monkeypatch.setenv("PIC1DP_PREDICT", "0")
-    b = amd.Pic1dp(amd.make_input(**kw))
+    b = Checked(amd.Pic1dp(amd.make_input(**kw)))
     monkeypatch.delenv("PIC1DP_LAZY_CALLS")
     monkeypatch.delenv("PIC1DP_PREDICT")
     assert a.predict_kind() == kind and b.predict_kind() == 0
