@@ -425,7 +425,8 @@ int pic1dp_hip_substep(pic1dp_ctx *c, int32_t irk) {
 // LDS bytes of the whole-step kernels: E0 tile, Eh tile (full only), rho tile
 size_t pic1dp_host::step_lds_bytes(int nx, bool full, int rcopies) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
-  return sizeof(double) * ((full ? 2 : 1) * ne + ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)));
+  return sizeof(double) * ((full ? 2 : 1) * ne + ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) +
+                           2);  // (+ the drawn chunks' counter, 16-byte slot)
 }
 
 static bool step_recompute_ok(const pic1dp_ctx *c) {
@@ -644,6 +645,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     a.deltaf = c->in.deltaf;
     a.linear = c->in.linear;
     a.stream_nt = stream_nt;
+    a.dyn_tail = c->dyn_tail;  // the drawn chunk tail of every whole-step kernel
     // a species with general divisor constants and an exp-bearing f0 is FP64-issue-bound: its
     // -f0'/f0 at the step-start velocity goes from the first kernel to the second through
     // memory (8 B per marker) instead of being evaluated twice.  Measured at 1e8 markers
@@ -676,7 +678,6 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
                                  : c->d_pred + static_cast<size_t>(s) * (1 + 2 * c->in.nmode) * c->in.nx;
       a.pred_nm = c->in.nmode;
       a.pred_private = priv ? 1 : 0;
-      a.dyn_tail = c->pred_kind == 2 ? c->dyn_tail : 0;  // (k_step_one<PRIV>, k_step_sums)
       if (c->pred_kind == 2) {
         a.eh_re = c->eh_modes == 2 ? c->d_mode_h : c->fa.mode_re;
         a.eh_im = c->eh_modes == 2 ? c->d_mode_h + 1 : c->fa.mode_im;

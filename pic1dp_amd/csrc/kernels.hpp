@@ -238,7 +238,7 @@ struct StepArgs {
   const double *eh_re, *eh_im;
   FusedSolve fused;  // pred_kind 2 only: the prologue solves the previous step's field (E0, Eh, eh_re / eh_im unused)
   StepTail tail;     // pred_kind 2 only, several ranks: the last workgroup packs / posts this rank's charge (mode 0: no)
-  int dyn_tail;      // k_step_one<PRIV>, k_step_sums: sixteenths of a workgroup's chunks that its waves draw from an LDS counter (0: all dealt)
+  int dyn_tail;      // every whole-step kernel: sixteenths of a workgroup's chunks that its waves draw from an LDS counter (0: all dealt)
 #ifdef PIC1DP_TUNE_SUMS2
   int sums2;         // tuning build: two kept modes as twenty private sums (marker kernel only, tools/ab_sums2.sh)
 #endif
@@ -258,7 +258,7 @@ inline size_t step_one_lds_bytes(int nx, int rcopies, int nm) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
   return sizeof(double) * (2 * ne + (static_cast<size_t>(nx) + 1) * 2 * nm +
                            ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) +
-                           (static_cast<size_t>(nx) + 2) * (1 + 2 * nm));
+                           (static_cast<size_t>(nx) + 2) * (1 + 2 * nm) + 2);  // (+ the drawn chunks' counter)
 }
 // dynamic LDS of k_step_one<PRIV>: E0, Eh tiles, the one mode's tables cell by cell (nx + 1 cells of 2), rho copies,
 // six private sums per thread, reduction scratch

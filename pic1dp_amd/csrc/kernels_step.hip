@@ -63,6 +63,39 @@ namespace {
 // FP64 rate at the HBM-bound pace).
 // ---------------------------------------------------------------------------
 
+// The workgroup's pairs: row k = pairs (blockIdx + k gridDim) blockDim ... of the grid-stride split.  `dealt` rows go to
+// its threads as they stand; the 64-pair chunks of the remaining rows (StepArgs::dyn_tail sixteenths of them) are DRAWN:
+// every wave takes the next one from a counter in the LDS (one ds_add_rtn_u32 per chunk, no device-scope traffic), so the
+// waves that run ahead take more and the workgroup meets its final barrier together (round 5: the skew between a
+// workgroup's waves was worth 1.4-4.7 % of k_step_one<PRIV>, which has this loop spelled out for its register budget).
+struct PairRows {
+  int64_t first, stride;
+  int dealt, drawn_total;
+};
+__device__ __forceinline__ PairRows pair_rows(int64_t npair, int dyn_tail) {
+  PairRows r;
+  r.first = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  r.stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  r.dealt = r.first < npair ? static_cast<int>((npair - r.first + r.stride - 1) / r.stride) : 0;
+  r.drawn_total = 0;
+  if (dyn_tail > 0) {
+    const int drawn_rows = (r.dealt * dyn_tail) >> 4;
+    r.dealt -= drawn_rows;
+    r.drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
+  }
+  return r;
+}
+// the pair of this lane in the next drawn chunk, or false: the workgroup's pairs are exhausted (wave-uniform)
+__device__ __forceinline__ bool draw_chunk(const PairRows &r, unsigned *ctr, int64_t &j) {
+  int c = 0;
+  if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  c = __builtin_amdgcn_readfirstlane(c);
+  if (c >= r.drawn_total) return false;
+  const int waves = static_cast<int>(blockDim.x >> 6);
+  j = r.first + static_cast<int64_t>(r.dealt + c / waves) * r.stride + (c % waves) * 64 + (threadIdx.x & 63);
+  return true;
+}
+
 // CARRY: a species whose divisor constants are general numbers spends most of either kernel
 // in -f0'/f0 (two exp, eight constant divisions, one true division: FP64-issue-bound).  The
 // second kernel evaluates it twice -- at the step-start velocity again, to recompute the
@@ -80,19 +113,26 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   double *sE = reinterpret_cast<double *>(smem);
   const int nx = a.g.nx;
   double *sR0 = sE + ((nx + 2) & ~1);
+  unsigned *sDraw = reinterpret_cast<unsigned *>(sR0 + ((nx * a.g.rcopies + 2) & ~1));  // the drawn chunks' counter
   for (int i = threadIdx.x; i < nx; i += blockDim.x) sE[i] = a.E0[i];
   zero_rho(sR0, a.g);
-  if (threadIdx.x == 0) sE[nx] = a.E0[0];
+  if (threadIdx.x == 0) {
+    sE[nx] = a.E0[0];
+    *sDraw = 0u;
+  }
   __syncthreads();
   double *sR = my_rho_copy(sR0, a.g);
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   const int64_t npair = a.np >> 1;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   const double2 *x2 = reinterpret_cast<const double2 *>(a.x);
   const double2 *v2 = reinterpret_cast<const double2 *>(a.v);
   const double2 *w2 = reinterpret_cast<const double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
-  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+  const PairRows rows = pair_rows(npair, a.dyn_tail);
+  int64_t j = rows.first + threadIdx.x;
+  for (int k = 0;; ++k, j += rows.stride) {
+    if (k >= rows.dealt && !draw_chunk(rows, sDraw, j)) break;
+    if (j >= npair) continue;
     const int64_t o = tidx2(j);
     const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0);
@@ -157,22 +197,27 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   }
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
-  // DIAG: histograms behind the rho copies (16-byte aligned), then the block_sum scratch
-  double *sH = sR0 + ((nx * a.g.rcopies + 2) & ~1);
+  // behind the rho copies (16-byte aligned): the drawn chunks' counter; DIAG: the histograms, then the block_sum scratch
+  unsigned *sDraw = reinterpret_cast<unsigned *>(sR0 + ((nx * a.g.rcopies + 2) & ~1));
+  double *sH = sR0 + ((nx * a.g.rcopies + 2) & ~1) + 2;
   const int ntot = DIAG ? 3 * a.dg.nxo * a.dg.nvo + 3 * a.dg.nvo : 0;
   const DistBins bins{sH, a.dg.nxo * a.dg.nvo, a.dg.nvo};
   DistSums sums;
   if constexpr (DIAG)
     for (int i = threadIdx.x; i < ntot; i += blockDim.x) sH[i] = 0.0;
+  if (threadIdx.x == 0) *sDraw = 0u;
   __syncthreads();
   double *sR = my_rho_copy(sR0, a.g);
   const int64_t npair = a.np >> 1;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   double2 *x2 = reinterpret_cast<double2 *>(a.x);
   double2 *v2 = reinterpret_cast<double2 *>(a.v);
   double2 *w2 = reinterpret_cast<double2 *>(a.w);
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
-  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < npair; j += stride) {
+  const PairRows rows = pair_rows(npair, a.dyn_tail);
+  int64_t j = rows.first + threadIdx.x;
+  for (int k = 0;; ++k, j += rows.stride) {
+    if (k >= rows.dealt && !draw_chunk(rows, sDraw, j)) break;
+    if (j >= npair) continue;
     const int64_t o = tidx2(j);
     const double2 X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     double2 W = make_double2(0.0, 0.0);
@@ -653,13 +698,13 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     sE0[nx] = a.E0[0];
     sEh[nx] = a.Eh[0];
   }
-  unsigned *sDraw = reinterpret_cast<unsigned *>(sP + NS * PT);  // PRIV: the chunk counter of the drawn tail
+  unsigned *sDraw = reinterpret_cast<unsigned *>(PRIV ? sP + NS * PT : sP + np1 * (nx + 2));  // the chunk counter of the drawn tail
   if constexpr (PRIV) {
     for (int k = 0; k < NS; ++k) sP[k * PT + threadIdx.x] = 0.0;
-    if (threadIdx.x == 0) *sDraw = 0u;
   } else {
     for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
   }
+  if (threadIdx.x == 0) *sDraw = 0u;
   __syncthreads();
   STAMP(a, 1);
   double *sR = my_rho_copy(sR0, a.g);
@@ -675,32 +720,27 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   const double2 *p2 = reinterpret_cast<const double2 *>(a.p);
   double2 *t2 = reinterpret_cast<double2 *>(a.t2);
   // The workgroup's pairs: row k = pairs (blockIdx + k gridDim) blockDim ..., dealt to its threads (static grid stride).
-  // Tuning (PIC1DP_DYN_TAIL): the last dyn_tail / 16 of the rows are not dealt but DRAWN -- every wave
+  // (PIC1DP_DYN_TAIL; pair_rows / draw_chunk above, spelled out here for this kernel's register budget):
+  // the last dyn_tail / 16 of the rows are not dealt but DRAWN -- every wave
   // takes the next 64-pair chunk of them from a counter in the LDS (one ds_add_rtn_u32 per chunk, no device-scope traffic),
   // so that the waves that run ahead take more and the workgroup meets its final barrier together.
   const int64_t first = static_cast<int64_t>(blockIdx.x) * blockDim.x;
   int dealt = first < npair ? static_cast<int>((npair - first + stride - 1) / stride) : 0;  // rows of this workgroup
   int drawn_total = 0;
-  if constexpr (PRIV) {
-    if (a.dyn_tail > 0) {
-      const int drawn_rows = (dealt * a.dyn_tail) >> 4;
-      dealt -= drawn_rows;
-      drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
-    }
+  if (a.dyn_tail > 0) {
+    const int drawn_rows = (dealt * a.dyn_tail) >> 4;
+    dealt -= drawn_rows;
+    drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
   }
   int64_t j = first + threadIdx.x;
   for (int k = 0;; ++k, j += stride) {
-    if constexpr (PRIV) {
-      if (k >= dealt) {
-        int c = 0;
-        if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(sDraw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= drawn_total) break;
-        const int waves = static_cast<int>(blockDim.x >> 6);
-        j = first + static_cast<int64_t>(dealt + c / waves) * stride + (c % waves) * 64 + (threadIdx.x & 63);
-      }
-    } else {
-      if (k >= dealt) break;
+    if (k >= dealt) {
+      int c = 0;
+      if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(sDraw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      c = __builtin_amdgcn_readfirstlane(c);
+      if (c >= drawn_total) break;
+      const int waves = static_cast<int>(blockDim.x >> 6);
+      j = first + static_cast<int64_t>(dealt + c / waves) * stride + (c % waves) * 64 + (threadIdx.x & 63);
     }
     if (j >= npair) continue;
     const int64_t o = tidx2(j);

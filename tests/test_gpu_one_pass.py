@@ -344,7 +344,7 @@ def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind)
 @pytest.mark.parametrize("kw,kind", [
     (dict(nx=2542), 1), (dict(nx=2543), 2),                                   # the last grid the tiles hold, the first for the sums
     (dict(nx=1694, nmode=2, modes=[1, 3]), 1), (dict(nx=1695, nmode=2, modes=[1, 3]), 0),
-    (dict(nx=1016, nmode=4, modes=[1, 2, 3, 5]), 1), (dict(nx=1017, nmode=4, modes=[1, 2, 3, 5]), 0),
+    (dict(nx=1015, nmode=4, modes=[1, 2, 3, 5]), 1), (dict(nx=1016, nmode=4, modes=[1, 2, 3, 5]), 0),
     (dict(nx=5063), 2), (dict(nx=5064), 0)],                                  # the last grid for the sums, then two passes
     ids=["tiles_last", "sums_first", "two_modes_last", "two_modes_beyond", "four_modes_last", "four_modes_beyond", "sums_last",
          "beyond"])
