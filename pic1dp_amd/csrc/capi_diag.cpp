@@ -77,7 +77,7 @@ static int run_diag_pass(pic1dp_ctx *c, int isp, bool fixed, bool *was_fixed) {
     bw = c->diag_fx_margin_w * c->diag_max_w[isp];
   }
   c->diag_blocks[isp] = ptcldist_blocks(S.np, in.nx_opd, in.nv_opd, c->num_cu);
-  HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, dist_geom(c), in.deltaf == 1, bp, bw, hist, part_dev, c->num_cu, c->st,
+  HIP_TRY(launch_ptcldist(A.x, A.v, S.p, A.w, S.np, dist_geom(c), in.deltaf == 1, bp, bw, hist, part_dev, c->num_cu, c->dyn_tail, c->st,
                           was_fixed));
   c->diag_passes++;
   if (*was_fixed) c->diag_fx_passes++;

@@ -506,6 +506,40 @@ __device__ __forceinline__ double deposit_one(double x, double q, double *sR, co
   return px;
 }
 
+// The workgroup's pairs: row k = pairs (blockIdx + k gridDim) blockDim ... of the grid-stride split.  `dealt` rows go to
+// its threads as they stand; the 64-pair chunks of the remaining rows (StepArgs::dyn_tail sixteenths of them) are DRAWN:
+// every wave takes the next one from a counter in the LDS (one ds_add_rtn_u32 per chunk, no device-scope traffic), so the
+// waves that run ahead take more and the workgroup meets its final barrier together (round 5: the skew between a
+// workgroup's waves was worth 1.4-4.7 % of k_step_one<PRIV>, which has this loop spelled out for its register budget).
+// Used by k_step_half, k_step_full, the tiles' k_step_one (kernels_step.hip) and k_ptcldist (kernels_diag.hip).
+struct PairRows {
+  int64_t first, stride;
+  int dealt, drawn_total;
+};
+__device__ __forceinline__ PairRows pair_rows(int64_t npair, int dyn_tail) {
+  PairRows r;
+  r.first = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  r.stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  r.dealt = r.first < npair ? static_cast<int>((npair - r.first + r.stride - 1) / r.stride) : 0;
+  r.drawn_total = 0;
+  if (dyn_tail > 0) {
+    const int drawn_rows = (r.dealt * dyn_tail) >> 4;
+    r.dealt -= drawn_rows;
+    r.drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
+  }
+  return r;
+}
+// the pair of this lane in the next drawn chunk, or false: the workgroup's pairs are exhausted (wave-uniform)
+__device__ __forceinline__ bool draw_chunk(const PairRows &r, unsigned *ctr, int64_t &j) {
+  int c = 0;
+  if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  c = __builtin_amdgcn_readfirstlane(c);
+  if (c >= r.drawn_total) return false;
+  const int waves = static_cast<int>(blockDim.x >> 6);
+  j = r.first + static_cast<int64_t>(r.dealt + c / waves) * r.stride + (c % waves) * 64 + (threadIdx.x & 63);
+  return true;
+}
+
 // The workgroup's LDS copy of rho may be replicated (g.rcopies = 1, 2, 4 or 8 copies,
 // lane l deposits into copy l % rcopies): neighbouring lanes of a wave that hit the same
 // cell then hit different addresses, which matters for small grids (at nx = 192 a wave's

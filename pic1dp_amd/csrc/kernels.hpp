@@ -367,7 +367,7 @@ hipError_t launch_tile_copy(double *dst, const double *src, int64_t n, hipStream
 // bound_p, bound_w > 0: the (x, v) histograms as 64-bit fixed-point sums in the LDS (device_diag.hpp DistScale)
 hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
                            int64_t np, const DistGeom &dg, bool deltaf, double bound_p, double bound_w,
-                           double *out, double *partial, int num_cu, hipStream_t st, bool *fixed_point);
+                           double *out, double *partial, int num_cu, int dyn_tail, hipStream_t st, bool *fixed_point);
 int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu);
 // ---- marker optimisation events (kernels_opt.hip; host side of the sequential part: optimize.hpp plan_*) ----
 // one reference rank block of a species inside the species' packed (tiled) arrays: block-local marker i lies at global

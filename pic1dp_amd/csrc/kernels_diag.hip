@@ -82,39 +82,49 @@ namespace {
 template <bool LDS, bool DELTAF, bool NT, bool FX>
 __global__ void __launch_bounds__(1024)
 k_ptcldist(const double *x, const double *v, const double *p, const double *w, int64_t np, const DistGeom dg,
-           double *out, double *partial, const DistScale fx) {
+           double *out, double *partial, const DistScale fx, int dyn_tail) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntot = 3 * dg.nxo * dg.nvo + 3 * dg.nvo;
   DistBins b{LDS ? reinterpret_cast<double *>(smem) : out, dg.nxo * dg.nvo, dg.nvo};
   double *scr = reinterpret_cast<double *>(smem) + (LDS ? ntot : 0);  // [16]
-  if constexpr (LDS) {
+  unsigned *sDraw = reinterpret_cast<unsigned *>(scr + 16);            // the drawn chunks' counter
+  if constexpr (LDS)
     for (int i = threadIdx.x; i < ntot; i += blockDim.x) b.h[i] = 0.0;
-    __syncthreads();
-  }
+  if (threadIdx.x == 0) *sDraw = 0u;
+  __syncthreads();
   const int64_t npair = np >> 1;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   const double2 *x2 = reinterpret_cast<const double2 *>(x), *v2 = reinterpret_cast<const double2 *>(v);
   const double2 *p2 = reinterpret_cast<const double2 *>(p), *w2 = reinterpret_cast<const double2 *>(w);
   DistSums sm;
-  int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  // the workgroup's rows of pairs, the last dyn_tail / 16 of them drawn chunk by chunk by its waves (device_math.hpp
+  // pair_rows): with one workgroup of sixteen waves per CU, the waves that are done would idle a quarter of the CU each
+  const PairRows rows = pair_rows(npair, dyn_tail);
+  int k = 0;
+  int64_t j = rows.first + threadIdx.x;
+  bool have = rows.dealt > 0 || draw_chunk(rows, sDraw, j);
   double2 X = make_double2(0.0, 0.0), V = X, P = X, W = X;
-  if (j < npair) {
+  if (have && j < npair) {
     const int64_t o = tidx2(j);
     X = ld2t<NT>(x2 + o), V = ld2t<NT>(v2 + o), P = ld2t<NT>(p2 + o);
     if constexpr (DELTAF) W = ld2t<NT>(w2 + o);
   }
-  while (j < npair) {
-    const int64_t jn = j + stride;
+  while (have) {
+    int64_t jn = j + rows.stride;
+    bool have_n = true;
+    if (++k >= rows.dealt) have_n = draw_chunk(rows, sDraw, jn);
     double2 Xn = make_double2(0.0, 0.0), Vn = Xn, Pn = Xn, Wn = Xn;
-    if (jn < npair) {  // the next trip's loads are under way while this trip's atomics run
+    if (have_n && jn < npair) {  // the next trip's loads are under way while this trip's atomics run
       const int64_t o = tidx2(jn);
       Xn = ld2t<NT>(x2 + o), Vn = ld2t<NT>(v2 + o), Pn = ld2t<NT>(p2 + o);
       if constexpr (DELTAF) Wn = ld2t<NT>(w2 + o);
     }
-    ptcldist_one<LDS, DELTAF, FX>(X.x, V.x, P.x, W.x, dg, b, sm, &fx);
-    ptcldist_one<LDS, DELTAF, FX>(X.y, V.y, P.y, W.y, dg, b, sm, &fx);
+    if (j < npair) {
+      ptcldist_one<LDS, DELTAF, FX>(X.x, V.x, P.x, W.x, dg, b, sm, &fx);
+      ptcldist_one<LDS, DELTAF, FX>(X.y, V.y, P.y, W.y, dg, b, sm, &fx);
+    }
     X = Xn, V = Vn, P = Pn, W = Wn;
     j = jn;
+    have = have_n;
   }
   if ((np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = tidx(np - 1);
@@ -139,11 +149,11 @@ int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu) {
 // the pass then sums in doubles.  partial: [blocks][6] = the kinetic sums, max |p|, max |w|, overflow flag per workgroup
 hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
                            int64_t np, const DistGeom &dg, bool deltaf, double bound_p, double bound_w,
-                           double *out, double *partial, int num_cu, hipStream_t st, bool *fixed_point) {
+                           double *out, double *partial, int num_cu, int dyn_tail, hipStream_t st, bool *fixed_point) {
   const int nxo = dg.nxo, nvo = dg.nvo;
   const size_t hist = sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo));
   const bool lds = hist <= 150 * 1024;
-  const size_t bytes = (lds ? hist : 0) + 16 * sizeof(double);  // + block_sum scratch
+  const size_t bytes = (lds ? hist : 0) + 18 * sizeof(double);  // + block_sum scratch + the drawn chunks' counter
   const int threads = 1024;
   const int blocks = ptcldist_blocks(np, nxo, nvo, num_cu);
   // x, v, p, w against the 256 MiB Infinity Cache: beyond it the pass streams (PIC1DP_DIAG_NT=0 / 1 insists)
@@ -175,7 +185,7 @@ hipError_t launch_ptcldist(const double *x, const double *v, const double *p, co
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(threads), bytes, st, x, v, p, w, np, dg, out,
-                       partial, fx);
+                       partial, fx, dyn_tail);
     return hipGetLastError();
   };
   if (use_fx) {
