@@ -646,6 +646,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     a.linear = c->in.linear;
     a.stream_nt = stream_nt;
     a.dyn_tail = c->dyn_tail;  // the drawn chunk tail of every whole-step kernel
+    a.wave_prio = c->wave_prio;
     // a species with general divisor constants and an exp-bearing f0 is FP64-issue-bound: its
     // -f0'/f0 at the step-start velocity goes from the first kernel to the second through
     // memory (8 B per marker) instead of being evaluated twice.  Measured at 1e8 markers

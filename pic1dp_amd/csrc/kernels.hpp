@@ -238,6 +238,7 @@ struct StepArgs {
   const double *eh_re, *eh_im;
   FusedSolve fused;  // pred_kind 2 only: the prologue solves the previous step's field (E0, Eh, eh_re / eh_im unused)
   StepTail tail;     // pred_kind 2 only, several ranks: the last workgroup packs / posts this rank's charge (mode 0: no)
+  int wave_prio;     // k_step_one, k_step_sums (experiment, PIC1DP_WAVE_PRIO): a wave's issue priority falls with its progress
   int dyn_tail;      // every whole-step kernel: sixteenths of a workgroup's chunks that its waves draw from an LDS counter (0: all dealt)
 #ifdef PIC1DP_TUNE_SUMS2
   int sums2;         // tuning build: two kept modes as twenty private sums (marker kernel only, tools/ab_sums2.sh)

@@ -699,8 +699,21 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     dealt -= drawn_rows;
     drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
   }
+  // PIC1DP_WAVE_PRIO (experiment): a wave's issue priority falls with its progress (quarters of its trips), so that of the
+  // two workgroups that share a CU the one that is behind wins the issue slots -- they stay together instead of the older
+  // one finishing a third earlier and the younger one running the last stretch alone at half the occupancy
+  const int trips_q = a.wave_prio ? max(1, (dealt + (drawn_total / max(1, static_cast<int>(blockDim.x >> 6))) + 3) >> 2) : 0;
+  int next_q = 0;
+  if (a.wave_prio) __builtin_amdgcn_s_setprio(3);
   int64_t j = first + threadIdx.x;
   for (int k = 0;; ++k, j += stride) {
+    if (a.wave_prio && k >= next_q) {  // (wave-uniform)
+      next_q += trips_q;
+      const int q = k / trips_q;
+      if (q == 1) __builtin_amdgcn_s_setprio(2);
+      else if (q == 2) __builtin_amdgcn_s_setprio(1);
+      else if (q >= 3) __builtin_amdgcn_s_setprio(0);
+    }
     if (k >= dealt) {
       int c = 0;
       if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(sDraw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -939,8 +952,21 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
     dealt -= drawn_rows;
     drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
   }
+  // PIC1DP_WAVE_PRIO (experiment): a wave's issue priority falls with its progress (quarters of its trips), so that of the
+  // two workgroups that share a CU the one that is behind wins the issue slots -- they stay together instead of the older
+  // one finishing a third earlier and the younger one running the last stretch alone at half the occupancy
+  const int trips_q = a.wave_prio ? max(1, (dealt + (drawn_total / max(1, static_cast<int>(blockDim.x >> 6))) + 3) >> 2) : 0;
+  int next_q = 0;
+  if (a.wave_prio) __builtin_amdgcn_s_setprio(3);
   int64_t j = first + threadIdx.x;
   for (int k = 0;; ++k, j += stride) {
+    if (a.wave_prio && k >= next_q) {  // (wave-uniform)
+      next_q += trips_q;
+      const int q = k / trips_q;
+      if (q == 1) __builtin_amdgcn_s_setprio(2);
+      else if (q == 2) __builtin_amdgcn_s_setprio(1);
+      else if (q >= 3) __builtin_amdgcn_s_setprio(0);
+    }
     if (k >= dealt) {
       int c = 0;
       if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(sDraw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));

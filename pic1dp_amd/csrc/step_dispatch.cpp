@@ -35,6 +35,7 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.fused = a.fused;
   d.tail = a.tail;
   d.dyn_tail = a.dyn_tail;
+  d.wave_prio = a.wave_prio;
 #ifdef PIC1DP_TUNE_SUMS2
   d.sums2 = a.sums2;
 #endif
