@@ -47,6 +47,18 @@ namespace {
 #define STAMP(a, k) ((void)0)
 #define STAMP_HWID(a) ((void)0)
 #endif
+// -DPIC1DP_TUNE_STAMPS -DPIC1DP_TUNE_STAMPS_SOLVE: stamps 2, 3, 4 are taken INSIDE the fused prologue's solve instead
+// (2 charge / products staged, 3 the serial forward sums done, 4 the prediction's sums combined; 1 stays "tiles staged")
+#if defined(PIC1DP_TUNE_STAMPS) && defined(PIC1DP_TUNE_STAMPS_SOLVE)
+#define STAMP_SOLVE(p, k)                                                                   \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && (p)) (p)[static_cast<size_t>(blockIdx.x) * 8 + (k)] = wall_clock64(); \
+  } while (0)
+#define STAMP_LOOP(a, k) ((void)0)
+#else
+#define STAMP_SOLVE(p, k) ((void)0)
+#define STAMP_LOOP(a, k) STAMP(a, k)
+#endif
 
 // ---------------------------------------------------------------------------
 // Whole-time-step kernels (pic1dp_hip_step): the half-step state is never
@@ -364,7 +376,8 @@ struct TabTiles {  // k_step_sums: a tile each
 };
 template <bool TILE_EH, class TAB>
 __device__ __forceinline__ void fused_solve(const FusedSolve &fs, const TAB &tab, double *sE0, double *sX, double *sSc,
-                                            double &re_h, double &im_h) {
+                                            double &re_h, double &im_h, unsigned long long *stamps = nullptr) {
+  (void)stamps;
   const FieldArgs &f = fs.f;
   const int nx = f.nx;
   double *sMode = sSc, *sScr = sSc + 8, *sPart = sSc + 24;
@@ -394,6 +407,7 @@ __device__ __forceinline__ void fused_solve(const FusedSolve &fs, const TAB &tab
     for (int i = threadIdx.x; i < 8 * PRED_SUM_COPIES; i += blockDim.x) fs.zero_pred[i] = 0.0;
   }
   __syncthreads();
+  STAMP_SOLVE(stamps, 2);
   const double ginv = f.grad_inv[0];
   {  // the forward sums (:231-240); beside them the last wave adds up the copies of the six sums, in copy order
     const double acc = lean_forward_sums<FUSED_CHAIN_W>(f, sPc, sPs, sPart, [&]() {
@@ -422,9 +436,11 @@ __device__ __forceinline__ void fused_solve(const FusedSolve &fs, const TAB &tab
     }
   }
   __syncthreads();
+  STAMP_SOLVE(stamps, 3);
   const double re = sMode[0], im = sMode[1];
   double ac, as;
   pred_forward_sums(f, fs.pt, sMode + 2, re, im, ac, as);
+  STAMP_SOLVE(stamps, 4);
   im_h = ac * f.sc_im * ginv;  // :234, :239, :243-247
   re_h = as * f.sc_re * ginv;
   if (lead && threadIdx.x == 0) {
@@ -659,7 +675,11 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   if constexpr (FUSED) {  // E0 and Eh of this step from the previous launch's deposits and six sums (scratch: the
                           // head of the slots, zeroed behind it)
     double re_h, im_h;
+#ifdef PIC1DP_TUNE_STAMPS
+    fused_solve<true>(a.fused, TabCells{sAB}, sE0, sEh, sP, re_h, im_h, a.stamps);
+#else
     fused_solve<true>(a.fused, TabCells{sAB}, sE0, sEh, sP, re_h, im_h);  // (stages sAB as well)
+#endif
     __syncthreads();
   } else if (threadIdx.x == 0) {
     sE0[nx] = a.E0[0];
@@ -766,11 +786,11 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
       u = pred_one<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP, a);
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
   }
-  STAMP(a, 2);
+  STAMP_LOOP(a, 2);
   __syncthreads();
-  STAMP(a, 3);
+  STAMP_LOOP(a, 3);
   flush_rho(sR0, a.rho, a.g);
-  STAMP(a, 4);
+  STAMP_LOOP(a, 4);
   if constexpr (PRIV) {  // the six sums: wave k adds up the slots of sum k (12 reads per lane, a wave reduction), one
                          // global atomic each -- no barrier beyond the one above
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1008,11 +1028,11 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
     const double u = pred_one_sums<DIST, MODE, POW2>(n, p, ic, lc, sA, sB, ks, a);
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
   }
-  STAMP(a, 2);
+  STAMP_LOOP(a, 2);
   __syncthreads();
-  STAMP(a, 3);
+  STAMP_LOOP(a, 3);
   flush_rho(sR0, a.rho, a.g);
-  STAMP(a, 4);
+  STAMP_LOOP(a, 4);
   // the six sums: workgroup reduction, one global atomic each into one of the copies (kernels.hpp PRED_SUM_COPIES)
   const double mine[6] = {ks.k0c, ks.k1c, ks.k2c, ks.k0s, ks.k1s, ks.k2s};
   block_sum6_add(mine, sScr, a.pred + (blockIdx.x % PRED_SUM_COPIES) * 8);
