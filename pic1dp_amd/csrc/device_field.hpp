@@ -176,14 +176,37 @@ __device__ __forceinline__ double chain_rows_mfma(const double *rows, int stride
   const double *src = rows + (ra < nrows ? ra : 0) * stride;
   double acc = 0.0;
   const int nb = n >> 2;
-  constexpr int U = 8;  // terms for eight instructions in flight ahead of the dependent chain
+  constexpr int U = 8;  // terms of eight instructions per batch; the NEXT batch's LDS reads are under way while this
+                        // batch's dependent instructions run (round 5: read-then-run left the LDS round trip, about as long
+                        // as the eight instructions themselves, exposed in every batch -- profiles/r05/experiments/
+                        // stamps_prologue_solve.log: 4.6 us for 1024 terms)
   int t = 0;
-  for (; t + U <= nb; t += U) {
-    double a[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) a[u] = src[4 * (t + u) + k];
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], 1.0, acc, 0, 0, 0);
+  if (nb >= U) {
+    double a[U], b[U];  // two batches in ping-pong; the scheduling fences keep a batch's reads IN FRONT of the other's instructions
+#define PIC1DP_CHAIN_READ(r, t0)                                       \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) r[u] = src[4 * ((t0) + u) + k]; \
+  __builtin_amdgcn_sched_barrier(0)
+#define PIC1DP_CHAIN_RUN(r) \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(r[u], 1.0, acc, 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0)
+    PIC1DP_CHAIN_READ(a, 0);
+    for (; t + 3 * U <= nb; t += 2 * U) {  // (a holds batch t; two more full batches follow)
+      PIC1DP_CHAIN_READ(b, t + U);
+      PIC1DP_CHAIN_RUN(a);
+      PIC1DP_CHAIN_READ(a, t + 2 * U);
+      PIC1DP_CHAIN_RUN(b);
+    }
+    if (t + 2 * U <= nb) {
+      PIC1DP_CHAIN_READ(b, t + U);
+      PIC1DP_CHAIN_RUN(a);
+      PIC1DP_CHAIN_RUN(b);
+      t += 2 * U;
+    } else {
+      PIC1DP_CHAIN_RUN(a);
+      t += U;
+    }
+#undef PIC1DP_CHAIN_READ
+#undef PIC1DP_CHAIN_RUN
   }
   for (; t < nb; ++t) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(src[4 * t + k], 1.0, acc, 0, 0, 0);
   const double *dsrc = rows + (rd < nrows ? rd : 0) * stride;  // the last n % 4 terms, by the result's row
