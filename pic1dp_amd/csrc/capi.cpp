@@ -1004,7 +1004,10 @@ int pic1dp_hip_cell_indices(pic1dp_ctx *c, int32_t isp, int32_t *ix, int64_t *co
 // ---------------------------------------------------------------------------
 int pic1dp_hip_timers_enable(pic1dp_ctx *c, int32_t on) {
   CHECK_CTX(c);
+  if (on < 0) return fail(PIC1DP_ERR_ARG, "timers_enable: 0 off, 1 every launch, n >= 2 every n-th launch of a timer");
+  if (int rc = ev_resolve(c)) return rc;
   c->timers_on = on != 0;
+  c->timer_every = on > 1 ? on : 1;
   return 0;
 }
 
@@ -1013,6 +1016,14 @@ int pic1dp_hip_timer_ms(pic1dp_ctx *c, int32_t iwt, double *ms) {
   if (iwt < 0 || iwt >= 100 || !ms) return fail(PIC1DP_ERR_ARG, "bad timer id");
   if (int rc = ev_resolve(c)) return rc;
   *ms = c->acc_ms[iwt];
+  // sampled timers: the spans that were timed stand for the ones that were only counted -- apart from the first block of
+  // the timer id (first launches, the run's first step), which is always timed and enters as it is
+  const int64_t later = c->span_seen[iwt] - c->head_n[iwt];
+  if (c->acc_n[iwt] > 0 && later > c->acc_n[iwt]) *ms *= static_cast<double>(later) / static_cast<double>(c->acc_n[iwt]);
+  *ms += c->head_ms[iwt];
+  // (no later block timed yet -- a short run, or a timer id with few launches: the first block's mean stands for them)
+  if (c->acc_n[iwt] == 0 && c->head_n[iwt] > 0 && later > 0)
+    *ms += c->head_ms[iwt] * static_cast<double>(later) / static_cast<double>(c->head_n[iwt]);
   return 0;
 }
 
@@ -1022,6 +1033,9 @@ int pic1dp_hip_timers_reset(pic1dp_ctx *c) {
   for (int i = 0; i < kNumTags; ++i) {
     c->acc_ms[i] = 0.0;
     c->acc_n[i] = 0;
+    c->span_seen[i] = 0;
+    c->head_ms[i] = 0.0;
+    c->head_n[i] = 0;
   }
   return 0;
 }

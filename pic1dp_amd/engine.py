@@ -392,6 +392,7 @@ class Pic1dp:
 
     # -- timers / knobs -----------------------------------------------------------------
     def timers_enable(self, on=True):
+        """False / 0 off; True / 1 HIP events around every launch; n >= 2 around every n-th block of 64 launches of a timer id (scaled)"""
         check(self.L.pic1dp_hip_timers_enable(self._ctx, int(on)))
 
     def timer_ms(self, iwt):

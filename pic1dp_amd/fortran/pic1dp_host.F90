@@ -46,7 +46,8 @@ real(c_double) :: t_run0, t_loop0, t_a, steps_s, load_s
 character(len=8) :: buf
 character(len=512) :: dump_path
 integer :: stat, verbosity
-logical :: fused, whole_step, batched, use_rccl
+integer(c_int32_t) :: timer_mode
+logical :: fused, whole_step, batched, use_rccl, loop_profile
 integer(c_signed_char) :: handle(PIC1DP_XCHG_HANDLE_BYTES), comm_id(PIC1DP_COMM_ID_BYTES)
 integer(c_signed_char), allocatable :: handles(:)
 
@@ -79,14 +80,20 @@ fused = (stat == 0 .and. buf(1:1) == '1')
 whole_step = (stat == 0 .and. (buf(1:1) == '2' .or. buf(1:1) == '3'))
 batched = (stat == 0 .and. buf(1:1) == '3')
 call get_environment_variable('PIC1DP_HOST_PROFILE', buf, status=stat)
-output_profile = (stat == 0 .and. buf(1:1) == '1')
+output_profile = (stat == 0 .and. buf(1:1) == '1')   ! the split steps | output_all | file writes: one device sync per iteration
+loop_profile = (stat == 0 .and. buf(1:1) == '2')     ! the time loop's wall clock only: nothing added to the loop
+call get_environment_variable('PIC1DP_TIMERS', buf, status=stat)
+timer_mode = 17                                      ! the reference's timers (wtimer): HIP events around the launches of every 17th
+                                                     ! block of 64 under a timer id, scaled (1: around every launch -- 10-28 % of a
+                                                     ! default-size run; 0: off)
+if (stat == 0) read (buf, *, iostat=stat) timer_mode
 steps_s = 0.0_c_double
 
 t_run0 = output_wall()
 call pic1dp_hip_check(pic1dp_hip_particle_load(ctx), 'particle_load')
 if (output_profile) call pic1dp_hip_check(pic1dp_hip_sync(ctx), 'sync')
 load_s = output_wall() - t_run0
-call pic1dp_hip_check(pic1dp_hip_timers_enable(ctx, 1), 'timers_enable')
+call pic1dp_hip_check(pic1dp_hip_timers_enable(ctx, timer_mode), 'timers_enable')
 ! output_all is called at the reference's cadence below: steps it follows take its diagnostics along
 call pic1dp_hip_check(pic1dp_hip_set_output_fusion(ctx, 1), 'set_output_fusion')
 
@@ -135,6 +142,10 @@ do while (itermination == 0)                 ! main time evolution loop
 end do
 
 if (ranks_rank == 0) call output_final
+if (loop_profile .and. ranks_rank == 0) then
+  call pic1dp_hip_check(pic1dp_hip_sync(ctx), 'sync')
+  write (*, '(a, f10.3, a, i8, a)') 'Info: host wall clock (s):   time loop', output_wall() - t_loop0, '   (', global_itime, ' steps)'
+end if
 if (output_profile .and. ranks_rank == 0) then
   t_a = output_wall()
   write (*, '(a)') 'Info: host wall clock (s):'

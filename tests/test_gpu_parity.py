@@ -864,6 +864,34 @@ def test_timers_and_kernel_stats(amd):
     assert eng.kernel_stats(0) == (0.0, 0)
 
 
+def test_sampled_timers_estimate_the_exact_ones(amd):
+    """pic1dp_hip_timers_enable(n >= 2): only every n-th launch under a timer id is bracketed by events (an event pair
+    costs the stream a dependency: 10-28 % of a default-size run), the time reported is scaled by launches seen /
+    launches timed -- within the run-to-run spread of the exact timers on a homogeneous run, and the same results"""
+    kw = dict(nparticle_max=2000000, nx=192)
+    times, energy = {}, {}
+    for every in (1, 8):
+        eng = amd.Pic1dp(amd.make_input(**kw))
+        eng.particle_load()
+        eng.interaction_collect_charge()
+        eng.field_solve_electric()
+        eng.step(20)
+        eng.timers_enable(every)
+        for _ in range(160):
+            for irk in (1, 2):
+                eng.interaction_push_particle(irk)
+                eng.interaction_collect_charge()
+                eng.field_solve_electric()
+        times[every] = (eng.timer_ms(4), eng.timer_ms(7))      # push particle, electric field
+        energy[every] = eng.field_energy()
+        eng.close()
+    assert abs(energy[1] / energy[8] - 1.0) < 1e-12   # (the charge atomics' order)
+    for a, b in zip(times[1], times[8]):
+        assert a > 0.0 and b > 0.0 and 0.6 < b / a < 1.6, times
+    with pytest.raises(amd.Pic1dpError):
+        amd.Pic1dp(amd.make_input(nparticle_max=1000, nx=16)).timers_enable(-1)
+
+
 # --------------------------------------------------------------------------
 # full-size properties (BASELINE.json configs 2 and 3): no oracle at this size
 # --------------------------------------------------------------------------

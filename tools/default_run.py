@@ -7,8 +7,9 @@ runs it (src/pic1dp.F90:78-109).
     python tools/default_run.py [--modes 0,2,3] [--time-max 500] [--oracle-steps 100] [--keep DIR]
 
 For every mode of the host (PIC1DP_FUSED: 0 the three call sites, 2 pic1dp_hip_step(1) per iteration, 3 all the steps
-up to the next output_all in one call) it prints: wall clock of the process, the host's own split (steps | output_all in
-the library | file writes, PIC1DP_HOST_PROFILE=1), the size and record count of pic1dp.out against the layout of
+up to the next output_all in one call) it prints: wall clock of the process, the time loop's wall clock as the host takes
+it (PIC1DP_HOST_PROFILE=2: nothing added to the loop; --profile 1: the split steps | output_all in the library | file
+writes, which costs a device synchronisation per iteration), the size and record count of pic1dp.out against the layout of
 SURVEY 5.5 (103 000 B per record), 2 gamma fitted by the rule of tools/OutputData.py:153-170 against the analytic
 0.16766, and the records' int E^2 dx of the first --oracle-steps steps against the CPU oracle (test infrastructure;
 this tool is a measurement harness, not the product)."""
@@ -32,6 +33,8 @@ def main():
     ap.add_argument("--time-max", type=float, default=500.0)
     ap.add_argument("--oracle-steps", type=int, default=100)
     ap.add_argument("--keep", default="")
+    ap.add_argument("--profile", default="2", help="PIC1DP_HOST_PROFILE: 1 the split (a device sync per iteration), 2 the time loop's wall clock only")
+    ap.add_argument("--timers", default="17", help="PIC1DP_TIMERS: the host's timer mode (0 off, 1 HIP events around every launch, n every n-th block of 64 launches: the host's default 17)")
     args = ap.parse_args()
     from pic1dp_amd import output
     import pic1dp_amd
@@ -62,7 +65,7 @@ def main():
     for mode in args.modes.split(","):
         wd = os.path.join(base, "fused" + mode)
         os.makedirs(wd)
-        env = dict(os.environ, PIC1DP_FUSED=mode, PIC1DP_HOST_PROFILE="1", PIC1DP_TIME_MAX=repr(args.time_max))
+        env = dict(os.environ, PIC1DP_FUSED=mode, PIC1DP_HOST_PROFILE=args.profile, PIC1DP_TIMERS=args.timers, PIC1DP_TIME_MAX=repr(args.time_max))
         t0 = time.perf_counter()
         r = subprocess.run([exe], cwd=wd, env=env, capture_output=True, text=True)
         wall = time.perf_counter() - t0
