@@ -14,8 +14,75 @@ integer(c_int32_t), parameter :: vec_file_classid = 1211214
 logical :: output_profile = .false.
 real(c_double) :: output_lib_s = 0.0_c_double, output_write_s = 0.0_c_double
 integer :: output_records = 0
+! A record is assembled in memory as big-endian 8-byte words (every item of it is one: a float64, or a Vec's two int32 of
+! header) and written with ONE native write: through the Fortran runtime's convert='big_endian' the same bytes cost 0.12 ms
+! per 103 KB record (element-wise conversion), a fifth of the default run's output cost
+integer(c_int64_t), allocatable :: rec_buf(:)
+integer :: rec_n = 0
 
 contains
+
+pure elemental function bswap64(x) result(y)
+  integer(c_int64_t), intent(in) :: x
+  integer(c_int64_t) :: y
+  y = ior(ior(ior(ishft(iand(x, int(z'FF', c_int64_t)), 56), ishft(iand(x, int(z'FF00', c_int64_t)), 40)), &
+              ior(ishft(iand(x, int(z'FF0000', c_int64_t)), 24), ishft(iand(x, int(z'FF000000', c_int64_t)), 8))), &
+          ior(ior(iand(ishft(x, -8), int(z'FF000000', c_int64_t)), iand(ishft(x, -24), int(z'FF0000', c_int64_t))), &
+              ior(iand(ishft(x, -40), int(z'FF00', c_int64_t)), iand(ishft(x, -56), int(z'FF', c_int64_t)))))
+end function bswap64
+
+pure elemental function bswap32(x) result(y)
+  integer(c_int32_t), intent(in) :: x
+  integer(c_int32_t) :: y
+  y = ior(ior(ishft(iand(x, int(z'FF', c_int32_t)), 24), ishft(iand(x, int(z'FF00', c_int32_t)), 8)), &
+          ior(iand(ishft(x, -8), int(z'FF00', c_int32_t)), iand(ishft(x, -24), int(z'FF', c_int32_t))))
+end function bswap32
+
+subroutine rec_room(n)
+  integer, intent(in) :: n
+  integer(c_int64_t), allocatable :: grown(:)
+  if (.not. allocated(rec_buf)) allocate (rec_buf(max(4096, 2 * n)))
+  if (rec_n + n > size(rec_buf)) then
+    allocate (grown(2 * (rec_n + n)))
+    grown(1 : rec_n) = rec_buf(1 : rec_n)
+    call move_alloc(grown, rec_buf)
+  end if
+end subroutine rec_room
+
+! the reals of a record, as they stand in the file
+subroutine rec_put(a)
+  real(c_double), intent(in) :: a(:)
+  call rec_room(size(a))
+  rec_buf(rec_n + 1 : rec_n + size(a)) = bswap64(transfer(a, 1_c_int64_t, size(a)))
+  rec_n = rec_n + size(a)
+end subroutine rec_put
+
+! a PETSc Vec: class id, length (int32 each), values
+subroutine rec_put_vec(a)
+  real(c_double), intent(in) :: a(:)
+  integer(c_int32_t) :: hdr(2)
+  call rec_room(1)
+  hdr(1) = bswap32(vec_file_classid)
+  hdr(2) = bswap32(int(size(a), c_int32_t))
+  rec_n = rec_n + 1
+  rec_buf(rec_n) = transfer(hdr, 1_c_int64_t)
+  call rec_put(a)
+end subroutine rec_put_vec
+
+subroutine rec_flush
+  if (rec_n > 0) write (output_unit_out) rec_buf(1 : rec_n)
+  rec_n = 0
+end subroutine rec_flush
+
+! The record output_all has assembled goes to the file HERE: the driver calls this after it has handed the next step(s) to
+! the GPU, so that the write passes while the device works (and once more before the file is closed)
+subroutine output_flush
+  real(c_double) :: t0
+  if (rec_n == 0) return
+  t0 = output_wall()
+  call rec_flush
+  output_write_s = output_write_s + (output_wall() - t0)
+end subroutine output_flush
 
 function output_wall() result(t)
   real(c_double) :: t
@@ -26,18 +93,12 @@ end function output_wall
 
 subroutine output_init(inp)
   type(pic1dp_input_t), intent(in) :: inp
-  open (output_unit_out, file='pic1dp.out', access='stream', form='unformatted', &
-    status='replace', convert='big_endian')
-  write (output_unit_out) inp%nspecies, inp%nmode, inp%nx, inp%nv, inp%nx_opd, inp%nv_opd, &
-    inp%modes(1 : inp%nmode)
-  write (output_unit_out) inp%lx, inp%v_max
+  open (output_unit_out, file='pic1dp.out', access='stream', form='unformatted', status='replace')
+  write (output_unit_out) bswap32(inp%nspecies), bswap32(inp%nmode), bswap32(inp%nx), bswap32(inp%nv), &
+    bswap32(inp%nx_opd), bswap32(inp%nv_opd), bswap32(inp%modes(1 : inp%nmode))
+  call rec_put([inp%lx, inp%v_max])
+  call rec_flush
 end subroutine output_init
-
-subroutine output_vec(a)
-  real(c_double), intent(in) :: a(:)
-  write (output_unit_out) vec_file_classid, int(size(a), c_int32_t)
-  write (output_unit_out) a
-end subroutine output_vec
 
 ! output_field + output_ptcldist + output_progress(1)
 subroutine output_all(ctx, inp, verbosity)
@@ -62,12 +123,12 @@ subroutine output_all(ctx, inp, verbosity)
     call pic1dp_hip_check(pic1dp_hip_output_all(ctx, scal, int(size(scal), c_int32_t), e, cd, re, im, dist), 'output_all')
     t1 = output_wall()
     output_lib_s = output_lib_s + (t1 - t0)
-    write (output_unit_out) scal
-    call output_vec(re)
-    call output_vec(im)
-    call output_vec(e)
-    call output_vec(cd)
-    write (output_unit_out) dist        ! per species: markr_xv, total_xv, pertb_xv, markr_v, total_v, pertb_v -- the file's order
+    call rec_put(scal)
+    call rec_put_vec(re)
+    call rec_put_vec(im)
+    call rec_put_vec(e)
+    call rec_put_vec(cd)
+    call rec_put(dist)                  ! per species: markr_xv, total_xv, pertb_xv, markr_v, total_v, pertb_v -- the file's order
     t0 = output_wall()
     output_write_s = output_write_s + (t0 - t1)
     output_records = output_records + 1
@@ -84,11 +145,11 @@ subroutine output_all(ctx, inp, verbosity)
     call pic1dp_hip_check(pic1dp_hip_get_field(ctx, e, cd, re, im), 'get_field')
     t1 = output_wall()
     output_lib_s = output_lib_s + (t1 - t0)
-    write (output_unit_out) scal
-    call output_vec(re)
-    call output_vec(im)
-    call output_vec(e)
-    call output_vec(cd)
+    call rec_put(scal)
+    call rec_put_vec(re)
+    call rec_put_vec(im)
+    call rec_put_vec(e)
+    call rec_put_vec(cd)
     t0 = output_wall()
     output_write_s = output_write_s + (t0 - t1)
   end if
@@ -106,12 +167,12 @@ subroutine output_all(ctx, inp, verbosity)
     if (ranks_rank /= 0) cycle
     t1 = output_wall()
     output_lib_s = output_lib_s + (t1 - t0)
-    write (output_unit_out) mxv
-    write (output_unit_out) txv
-    write (output_unit_out) pxv
-    write (output_unit_out) mv
-    write (output_unit_out) tv
-    write (output_unit_out) pv
+    call rec_put(mxv)
+    call rec_put(txv)
+    call rec_put(pxv)
+    call rec_put(mv)
+    call rec_put(tv)
+    call rec_put(pv)
     t0 = output_wall()
     output_write_s = output_write_s + (t0 - t1)
   end do
@@ -169,6 +230,7 @@ end subroutine output_progress_optimized
 
 subroutine output_final
   real(c_double) :: t0
+  call output_flush
   t0 = output_wall()
   close (output_unit_out)
   output_write_s = output_write_s + (output_wall() - t0)

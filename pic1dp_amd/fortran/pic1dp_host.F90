@@ -132,6 +132,7 @@ do while (itermination == 0)                 ! main time evolution loop
     global_time = global_time + inp%dt
     call pic1dp_hip_check(pic1dp_hip_set_time(ctx, global_itime, global_time), 'set_time')
   end if
+  if (ranks_rank == 0) call output_flush     ! the previous record's file write, while the GPU works on what was just enqueued
   if (output_profile) then
     call pic1dp_hip_check(pic1dp_hip_sync(ctx), 'sync')
     steps_s = steps_s + (output_wall() - t_a)
