@@ -604,6 +604,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
                     c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred_all, c->d_cd_h, c->d_mode_h, c->d_Ehn, c->d_pack};
   for (double *b : bufs) (void)hipFree(b);
   (void)hipFree(c->d_ticket);
+  (void)hipFree(c->d_rec);
   (void)hipHostFree(c->h_pin);
   for (auto &e : c->evpool) {
     (void)hipEventDestroy(e.a);

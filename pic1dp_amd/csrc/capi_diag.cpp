@@ -358,25 +358,45 @@ int pic1dp_hip_output_all(pic1dp_ctx *c, double *scalars, int32_t nscal, double 
   if (int rc = pinned(c, off, &h)) return rc;
   double *slot = c->d_scratch + kEnergyBlocks * 3;
   HIP_TRY(launch_field_energy(c->d_E, in.nx, in.lx, static_cast<double>(in.nx), slot, c->st));
-  HIP_TRY(hipMemcpyAsync(h, c->d_E, sizeof(double) * nx, hipMemcpyDeviceToHost, c->st));
-  HIP_TRY(hipMemcpyAsync(h + nx, c->d_chargeden, sizeof(double) * nx, hipMemcpyDeviceToHost, c->st));
-  HIP_TRY(hipMemcpyAsync(h + 2 * nx, c->d_mode_re, sizeof(double) * nm, hipMemcpyDeviceToHost, c->st));
-  HIP_TRY(hipMemcpyAsync(h + 2 * nx + nm, c->d_mode_im, sizeof(double) * nm, hipMemcpyDeviceToHost, c->st));
-  HIP_TRY(hipMemcpyAsync(h + 2 * nx + 2 * nm, slot, sizeof(double), hipMemcpyDeviceToHost, c->st));
+  // the record is gathered on the device and crosses in ONE transfer (every small copy of its own costs the stream ~10 us)
+  if (c->d_rec_doubles < off) {
+    if (c->d_rec) HIP_TRY(hipFree(c->d_rec));
+    c->d_rec = nullptr, c->d_rec_doubles = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_rec), sizeof(double) * off));
+    c->d_rec_doubles = off;
+  }
+  PackArgs pk{};
+  auto seg = [&pk](const double *src, size_t dst, size_t n) {
+    if (n == 0) return;
+    pk.src[pk.count] = src, pk.dst[pk.count] = static_cast<unsigned>(dst), pk.n[pk.count] = static_cast<unsigned>(n);
+    pk.count++;
+  };
+  seg(c->d_E, 0, nx);
+  seg(c->d_chargeden, nx, nx);
+  seg(c->d_mode_re, 2 * nx, nm);
+  seg(c->d_mode_im, 2 * nx + nm, nm);
+  seg(slot, 2 * nx + 2 * nm, 1);
+  size_t used = 2 * nx + 2 * nm + 8;
+  bool tails = false;
   for (int s = 0; s < ns; ++s) {
-    Species &S = c->sp[s];
     if (c->diag_pending[s]) {
       const int blocks = c->diag_blocks[s], stride = c->diag_stride[s];
-      double *part_dev = c->d_diag_part + static_cast<size_t>(6) * diag_max_blocks(c) * s;
-      if (blocks > 0)
-        HIP_TRY(hipMemcpyAsync(h + off_part[s], part_dev, sizeof(double) * blocks * stride, hipMemcpyDeviceToHost, c->st));
-      if (tb[s] > 0) {  // the reference sums the whole local vector (VecSum); slots beyond np live in set 0
-        HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, S.nalloc - S.np, c->d_scratch,
-                                   tb[s], c->st));
-        HIP_TRY(hipMemcpyAsync(h + off_tail[s], c->d_scratch, sizeof(double) * tb[s] * 3, hipMemcpyDeviceToHost, c->st));
-      }
+      seg(c->d_diag_part + static_cast<size_t>(6) * diag_max_blocks(c) * s, off_part[s], static_cast<size_t>(blocks) * stride);
+      if (tb[s] > 0) tails = true;
     }
-    if (dist) HIP_TRY(hipMemcpyAsync(h + off_hist[s], c->d_dist + ntot * s, sizeof(double) * ntot, hipMemcpyDeviceToHost, c->st));
+    if (dist) seg(c->d_dist + ntot * s, off_hist[s], ntot);
+    used = off_hist[s] + ntot;
+  }
+  HIP_TRY(launch_pack_record(pk, c->d_rec, c->st));
+  HIP_TRY(hipMemcpyAsync(h, c->d_rec, sizeof(double) * used, hipMemcpyDeviceToHost, c->st));
+  if (tails) {  // (unloaded or emptied slots: the reference sums the whole local vector (VecSum); slots beyond np live in set 0)
+    for (int s = 0; s < ns; ++s) {
+      Species &S = c->sp[s];
+      if (!(c->diag_pending[s] && tb[s] > 0)) continue;
+      HIP_TRY(launch_energy_sums(S.set[0].v, S.p, in.deltaf ? S.set[0].w : nullptr, S.np, S.nalloc - S.np, c->d_scratch,
+                                 tb[s], c->st));
+      HIP_TRY(hipMemcpyAsync(h + off_tail[s], c->d_scratch, sizeof(double) * tb[s] * 3, hipMemcpyDeviceToHost, c->st));
+    }
   }
   HIP_TRY(hipStreamSynchronize(c->st));
   if (int rc = xchg_check(c)) return rc;

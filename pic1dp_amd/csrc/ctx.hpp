@@ -196,6 +196,8 @@ struct pic1dp_ctx {
   double diag_fx_margin_w = 16.0;   // bound on |w| = this x the last pass's max |w| (PIC1DP_DIAG_FX_MARGIN: tests)
   int64_t diag_fx_passes = 0, diag_fx_repeats = 0;   // fixed-point passes so far; passes repeated in doubles after an overflow
   int fuse_output = 0;                     // take the diagnostics inside k_step_full on steps output_all follows
+  double *d_rec = nullptr;                 // output_all's record gathered on the device (kernels.hpp PackArgs), grow-only
+  size_t d_rec_doubles = 0;
   double *h_pin = nullptr;                 // pinned host staging of the small device-to-host transfers (output_all's calls:
   size_t h_pin_doubles = 0;                // pageable copies cost a synchronous call each, ~20 us; grow-only, capi_diag.cpp pinned)
   DistGeom dist_geom_v{};                  // output_ptcldist's histogram geometry (capi_diag.cpp dist_geom)

@@ -350,6 +350,16 @@ hipError_t launch_field_fd(const double *chargeden, double *E, double *history, 
 // chain_rows_mfma -- create() compares them with the host's sequential sums
 hipError_t launch_chain_selftest(const double *v, int nrows, int n, double *out, hipStream_t st);
 // int E^2 dx into *out (device)
+// output_all's record gathered on the device: up to PACK_MAX_SEGMENTS ranges copied into one contiguous buffer, which then
+// crosses PCIe in ONE transfer (a small device-to-host copy costs the stream ~10 us whatever its size; a record had 5 + 2 per species)
+constexpr int PACK_MAX_SEGMENTS = 5 + 2 * 8;
+struct PackArgs {
+  const double *src[PACK_MAX_SEGMENTS];
+  unsigned dst[PACK_MAX_SEGMENTS];  // offset in the record, in doubles
+  unsigned n[PACK_MAX_SEGMENTS];
+  int count;
+};
+hipError_t launch_pack_record(const PackArgs &a, double *out, hipStream_t st);
 hipError_t launch_field_energy(const double *E, int nx, double lx, double dnx, double *out,
                                hipStream_t st);
 

@@ -200,6 +200,21 @@ hipError_t launch_ptcldist(const double *x, const double *v, const double *p, co
   return deltaf ? go(k_ptcldist<false, true, false, false>) : go(k_ptcldist<false, false, false, false>);
 }
 
+namespace {
+__global__ void __launch_bounds__(256) k_pack_record(const PackArgs a, double *out) {
+  const int seg = blockIdx.y;
+  if (seg >= a.count) return;
+  const double *src = a.src[seg];
+  double *dst = out + a.dst[seg];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[seg]; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+hipError_t launch_pack_record(const PackArgs &a, double *out, hipStream_t st) {
+  if (a.count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_record, dim3(16, a.count), dim3(256), 0, st, a, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_energy_sums(const double *v, const double *p, const double *w, int64_t i0, int64_t n,
                               double *partial, int blocks, hipStream_t st) {
   hipLaunchKernelGGL(k_energy_sums, dim3(blocks), dim3(256), 0, st, v, p, w, i0, n, partial);
