@@ -295,7 +295,8 @@ struct Span {
       // every bracketed launch pays a write-back of the caches its markers live in (a 70 us step at the reference's default
       // size: +10-28 %), and the time it reports contains that write-back
       auto make = [](hipEvent_t *e) {
-        if (hipEventCreateWithFlags(e, hipEventDisableSystemFence) == hipSuccess) return true;
+        static const bool fenced = std::getenv("PIC1DP_EVENT_FENCE") != nullptr;  // (A/B: the default events)
+        if (!fenced && hipEventCreateWithFlags(e, hipEventDisableSystemFence) == hipSuccess) return true;
         (void)hipGetLastError();
         return hipEventCreate(e) == hipSuccess;
       };
