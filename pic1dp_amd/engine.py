@@ -438,8 +438,12 @@ class Pic1dp:
         steps = 0
         term = self.check_termination()
         while term == 0 and (max_steps is None or steps < max_steps):
-            if fused:
-                self.step(1)
+            if fused:          # every step up to the next output_all in one call (src/pic1dp.F90:78-109 evaluated ahead)
+                n = max(1, self.steps_to_output())
+                if max_steps is not None:
+                    n = min(n, max_steps - steps)
+                self.step(n)
+                steps += n - 1
             else:
                 for irk in (1, 2):
                     self.interaction_push_particle(irk)
