@@ -719,6 +719,33 @@ def test_call_sites_two_launches_per_step(oracle_mod, amd, monkeypatch, kind):
     assert e.kernel_stats(11)[1] == (39 if kind == 2 else 0)
 
 
+@pytest.mark.parametrize("path", ["two_passes", "tiles", "tiles_two_modes"])
+@pytest.mark.parametrize("drawn", ["4", "16"])
+def test_chunks_drawn_in_the_other_whole_step_kernels(amd, monkeypatch, drawn, path):
+    """the drawn chunk tail in k_step_half / k_step_full (two passes per step) and in the tiles' k_step_one, and in the
+    diagnostics pass (k_ptcldist): every pair exactly once whoever takes it -- markers, energies and histograms against the
+    same engine with every chunk dealt, to the order of the charge atomics"""
+    kw = dict(nparticle_max=1_200_001, nx=256)
+    if path == "tiles_two_modes":
+        kw.update(nmode=2, modes=[1, 3])
+    predict, kind = (False, None) if path == "two_passes" else (True, 1)
+    monkeypatch.setenv("PIC1DP_DYN_TAIL", drawn)
+    a = engine(amd, monkeypatch, predict, kind, **kw)
+    monkeypatch.setenv("PIC1DP_DYN_TAIL", "0")
+    b = engine(amd, monkeypatch, predict, kind, **kw)
+    assert a.predict_kind() == (1 if predict else 0)
+    a.step(20)
+    b.step(20)
+    assert np.max(np.abs(a.energy_history() / b.energy_history() - 1.0)) < 1e-11
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
+    da, db = a.ptcldist(0), b.ptcldist(0)
+    for k in da:
+        assert np.allclose(da[k], db[k], rtol=1e-11, atol=1e-12 * np.max(np.abs(db[k]))), k
+    assert np.allclose(a.energy_sums(), b.energy_sums(), rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("drawn", ["4", "16"])
 def test_chunks_drawn_from_the_lds_counter(oracle_mod, amd, monkeypatch, drawn):
     """tuning knob PIC1DP_DYN_TAIL: the last n/16 of a workgroup's 64-pair chunks are drawn by its
