@@ -378,7 +378,8 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   }
   if (const char *e = std::getenv("PIC1DP_OSUB")) c->osub_req = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("PIC1DP_WAVE_PRIO")) c->wave_prio = std::atoi(e) != 0;
-  if (const char *e = std::getenv("PIC1DP_DYN_TAIL")) c->dyn_tail = std::max(0, std::min(16, std::atoi(e)));
+  if (const char *e = std::getenv("PIC1DP_DYN_TAIL")) c->dyn_tail = c->dyn_tail_full = std::max(0, std::min(16, std::atoi(e)));
+  if (const char *e = std::getenv("PIC1DP_DYN_TAIL_FULL")) c->dyn_tail_full = std::max(0, std::min(16, std::atoi(e)));
   if (const char *e = std::getenv("PIC1DP_PAIR_PLAIN")) c->pair_plain = std::atoi(e) != 0;
   while (c->grid.rcopies > 1 && step_lds_bytes(nx, true, c->grid.rcopies) > 80 * 1024) c->grid.rcopies >>= 1;
   if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_MB"))

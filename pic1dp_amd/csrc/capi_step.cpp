@@ -645,7 +645,9 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     a.deltaf = c->in.deltaf;
     a.linear = c->in.linear;
     a.stream_nt = stream_nt;
-    a.dyn_tail = c->dyn_tail;  // the drawn chunk tail of every whole-step kernel
+    // the drawn chunk tail of every whole-step kernel: half a workgroup's chunks, all of them for k_step_full (two passes
+    // per step at 1e8 markers: 0.913 -> 0.898 ms with 16/16 against 8/16, profiles/r05/experiments/ab_dyn_tail_other.log)
+    a.dyn_tail = (full && !pred) ? c->dyn_tail_full : c->dyn_tail;
     a.wave_prio = c->wave_prio;
     // a species with general divisor constants and an exp-bearing f0 is FP64-issue-bound: its
     // -f0'/f0 at the step-start velocity goes from the first kernel to the second through

@@ -109,6 +109,7 @@ struct pic1dp_ctx {
   int pair_plain = 0;              // PIC1DP_PAIR_PLAIN
   int osub_req = 0;                // PIC1DP_OSUB: grid size of the marker kernels in units of the resident one (0: auto)
   int wave_prio = 0;               // PIC1DP_WAVE_PRIO (experiment): the one-pass kernels' waves lower their issue priority as they progress
+  int dyn_tail_full = 16;          // ... of k_step_full (PIC1DP_DYN_TAIL sets both, PIC1DP_DYN_TAIL_FULL this one)
   int dyn_tail = 8;                // PIC1DP_DYN_TAIL: sixteenths of a workgroup's 64-pair chunks its waves DRAW from an LDS counter (every whole-step kernel)
   int pred_kind = 0;               // 0 no one-pass step here, 1 prediction tiles (k_step_one), 2 six sums (k_step_sums)
   int pred_private = 0;            // pred_kind 2 and E0, Eh, the table tiles and the private sums of two workgroups fit a
