@@ -50,6 +50,7 @@ int diag_buffers(pic1dp_ctx *c) {
     c->diag_stride.assign(ns, 3);
     c->diag_max_p.assign(ns, 0.0);
     c->diag_max_w.assign(ns, 0.0);
+    c->diag_fixed.assign(ns, 0);
   }
   if (!c->d_dist) HIP_TRY(hipMalloc(&c->d_dist, sizeof(double) * dist_len(in) * (ns + 1)));
   if (!c->d_diag_part) HIP_TRY(hipMalloc(&c->d_diag_part, sizeof(double) * 6 * diag_max_blocks(c) * ns));
@@ -70,6 +71,7 @@ static int run_diag_pass(pic1dp_ctx *c, int isp, bool fixed, bool *was_fixed) {
   c->diag_blocks[isp] = 0;
   c->diag_stride[isp] = 6;
   *was_fixed = false;
+  c->diag_fixed[isp] = 0;
   if (S.np <= 0) return 0;
   double bp = 0.0, bw = 0.0;
   if (fixed && c->diag_fx && c->diag_max_p[isp] > 0.0 && (in.deltaf != 1 || c->diag_max_w[isp] > 0.0)) {
@@ -81,6 +83,7 @@ static int run_diag_pass(pic1dp_ctx *c, int isp, bool fixed, bool *was_fixed) {
                           was_fixed));
   c->diag_passes++;
   if (*was_fixed) c->diag_fx_passes++;
+  c->diag_fixed[isp] = *was_fixed;
   return 0;
 }
 
@@ -96,6 +99,7 @@ int ensure_diag(pic1dp_ctx *c, int isp) {
     c->diag_version[isp] = c->state_version;
   }
   if (!c->diag_pending[isp]) return 0;
+  was_fixed = c->diag_fixed[isp] != 0;  // (the pending pass: the one just run, or k_step_full<DIAG> inside a step)
   // collect: partial kinetic sums of the pass (k_ptcldist, or k_step_full's DIAG variant), workgroup order
   double *sums = &c->diag_sums[3 * static_cast<size_t>(isp)];
   // the pass's partial sums and those of the tail slots (the reference sums the whole local vector, VecSum; slots beyond
@@ -341,10 +345,10 @@ int pic1dp_hip_output_all(pic1dp_ctx *c, double *scalars, int32_t nscal, double 
     if (c->diag_version[s] != c->state_version) {
       bool was_fixed = false;
       if (int rc = run_diag_pass(c, s, true, &was_fixed)) return rc;
-      fixed[s] = was_fixed;
       c->diag_pending[s] = 1;
       c->diag_version[s] = c->state_version;
     }
+    fixed[s] = c->diag_pending[s] && c->diag_fixed[s];  // (the pass just run, or k_step_full<DIAG> inside the step before)
     const int64_t ntail = c->sp[s].nalloc - c->sp[s].np;
     tb[s] = c->diag_pending[s] && ntail > 0 ? static_cast<int>(std::min<int64_t>(kEnergyBlocks, (ntail + 255) / 256)) : 0;
     off_part[s] = off;

@@ -748,7 +748,15 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
       lc.blocks = static_cast<int>(std::max<int64_t>(1, std::min(blocks, need)));
       c->diag_blocks[s] = lc.blocks;
-      c->diag_stride[s] = 3;       // (the kinetic sums only: no maxima from this kernel)
+      c->diag_stride[s] = 6;       // the kinetic sums, max |p|, max |w|, the fixed-point pass's overflow flag
+      // the histograms as 64-bit fixed-point sums where the species' max |p|, max |w| are known from the pass before (as the
+      // diagnostics' own pass does, capi_diag.cpp run_diag_pass; a marker beyond them: the collector repeats in doubles)
+      a.diag_fx = 0;
+      if (c->diag_fx && c->diag_max_p[s] > 0.0 && (c->in.deltaf != 1 || c->diag_max_w[s] > 0.0))
+        a.diag_fx = make_dist_scale(S.np, lc.blocks, c->in.deltaf == 1, 2.0 * c->diag_max_p[s],
+                                    c->diag_fx_margin_w * c->diag_max_w[s], &a.dscale, lc.threads) ? 1 : 0;
+      c->diag_fixed[s] = a.diag_fx != 0;
+      if (a.diag_fx) c->diag_fx_passes++;
       c->diag_pending[s] = 1;
       c->diag_version[s] = c->state_version;  // the caller has bumped it for this step already
     }

@@ -192,6 +192,7 @@ struct pic1dp_ctx {
   // k_ptcldist with 64-bit fixed-point histogram sums (device_diag.hpp DistScale): max |p| and max |w| of the species as
   // the last pass saw them (0: unknown -- the next pass sums in doubles and finds out); PIC1DP_DIAG_FX=0: always doubles
   std::vector<double> diag_max_p, diag_max_w;
+  std::vector<char> diag_fixed;            // [nspecies] the pending pass summed its histograms in fixed point (an overflow: once more in doubles)
   std::vector<uint64_t> diag_max_p_version;   // state_version-independent stamp: p changes with load / upload / events only
   int diag_fx = 1;
   double diag_fx_margin_w = 16.0;   // bound on |w| = this x the last pass's max |w| (PIC1DP_DIAG_FX_MARGIN: tests)

@@ -37,11 +37,7 @@ struct DistSums {
 // a workgroup's sums stay below 2^62; a term is rounded ONCE to a multiple of 1 / sc[k] (<= 2^-44 of the bound: 6e-14
 // relative, against the ~1e-16 sqrt(n) of a double sum in some order), the sums themselves are exact -- and independent of
 // the atomics' order.  A marker beyond the bound sets `over`; the host then repeats the pass with double sums.
-struct DistScale {
-  double sc[3];     // 2^e per plane
-  double inv[3];    // 2^-e
-  double bound[3];  // |q_k| the scale allows
-};
+// (struct DistScale: kernels.hpp)
 // RN(x * s) as a two's-complement 64-bit integer, |x * s| < 2^51: one FMA onto 1.5 * 2^52 and the magic's high word off
 __device__ __forceinline__ unsigned long long to_fixed(double x, double s) {
   const double t = fma(x, s, 6755399441055744.0);

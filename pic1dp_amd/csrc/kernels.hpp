@@ -118,6 +118,16 @@ struct DistGeom {
   int vfast;
 };
 DistGeom make_dist_geom(double lx, double vmax, int nxo, int nvo);
+// scales of the histograms' 64-bit fixed-point sums in a workgroup's LDS copy (device_diag.hpp): plane k (markers, p, w)
+// is summed as RN(term * sc[k]); a |p| / |w| beyond bound[k] makes the pass say so instead (the host repeats it in doubles)
+struct DistScale {
+  double sc[3];     // 2^e per plane
+  double inv[3];    // 2^-e
+  double bound[3];  // |q_k| the scale allows
+};
+// the scales for a pass of `blocks` workgroups over np markers whose |p|, |w| stay below bound_p, bound_w (<= 0: unknown);
+// false: no fixed-point pass possible (sum in doubles)
+bool make_dist_scale(int64_t np, int blocks, bool deltaf, double bound_p, double bound_w, DistScale *fx, int threads = 1024);
 
 // dynamic LDS a particle kernel may ask for: 160 KiB per CU minus the 1 KiB static exp table
 constexpr size_t PARTICLE_LDS_CAP = 159 * 1024;
@@ -238,6 +248,8 @@ struct StepArgs {
   const double *eh_re, *eh_im;
   FusedSolve fused;  // pred_kind 2 only: the prologue solves the previous step's field (E0, Eh, eh_re / eh_im unused)
   StepTail tail;     // pred_kind 2 only, several ranks: the last workgroup packs / posts this rank's charge (mode 0: no)
+  DistScale dscale;  // k_step_full<DIAG>: the histograms as fixed-point sums (diag_fx != 0)
+  int diag_fx;
   int wave_prio;     // k_step_one, k_step_sums (experiment, PIC1DP_WAVE_PRIO): a wave's issue priority falls with its progress
   int dyn_tail;      // every whole-step kernel: sixteenths of a workgroup's chunks that its waves draw from an LDS counter (0: all dealt)
 #ifdef PIC1DP_TUNE_SUMS2

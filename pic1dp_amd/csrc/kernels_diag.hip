@@ -145,6 +145,30 @@ int ptcldist_blocks(int64_t np, int nxo, int nvo, int num_cu) {
   return static_cast<int>(blocks);
 }
 
+// fixed-point sums: a workgroup adds at most its share of the markers into one bin; weights <= 1
+bool make_dist_scale(int64_t np, int blocks, bool deltaf, double bound_p, double bound_w, DistScale *out, int threads) {
+  DistScale fx{};
+  bool use_fx = blocks > 0 && bound_p > 0.0 && (!deltaf || bound_w > 0.0) && std::isfinite(bound_p) && std::isfinite(bound_w);
+  if (use_fx) {
+    const double th = static_cast<double>(threads);
+    const double per_wg = 2.0 * th * std::ceil(static_cast<double>((np >> 1) + 1) / (static_cast<double>(blocks) * th)) + 2.0;
+    const int e_n = static_cast<int>(std::ceil(std::log2(per_wg))) + 1;  // 2^e_n > the terms a bin can receive
+    const double bounds[3] = {1.0, bound_p, deltaf ? bound_w : 1.0};
+    for (int k = 0; k < 3; ++k) {
+      int eb;
+      (void)std::frexp(bounds[k], &eb);               // bounds[k] < 2^eb
+      const int mag = std::min(62 - e_n, 50);         // |term * 2^e| < 2^mag: below 2^51 for to_fixed, and the sums below 2^62
+      const int e = mag - eb;
+      if (e < -900 || e > 900) use_fx = false;        // (a bound no scale can serve)
+      fx.sc[k] = std::ldexp(1.0, e);
+      fx.inv[k] = std::ldexp(1.0, -e);
+      fx.bound[k] = std::ldexp(1.0, eb);
+    }
+  }
+  *out = fx;
+  return use_fx;
+}
+
 // bound_p / bound_w: max |p|, max |w| the markers are known not to exceed (with the caller's margin), or <= 0: unknown --
 // the pass then sums in doubles.  partial: [blocks][6] = the kinetic sums, max |p|, max |w|, overflow flag per workgroup
 hipError_t launch_ptcldist(const double *x, const double *v, const double *p, const double *w,
@@ -159,24 +183,8 @@ hipError_t launch_ptcldist(const double *x, const double *v, const double *p, co
   // x, v, p, w against the 256 MiB Infinity Cache: beyond it the pass streams (PIC1DP_DIAG_NT=0 / 1 insists)
   bool nt = 32.0 * static_cast<double>(np) > 288.0 * 1048576.0;
   if (const char *e = std::getenv("PIC1DP_DIAG_NT")) nt = std::atoi(e) != 0;
-  // fixed-point sums: a workgroup adds at most its share of the markers into one bin; weights <= 1
   DistScale fx{};
-  bool use_fx = lds && bound_p > 0.0 && (!deltaf || bound_w > 0.0) && std::isfinite(bound_p) && std::isfinite(bound_w);
-  if (use_fx) {
-    const double per_wg = 2.0 * 1024.0 * std::ceil(static_cast<double>((np >> 1) + 1) / (static_cast<double>(blocks) * 1024.0)) + 2.0;
-    const int e_n = static_cast<int>(std::ceil(std::log2(per_wg))) + 1;  // 2^e_n > the terms a bin can receive
-    const double bounds[3] = {1.0, bound_p, deltaf ? bound_w : 1.0};
-    for (int k = 0; k < 3; ++k) {
-      int eb;
-      (void)std::frexp(bounds[k], &eb);               // bounds[k] < 2^eb
-      const int mag = std::min(62 - e_n, 50);         // |term * 2^e| < 2^mag: below 2^51 for to_fixed, and the sums below 2^62
-      const int e = mag - eb;
-      if (e < -900 || e > 900) use_fx = false;        // (a bound no scale can serve)
-      fx.sc[k] = std::ldexp(1.0, e);
-      fx.inv[k] = std::ldexp(1.0, -e);
-      fx.bound[k] = std::ldexp(1.0, eb);
-    }
-  }
+  const bool use_fx = lds && make_dist_scale(np, blocks, deltaf, bound_p, bound_w, &fx);
   if (fixed_point) *fixed_point = use_fx;
   auto go = [&](auto kern) -> hipError_t {
     if (lds && bytes > 64 * 1024) {

@@ -156,8 +156,10 @@ __device__ __forceinline__ One step_full_one(double x, double v, double w, doubl
 // the kinetic sums of output_field (k_ptcldist's work: another 32 B per marker read) are taken here on
 // the state just computed, into an LDS copy of the histograms next to the grid tiles (one workgroup
 // of 1024 threads per CU then).
-template <int DIST, int MODE, int POW2, bool NT, bool CARRY, bool DIAG>
+// FX (DIAG): the LDS copy of the histograms as 64-bit fixed-point sums (device_diag.hpp DistScale), as in k_ptcldist
+template <int DIST, int MODE, int POW2, bool NT, bool CARRY, bool DIAG, bool FX = false>
 __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
+  static_assert(!FX || DIAG, "fixed-point sums are the diagnostics'");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   exp_table_init();
   const int nx = a.g.nx;
@@ -210,8 +212,8 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
     if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
     if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
     if constexpr (DIAG) {
-      ptcldist_one<true, HAS_W>(n0.x, n0.v, P.x, n0.w, a.dg, bins, sums);
-      ptcldist_one<true, HAS_W>(n1.x, n1.v, P.y, n1.w, a.dg, bins, sums);
+      ptcldist_one<true, HAS_W, FX>(n0.x, n0.v, P.x, n0.w, a.dg, bins, sums, &a.dscale);
+      ptcldist_one<true, HAS_W, FX>(n1.x, n1.v, P.y, n1.w, a.dg, bins, sums, &a.dscale);
     }
   }
   if ((a.np & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -222,11 +224,11 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
     a.x[i] = n.x;
     if constexpr (PUSH_V) a.v[i] = n.v;
     if constexpr (HAS_W) a.w[i] = n.w;
-    if constexpr (DIAG) ptcldist_one<true, HAS_W>(n.x, n.v, a.p[i], n.w, a.dg, bins, sums);
+    if constexpr (DIAG) ptcldist_one<true, HAS_W, FX>(n.x, n.v, a.p[i], n.w, a.dg, bins, sums, &a.dscale);
   }
   __syncthreads();
   flush_rho(sR0, a.rho, a.g);
-  if constexpr (DIAG) ptcldist_finish<true, HAS_W>(a.dg, bins, sums, sH + ntot, a.dist_out, a.dist_partial);
+  if constexpr (DIAG) ptcldist_finish<true, HAS_W, FX, 6>(a.dg, bins, sums, sH + ntot, a.dist_out, a.dist_partial, &a.dscale);
 }
 
 // ---------------------------------------------------------------------------
@@ -1182,9 +1184,13 @@ hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc,
     if (d.pred_nm == 4) return launch_step_one<DIST, MODE, POW2, 4>(d, t2m, lc, st);
     return hipErrorInvalidValue;  // PRED_MAX_MODES
   }
-  if (full && d.dist_out)  // with the diagnostics of output_all
+  if (full && d.dist_out) {  // with the diagnostics of output_all (their histograms as fixed-point sums where the host knows bounds)
+    if (d.diag_fx)
+      return d.nt ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY, true, true>, d, lc, st)
+                  : launch_step_kernel(k_step_full<DIST, MODE, POW2, false, CARRY, true, true>, d, lc, st);
     return d.nt ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY, true>, d, lc, st)
                 : launch_step_kernel(k_step_full<DIST, MODE, POW2, false, CARRY, true>, d, lc, st);
+  }
   if (d.nt)
     return full ? launch_step_kernel(k_step_full<DIST, MODE, POW2, true, CARRY, false>, d, lc, st)
                 : launch_step_kernel(k_step_half<DIST, MODE, POW2, true, CARRY>, d, lc, st);

@@ -28,6 +28,8 @@ struct StepArgsDev {
   double snx, pred_k;           // k_step_one's prediction: nx / lx, and dt/2 Z/m
   FusedSolve fused;             // kernels.hpp: the prologue solves the previous step's field
   StepTail tail;                // kernels.hpp: the last workgroup packs / posts this rank's charge
+  DistScale dscale;             // k_step_full<DIAG, FX>
+  int diag_fx;
   int wave_prio;                // (experiment) issue priority by progress
   int dyn_tail;                 // sixteenths of a workgroup's chunks drawn from an LDS counter
 #ifdef PIC1DP_TUNE_SUMS2  // tuning build (tools/ab_sums2.sh): two kept modes as twenty private sums (marker kernel only)

@@ -36,6 +36,8 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.tail = a.tail;
   d.dyn_tail = a.dyn_tail;
   d.wave_prio = a.wave_prio;
+  d.dscale = a.dscale;
+  d.diag_fx = a.diag_fx;
 #ifdef PIC1DP_TUNE_SUMS2
   d.sums2 = a.sums2;
 #endif
