@@ -542,6 +542,50 @@ def test_fixed_point_histograms_repeat_in_doubles_on_overflow(amd, monkeypatch):
     assert a.kernel_stats(12)[1] == 2 and a.kernel_stats(12)[0] == 2.0     # both fixed-point passes overflowed and were repeated
 
 
+@pytest.mark.parametrize("margin", [None, "0.5"], ids=["in_bounds", "overflow_repeats"])
+@pytest.mark.parametrize("predict", ["1", "0"], ids=["one_pass", "two_passes"])
+def test_fixed_point_histograms_inside_the_step_kernel(oracle_mod, amd, monkeypatch, predict, margin):
+    """the diagnostics taken INSIDE the step output_all follows (k_step_full<DIAG>; set_output_fusion 2 always, 1 where a
+    step is two passes anyway) sum their histograms as 64-bit fixed-point numbers as well, scaled from the record before:
+    against the same engine with double sums 1e-12 of the largest bin and against the oracle; with the margin on max |w|
+    below one the next record's largest weights are beyond the bounds: the collector notices and repeats in doubles"""
+    kw = dict(nparticle_max=300_000, nx=128, output_interval=0.5)
+    monkeypatch.setenv("PIC1DP_PREDICT", predict)
+    if margin:
+        monkeypatch.setenv("PIC1DP_DIAG_FX_MARGIN", margin)
+    engs = []
+    for fx in ("1", "0"):
+        monkeypatch.setenv("PIC1DP_DIAG_FX", fx)
+        e = amd.Pic1dp(amd.make_input(**kw))
+        e.set_output_fusion(2 if predict == "1" else 1)
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+        e.kernel_stats_enable(True)
+        engs.append(e)
+    a, b = engs
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    for rec in range(4):
+        pa, pb, po = a.ptcldist(), b.ptcldist(), sim.ptcldist()
+        for k in pa:
+            scale = max(np.max(np.abs(pb[k])), 1e-300)
+            assert np.max(np.abs(pa[k] - pb[k])) <= 1e-12 * scale, (rec, k)
+            assert relerr(np.asarray(pa[k]).ravel(), np.asarray(po[k]).ravel()) < 1e-9, (rec, k)
+        assert np.allclose(a.output_scalars(), b.output_scalars(), rtol=1e-12, atol=0.0)
+        for e in (a, b):
+            e.step(10)                      # the tenth step is followed by output_all: it takes the diagnostics along
+        sim.step(10)
+    fx_passes, repeats = a.kernel_stats(12)[1], a.kernel_stats(12)[0]
+    # record 0: the diagnostics' own pass (no step before it), bounds unknown: doubles.  Records 1 .. 3 and the step after
+    # the last look: inside the step kernel, in fixed point from the moment the bounds are known
+    assert fx_passes >= 3 and b.kernel_stats(12)[1] == 0, (fx_passes, repeats)
+    assert (repeats >= 2.0) if margin else (repeats == 0.0), repeats
+    assert a.kernel_stats(5)[1] == 1 + int(repeats)   # k_ptcldist: record 0, and the repeats' double passes
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(linear=1), dict(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0]),
                                 dict(nparticle_max=150_001, species_nparticle_init=[140_000]),
                                 dict(nspecies=2, species_charge=[-1.0, 1.0], species_mass=[1.0, 4.0], species_temperature=[1.0, 1.0],
