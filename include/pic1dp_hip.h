@@ -292,7 +292,9 @@ int pic1dp_hip_predict_kind(pic1dp_ctx *ctx, int32_t *kind);
  * sums of output_field inside its marker kernel, on the state it has just computed
  * (k_step_full<DIAG>): pic1dp_hip_output_scalars / pic1dp_hip_ptcldist then cost no pass over the
  * markers.  Results equal the separate pass up to the summation order of the atomics.
- *   on = 0 (default): never -- a host that never asks for output would pay ~30 % on that launch;
+ * Cost at 1e8 markers: inside a two-pass step +0.17 ms an output (the histograms as 64-bit
+ * fixed-point sums in the LDS; +0.48 as double sums, +0.6 as a pass of its own).
+ *   on = 0 (default): never -- a host that never asks for output would pay ~20 % on that launch;
  *   on = 1: where it pays.  Not on a predicted one-pass step (pic1dp_hip_predict_kind != 0):
  *           k_step_full<DIAG> cannot predict the next step's half-step charge, so the step after
  *           the output would run a first-sub-step pass again; there the step stays k_step_one and
