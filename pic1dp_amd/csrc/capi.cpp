@@ -935,10 +935,10 @@ int pic1dp_hip_set_chargeden(pic1dp_ctx *c, const double *cd) {
   if (!cd) return fail(PIC1DP_ERR_ARG, "null array");
   HIP_TRY(hipSetDevice(c->device));
   if (int rc = materialize_cd(c)) return rc;  // pending deposits are consumed, then overwritten
-  if (c->cd_lazy == 5) {                      // (a half-step field waiting to be adopted: the host's charge density rules now)
-    if (int rc = settle_half_pair(c)) return rc;
-    c->cd_lazy = 0;
-  }
+  // a half-step field waiting to be adopted, or adopted as far as the host can tell but not yet copied (half_solved): memory
+  // first becomes what the eager calls leave -- the adoption writes field_chargeden too --, then the host's vector rules
+  if (int rc = settle_half_pair(c)) return rc;
+  if (c->cd_lazy == 5) c->cd_lazy = 0;
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(c->d_chargeden, cd, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
   c->cd_kept_mode_only = false;

@@ -404,40 +404,51 @@ int pic1dp_hip_output_all(pic1dp_ctx *c, double *scalars, int32_t nscal, double 
   }
   HIP_TRY(hipStreamSynchronize(c->st));
   if (int rc = xchg_check(c)) return rc;
+  // a species' kinetic sums from its slots of the record (the pass's per-workgroup partial sums, then the tail slots'), and
+  // whether the pass saw a marker beyond its fixed-point bounds
+  auto fold = [&](int s) -> bool {
+    double *acc = &c->diag_sums[3 * static_cast<size_t>(s)];
+    const int blocks = c->diag_blocks[s], stride = c->diag_stride[s];
+    const double *part = h + off_part[s], *tail = h + off_tail[s];
+    acc[0] = acc[1] = acc[2] = 0.0;
+    double maxp = 0.0, maxw = 0.0, over = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+      for (int k = 0; k < 3; ++k) acc[k] += part[b * stride + k];
+      if (stride >= 6) {
+        maxp = std::max(maxp, part[b * stride + 3]);
+        maxw = std::max(maxw, part[b * stride + 4]);
+        over = std::max(over, part[b * stride + 5]);
+      }
+    }
+    for (int b = 0; b < tb[s]; ++b)
+      for (int k = 0; k < 3; ++k) acc[k] += tail[b * 3 + k];
+    if (stride >= 6 && blocks > 0) {
+      c->diag_max_p[s] = maxp;
+      c->diag_max_w[s] = maxw;
+    }
+    return over > 0.0;
+  };
   std::vector<double> sums(3 * static_cast<size_t>(ns));
   for (int s = 0; s < ns; ++s) {
-    double *acc = &c->diag_sums[3 * static_cast<size_t>(s)];
     if (c->diag_pending[s]) {
-      const int blocks = c->diag_blocks[s], stride = c->diag_stride[s];
-      const double *part = h + off_part[s], *tail = h + off_tail[s];
-      acc[0] = acc[1] = acc[2] = 0.0;
-      double maxp = 0.0, maxw = 0.0, over = 0.0;
-      for (int b = 0; b < blocks; ++b) {
-        for (int k = 0; k < 3; ++k) acc[k] += part[b * stride + k];
-        if (stride >= 6) {
-          maxp = std::max(maxp, part[b * stride + 3]);
-          maxw = std::max(maxw, part[b * stride + 4]);
-          over = std::max(over, part[b * stride + 5]);
-        }
-      }
-      for (int b = 0; b < tb[s]; ++b)
-        for (int k = 0; k < 3; ++k) acc[k] += tail[b * 3 + k];
-      if (stride >= 6 && blocks > 0) {
-        c->diag_max_p[s] = maxp;
-        c->diag_max_w[s] = maxw;
-      }
-      c->diag_pending[s] = 0;
-      if (fixed[s] && over > 0.0) {  // a marker beyond the fixed-point bounds: this species once more, in doubles (rare)
+      if (fold(s) && fixed[s]) {
+        // a marker beyond the fixed-point bounds: this species once more, in doubles (rare).  The repeat's partial sums and
+        // histograms go into THIS species' slots of the record -- everything else in it (the fields, the other species) is
+        // still to be read (the repeat used to stage through the start of the same buffer); the tail slots' sums
+        // are the ones already there
         c->diag_fx_repeats++;
         bool was_fixed = false;
         if (int rc = run_diag_pass(c, s, false, &was_fixed)) return rc;
-        c->diag_pending[s] = 1;
-        if (int rc = ensure_diag(c, s)) return rc;
-        if (dist) {
-          HIP_TRY(hipMemcpyAsync(h + off_hist[s], c->d_dist + ntot * s, sizeof(double) * ntot, hipMemcpyDeviceToHost, c->st));
-          HIP_TRY(hipStreamSynchronize(c->st));
-        }
+        const size_t npart = static_cast<size_t>(c->diag_blocks[s]) * c->diag_stride[s];
+        if (npart > static_cast<size_t>(6) * diag_max_blocks(c)) return fail(PIC1DP_ERR_STATE, "diagnostics: more partial sums than their slot holds");
+        if (npart > 0)
+          HIP_TRY(hipMemcpyAsync(h + off_part[s], c->d_diag_part + static_cast<size_t>(6) * diag_max_blocks(c) * s, sizeof(double) * npart,
+                                 hipMemcpyDeviceToHost, c->st));
+        if (dist) HIP_TRY(hipMemcpyAsync(h + off_hist[s], c->d_dist + ntot * s, sizeof(double) * ntot, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        (void)fold(s);
       }
+      c->diag_pending[s] = 0;
     }
     for (int k = 0; k < 3; ++k) sums[3 * s + k] = c->diag_sums[3 * static_cast<size_t>(s) + k];
     if (!in.deltaf) sums[3 * s + 2] = sums[3 * s + 1];

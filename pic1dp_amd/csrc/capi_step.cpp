@@ -194,9 +194,13 @@ int pic1dp_host::settle_half_pair(pic1dp_ctx *c) {
 // for readers of the field only: nothing to do until the host has called solve_field for the half step -- until then
 // field_electric is the step-start field, which is what d_E holds
 int pic1dp_host::settle_field_view(pic1dp_ctx *c) { return c->half_pair && c->half_solved ? settle_half_pair(c) : 0; }
-// field_electric and its kept modes <- the half-step field the pair solve left in d_Ehn / d_mode_h
+// field_electric and its kept modes <- the half-step field the pair solve left in d_Ehn / d_mode_h, and field_chargeden
+// <- the kept mode's content of the half-step charge density it left in d_cd_h (what collect_charge leaves there when it
+// is served from the six sums, cd_lazy 4): a solve_field that solves from field_chargeden again reproduces the half-step
+// field, as it does after eager calls
 int pic1dp_host::adopt_half_field(pic1dp_ctx *c) {
   const size_t nx = c->in.nx, nm = c->in.nmode;
+  HIP_TRY(hipMemcpyAsync(c->d_chargeden, c->d_cd_h, sizeof(double) * nx, hipMemcpyDeviceToDevice, c->st));
   HIP_TRY(hipMemcpyAsync(c->d_E, c->d_Ehn, sizeof(double) * nx, hipMemcpyDeviceToDevice, c->st));
   HIP_TRY(hipMemcpyAsync(c->fa.mode_re, c->d_mode_h, sizeof(double) * nm, hipMemcpyDeviceToDevice, c->st));
   HIP_TRY(hipMemcpyAsync(c->fa.mode_im, c->d_mode_h + nm, sizeof(double) * nm, hipMemcpyDeviceToDevice, c->st));
@@ -939,7 +943,8 @@ static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred) {
   const bool pair = pred && c->pred_version == c->state_version && (!multi || fused_xchg || will_pack) &&
                     c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (pair) {
-    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, c->pair_plain, 0};
+    // (cd_h: the tiles' scratch; with the six sums only the call sites want the half-step charge density's kept mode)
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->pred_kind == 2 ? nullptr : c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, c->pair_plain, 0};
     if (will_pack) {  // both charge sums of the step came in ONE all-reduce (pack_doubles)
       pa.pack = c->d_pack;
       HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));

@@ -81,10 +81,16 @@ __device__ __forceinline__ void exchange_wait_sum(const XchgArgs &x, double *sV,
 __device__ __forceinline__ void step_tail(const StepTail &t, double *sV) {
   // (no static LDS of its own: the marker kernels' dynamic tiles may take all but the exp table's 1 KiB of the CU's 160)
   int *s_last = reinterpret_cast<int *>(sV);
+  // Ordering (formal, not by ISA accident).  Every wave's accumulator atomics are relaxed agent-scope RMWs;
+  // the workgroup barrier orders them before lane 0's ticket add, which is a RELEASE at agent scope (cumulative over the
+  // barrier); the workgroup that draws the last ticket ACQUIRES with the same add, and its barrier hands that to the other
+  // threads' agent-scope loads below.  The explicit vmcnt wait stays: on gfx9 a no-return atomic is complete -- performed at
+  // the memory side, beyond the per-XCD L2s -- once vmcnt has counted it, and ROCm 7.2 is known to drop a fence's own wait
+  // when it believes the scoreboard empty (guide, G16 pitfall 12).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics have been performed
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     *s_last = prev + 1u == gridDim.x ? 1 : 0;
   }
   __syncthreads();  // (the ticket's lane has its answer: the barrier is behind the returned add)

@@ -942,6 +942,14 @@ k_field_solve_pair_sums1(const FieldArgs f, const XchgArgs x1, const PairArgs pa
     pa.mode_h[0] = re_h;
     pa.mode_h[1] = im_h;
   }
+  // call sites: the kept mode's content of the half-step charge density, as k_pred_chargeden forms it -- what
+  // field_chargeden has to hold once the host has called solve_field for the half step (adopt_half_field)
+  double alpha = 0.0, beta = 0.0;
+  if (pa.cd_h) {
+    const double det = pa.pt.g11 * pa.pt.g22 - pa.pt.g12 * pa.pt.g12;
+    alpha = (ac * pa.pt.g22 - as * pa.pt.g12) / det;
+    beta = (as * pa.pt.g11 - ac * pa.pt.g12) / det;
+  }
   double e2 = 0.0;
   const bool one_trip = nx <= U * T;
   for (int base = threadIdx.x; base < nx; base += U * T) {
@@ -967,6 +975,7 @@ k_field_solve_pair_sums1(const FieldArgs f, const XchgArgs x1, const PairArgs pa
         b = b + tr[u] * re_h;
         b = b + ti[u] * im_h;
         pa.E_h[ix] = b * 2.0;
+        if (pa.cd_h) pa.cd_h[ix] = alpha * tr[u] + beta * ti[u];
       }
     }
   }

@@ -11,6 +11,7 @@
 ! MPI calls named above and nothing else changes.
 module pic1dp_host_ranks
 use iso_c_binding
+use pic1dp_hip, only: pic1dp_hip_abort
 implicit none
 
 integer :: ranks_rank = 0, ranks_size = 1
@@ -91,7 +92,7 @@ subroutine ranks_fetch(path, bytes, nbytes)
     waited = waited + 0.002
     if (waited > ranks_timeout_s) then
       write (*, '(3a)') 'Error: rank file ', trim(path), ' did not appear (a peer stopped?)'
-      stop 1
+      call pic1dp_hip_abort()   ! (stops; a buffered record of pic1dp.out is written first)
     end if
   end do
   open (newunit=u, file=trim(path), access='stream', form='unformatted', status='old', iostat=stat)

@@ -504,6 +504,13 @@ interface
   end function pic1dp_hip_kernel_bytes
 end interface
 
+! called by pic1dp_hip_check before it stops the program on an error (a host with buffered output flushes it there)
+abstract interface
+  subroutine pic1dp_hip_abort_hook()
+  end subroutine pic1dp_hip_abort_hook
+end interface
+procedure(pic1dp_hip_abort_hook), pointer, save :: pic1dp_hip_on_abort => null()
+
 contains
 
 ! message of the last failed call as a Fortran string
@@ -533,8 +540,21 @@ subroutine pic1dp_hip_check(ierr, where)
   character(len=*), intent(in) :: where
   if (ierr /= 0) then
     write (*, '(5a, i0, a)') 'pic1dp_hip: ', where, ': ', pic1dp_hip_last_error(), ' (error ', ierr, ')'
-    stop 1
+    ! what the host still holds in memory goes out first (the record output_all has assembled: the reference has written
+    ! it by the time a later call fails)
+    call pic1dp_hip_abort()
   end if
 end subroutine pic1dp_hip_check
+
+! stop on an error, after the host's hook has run (once: it is taken off first, a failure inside it cannot come back)
+subroutine pic1dp_hip_abort()
+  procedure(pic1dp_hip_abort_hook), pointer :: hook
+  if (associated(pic1dp_hip_on_abort)) then
+    hook => pic1dp_hip_on_abort
+    pic1dp_hip_on_abort => null()
+    call hook()
+  end if
+  stop 1
+end subroutine pic1dp_hip_abort
 
 end module pic1dp_hip

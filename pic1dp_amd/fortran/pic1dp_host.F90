@@ -75,6 +75,7 @@ end if
 verbosity = input_verbosity
 if (ranks_rank /= 0) verbosity = 0          ! PetscPrintf prints on rank 0 only (src/pic1dp_global.F90:71-90)
 if (ranks_rank == 0) call output_init(inp)
+if (ranks_rank == 0) pic1dp_hip_on_abort => output_final   ! a record assembled but not yet written survives a stop on error
 call get_environment_variable('PIC1DP_FUSED', buf, status=stat)
 fused = (stat == 0 .and. buf(1:1) == '1')
 whole_step = (stat == 0 .and. (buf(1:1) == '2' .or. buf(1:1) == '3'))
@@ -159,7 +160,12 @@ if (verbosity >= 1) then
   call pic1dp_hip_check(pic1dp_hip_timer_ms(ctx, PIC1DP_IWT_PUSH_PARTICLE, ms_push), 'timer')
   call pic1dp_hip_check(pic1dp_hip_timer_ms(ctx, PIC1DP_IWT_COLLECT_CHARGE, ms_charge), 'timer')
   call pic1dp_hip_check(pic1dp_hip_timer_ms(ctx, PIC1DP_IWT_FIELD_ELECTRIC, ms_field), 'timer')
-  write (*, '(a)') 'Info: timers (GPU, ms):'
+  if (timer_mode > 1) then   ! (the reference's wtimer totals are exact: say so when these are not)
+    write (*, '(a, i0, a)') 'Info: timers (GPU, ms; estimates: launches of every ', timer_mode, &
+      'th block of 64 timed and scaled, PIC1DP_TIMERS=1 times every launch):'
+  else
+    write (*, '(a)') 'Info: timers (GPU, ms):'
+  end if
   write (*, '(a, f12.3, a, f12.3, a, f12.3)') '   push particle', ms_push, '   collect charge', ms_charge, &
     '   electric field', ms_field
 end if

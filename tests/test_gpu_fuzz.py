@@ -270,7 +270,7 @@ def test_random_call_sequences_predicted_equals_two_pass(amd, monkeypatch, seed,
     for i in range(40):
         r = rng.random()
         if phase == 1:                          # mid-step: finish it, perhaps after a look or a field change
-            op = str(rng.choice(["sub2", "sub2", "sub2", "look", "setE", "sums"]))
+            op = str(rng.choice(["sub2", "sub2", "sub2", "look", "setE", "sums", "resolve"]))
         elif r < 0.45:
             op = "step"
         elif r < 0.75:
@@ -314,3 +314,54 @@ def test_random_call_sequences_predicted_equals_two_pass(amd, monkeypatch, seed,
     assert len(ha) == len(hb)
     if len(hb):
         close(ha, hb, "energy history")
+
+
+@pytest.mark.parametrize("disturb", ["nothing", "set_electric", "look"])
+def test_solve_field_twice_for_the_half_step(amd, monkeypatch, disturb):
+    """through the call sites the solve_field of a half step launches nothing (its field came out of the previous
+    step's pair solve) -- field_chargeden must nevertheless be what a SECOND solve_field for the same half step solves from
+    (the kept mode's content of the half-step charge density), also after the host has overwritten field_electric in
+    between: against an engine that runs every call eagerly, 1e-10 on the field and on the markers after the step"""
+    kw = dict(nparticle_max=40001, nx=64, init_mode_sin=[1e-3])
+    a = Checked(amd.Pic1dp(amd.make_input(**kw)))
+    monkeypatch.setenv("PIC1DP_LAZY_CALLS", "0")
+    monkeypatch.setenv("PIC1DP_PREDICT", "0")
+    b = Checked(amd.Pic1dp(amd.make_input(**kw)))
+    monkeypatch.delenv("PIC1DP_LAZY_CALLS")
+    monkeypatch.delenv("PIC1DP_PREDICT")
+    for e in (a, b):
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+
+    def calls(e, irk):
+        e.interaction_push_particle(irk)
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+
+    def close(x, y, what):
+        assert np.max(np.abs(x - y)) <= 1e-10 * max(np.max(np.abs(y)), 1e-300), what
+
+    for e in (a, b):                            # two whole steps through the call sites: the pair solve is in use from the second
+        for _ in range(2):
+            calls(e, 1)
+            calls(e, 2)
+    skips = a.kernel_stats(11)[1]
+    for e in (a, b):
+        calls(e, 1)                             # a: push noted, collect_charge and solve_field launch nothing
+    assert a.kernel_stats(11)[1] == skips + 1   # (the case this test is about)
+    if disturb == "set_electric":
+        E = 0.01 * np.cos(2 * np.pi * np.arange(64) / 64)
+        for e in (a, b):
+            e.set_electric(E)
+    elif disturb == "look":
+        close(a.get_field()["electric"], b.get_field()["electric"], "half-step field")
+    for e in (a, b):
+        e.field_solve_electric()                # once more: from field_chargeden
+    close(a.get_field()["electric"], b.get_field()["electric"], "half-step field solved again")
+    for e in (a, b):
+        calls(e, 2)
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        close(ga[k], gb[k], k)
+    close(a.get_field()["electric"], b.get_field()["electric"], "field after the step")

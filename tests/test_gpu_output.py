@@ -624,3 +624,42 @@ def test_output_all_in_one_call_equals_the_separate_calls(amd, kw):
         assert a.kernel_stats(5)[1] == passes and np.array_equal(scal2, scal)
         for e in (a, b):
             e.step(10)
+
+
+@pytest.mark.parametrize("two_species", [False, True], ids=["one_species", "two_species"])
+def test_output_all_record_survives_a_fixed_point_repeat(amd, monkeypatch, two_species):
+    """when a fixed-point diagnostics pass meets a marker beyond its bounds, pic1dp_hip_output_all repeats
+    that species' pass in doubles -- and the repeat must not stage through the part of the pinned record that still holds
+    E, chargeden, the modes, int E^2 dx and the other species' sums.  The margin on max |w| below one makes every record
+    after the first overflow; fields, scalars and histograms against a twin engine with double sums and the separate calls"""
+    base = dict(nparticle_max=200_000, nx=96, output_interval=0.5)
+    if two_species:
+        base.update(nspecies=2, species_charge=[-1.0, 1.0], species_mass=[1.0, 4.0], species_temperature=[1.0, 1.0],
+                    species_temperature2=[1.0, 1.0], species_density=[0.9, 0.9], species_v0=[5.0, 5.0],
+                    species_nparticle_init=[120_000, 90_000])
+    monkeypatch.setenv("PIC1DP_DIAG_FX_MARGIN", "0.5")
+    a = amd.Pic1dp(amd.make_input(**base))
+    monkeypatch.setenv("PIC1DP_DIAG_FX", "0")
+    b = amd.Pic1dp(amd.make_input(**base))
+    for e in (a, b):
+        e.set_output_fusion(1)
+        e.particle_load()
+        e.interaction_collect_charge()
+        e.field_solve_electric()
+    ns = base.get("nspecies", 1)
+    for rec in range(3):
+        scal, fld, dists = a.output_all()
+        want_scal, want_fld = b.output_scalars(), b.get_field()
+        tol = 1e-11 * np.abs(want_scal)
+        for isp in range(ns):
+            tol[4 + 3 * isp] = max(tol[4 + 3 * isp], 1e-12 * abs(want_scal[3 + 3 * isp]))
+        assert np.all(np.abs(scal - want_scal) <= tol), (rec, scal, want_scal)
+        for k in ("electric", "chargeden", "mode_re", "mode_im"):
+            assert relerr(fld[k], want_fld[k]) < 1e-11, (rec, k)
+        for isp in range(ns):
+            want = b.ptcldist(isp)
+            for k in want:
+                assert np.max(np.abs(dists[isp][k] - want[k])) <= 1e-11 * max(np.max(np.abs(want[k])), 1e-300), (rec, isp, k)
+        for e in (a, b):
+            e.step(10)
+    assert a.kernel_stats(12)[0] >= 2.0          # the records after the first one were repeated in doubles
