@@ -454,7 +454,11 @@ int pic1dp_hip_comm_available(void);
  * run.  Set-up: every rank calls xchg_create and hands its 64-byte handle to all
  * ranks (MPI_Allgather / torch.distributed.all_gather); every rank then calls
  * xchg_connect with the nranks handles in rank order (handles[rank] is its own),
- * and set_allreduce(2) on all ranks at the same point of the run.  A rank that
+ * and set_allreduce(2) on all ranks at the same point of the run.  Ranks may be
+ * separate processes (the areas are mapped through hipIpc) or contexts of ONE
+ * process, each driven by its own host thread (a handle made in this process is
+ * recognised and its area addressed directly, with peer access enabled when it
+ * lies on another device): the reference's `mpiexec -n N` either way.  A rank that
  * waits longer than PIC1DP_XCHG_TIMEOUT_MS (default 20 000) for a peer gives up:
  * the kernels always finish and the next synchronising call returns
  * PIC1DP_ERR_COMM. */

@@ -1,5 +1,7 @@
 // capi_comm.cpp -- the charge sum over ranks: RCCL communicator (bound with dlopen, rccl_dyn.hpp), the one-hop
 // exchange's set-up over IPC-mapped memory, and the helpers the hot path calls (src/pic1dp_interaction.F90:126-135).
+#include <mutex>
+
 #include "ctx.hpp"
 
 namespace pic1dp_host {
@@ -17,6 +19,45 @@ int allreduce_charge(pic1dp_ctx *c) {
 }
 
 constexpr size_t kXchgFlagBytes = 4096;  // flags[2][XCHG_MAX_RANKS] u64, padded
+
+// Exchange areas created in THIS process, by their IPC handle: a host that drives several ranks from one process (one
+// thread per GPU, or several contexts on one GPU) hands xchg_connect handles of its own making -- hipIpcOpenMemHandle
+// refuses those, and there is nothing to open: the area is addressable as it is (on another device of the process once
+// peer access is enabled).
+struct LocalArea {
+  unsigned char handle[PIC1DP_XCHG_HANDLE_BYTES];
+  void *ptr;
+  int device;
+};
+std::mutex g_areas_mu;
+std::vector<LocalArea> g_areas;
+
+void area_register(const unsigned char *handle, void *ptr, int device) {
+  std::lock_guard<std::mutex> lk(g_areas_mu);
+  LocalArea a{};
+  std::memcpy(a.handle, handle, sizeof a.handle);
+  a.ptr = ptr;
+  a.device = device;
+  g_areas.push_back(a);
+}
+void area_forget(void *ptr) {
+  std::lock_guard<std::mutex> lk(g_areas_mu);
+  for (size_t i = 0; i < g_areas.size(); ++i)
+    if (g_areas[i].ptr == ptr) {
+      g_areas.erase(g_areas.begin() + static_cast<std::ptrdiff_t>(i));
+      return;
+    }
+}
+bool area_lookup(const unsigned char *handle, void **ptr, int *device) {
+  std::lock_guard<std::mutex> lk(g_areas_mu);
+  for (const LocalArea &a : g_areas)
+    if (std::memcmp(a.handle, handle, sizeof a.handle) == 0) {
+      *ptr = a.ptr;
+      *device = a.device;
+      return true;
+    }
+  return false;
+}
 
 bool xchg_active(const pic1dp_ctx *c) { return c->allreduce_kind == 2 && c->xc.connected; }
 
@@ -77,7 +118,10 @@ void comm_release(pic1dp_ctx *c) {
   }
   for (int q = 0; q < XCHG_MAX_RANKS; ++q)
     if (c->xc.opened[q]) (void)hipIpcCloseMemHandle(c->xc.peer[q]);
-  if (c->xc.local) (void)hipFree(c->xc.local);
+  if (c->xc.local) {
+    area_forget(c->xc.local);
+    (void)hipFree(c->xc.local);
+  }
   if (c->xc.err) (void)hipHostFree(c->xc.err);
   (void)hipFree(c->xc.ticks);
 }
@@ -182,6 +226,7 @@ int pic1dp_hip_xchg_create(pic1dp_ctx *c, unsigned char handle[PIC1DP_XCHG_HANDL
     HIP_TRY(hipMemset(c->xc.ticks, 0, 2 * sizeof(unsigned long long)));
   }
   HIP_TRY(hipDeviceSynchronize());
+  area_register(handle, c->xc.local, c->device);
   return 0;
 }
 
@@ -194,6 +239,21 @@ int pic1dp_hip_xchg_connect(pic1dp_ctx *c, const unsigned char *handles) {
   for (int q = 0; q < c->lay.nranks; ++q) {
     if (q == c->lay.rank) {
       c->xc.peer[q] = c->xc.local;
+      continue;
+    }
+    void *mine = nullptr;
+    int dev = -1;
+    if (area_lookup(handles + static_cast<size_t>(q) * PIC1DP_XCHG_HANDLE_BYTES, &mine, &dev)) {  // a rank of this very process
+      if (dev != c->device) {
+        hipError_t pe = hipDeviceEnablePeerAccess(dev, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+          (void)hipGetLastError();
+          return fail(PIC1DP_ERR_COMM, "peer access from device %d to device %d (rank %d of this process): %s", c->device, dev, q,
+                      hipGetErrorString(pe));
+        }
+        (void)hipGetLastError();
+      }
+      c->xc.peer[q] = mine;
       continue;
     }
     hipIpcMemHandle_t h;

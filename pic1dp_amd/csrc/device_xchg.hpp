@@ -81,16 +81,22 @@ __device__ __forceinline__ void exchange_wait_sum(const XchgArgs &x, double *sV,
 __device__ __forceinline__ void step_tail(const StepTail &t, double *sV) {
   // (no static LDS of its own: the marker kernels' dynamic tiles may take all but the exp table's 1 KiB of the CU's 160)
   int *s_last = reinterpret_cast<int *>(sV);
-  // Ordering (formal, not by ISA accident).  Every wave's accumulator atomics are relaxed agent-scope RMWs;
-  // the workgroup barrier orders them before lane 0's ticket add, which is a RELEASE at agent scope (cumulative over the
-  // barrier); the workgroup that draws the last ticket ACQUIRES with the same add, and its barrier hands that to the other
-  // threads' agent-scope loads below.  The explicit vmcnt wait stays: on gfx9 a no-return atomic is complete -- performed at
-  // the memory side, beyond the per-XCD L2s -- once vmcnt has counted it, and ROCm 7.2 is known to drop a fence's own wait
-  // when it believes the scoreboard empty (guide, G16 pitfall 12).
+  // Ordering.  What is handed over are agent-scope atomics ON BOTH SIDES (relaxed RMWs by the producers, agent-scope loads
+  // by the last arriver) signalled through one unsharded counter whose returned value names the last arriver -- one of the
+  // forms the CDNA4 notes list as valid on gfx950 ("8-B agent atomics both sides", MI355X_MICROARCH.md, Valid forms):
+  // a no-return atomic is performed at the memory side, beyond the per-XCD L2s, once the issuing wave's vmcnt has counted
+  // it, so "every wave waits for vmcnt(0), the workgroup meets, one lane adds to the counter" orders them before the
+  // ticket.  That is an ISA-level argument, not one the HIP memory model makes: the model's form is a RELEASE on the
+  // ticket add.  Built and measured in round 6 (__ATOMIC_ACQ_REL on the add): the compiler's agent-scope
+  // release is buffer_wbl2 sc1 -- a write-back of the XCD L2's dirty lines, i.e. of the marker stores this very kernel
+  // has just made -- once per workgroup: the 8-way share's marker launch 123.5 -> 142.2 us, the step 0.1293 -> 0.1475 ms
+  // (profiles/r06/experiments/ab_tail_order.log), 7.2x -> 6.4x of the strong-scaling budget for an ordering the atomics
+  // do not need (nothing handed over here is a plain store).  Hence relaxed + the explicit wait; tools/tail_soak.py and
+  // the bit-identity tests of the tail (tests/test_gpu_exchange.py, test_gpu_one_pass.py) are the evidence it holds.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics have been performed
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_last = prev + 1u == gridDim.x ? 1 : 0;
   }
   __syncthreads();  // (the ticket's lane has its answer: the barrier is behind the returned add)

@@ -17,15 +17,17 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(tmp_path, nproc, kw, steps, mode, port, timeout_ms="60000"):
+def run_ranks(tmp_path, nproc, kw, steps, mode, port, timeout_ms="60000", per=1):
+    """nproc processes of `per` ranks each (one context and one host thread per rank)"""
     out = str(tmp_path / ("xchg_%s_%d" % (mode, nproc)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PIC1DP_XCHG_TIMEOUT_MS=timeout_ms)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PIC1DP_XCHG_TIMEOUT_MS=timeout_ms,
+               PIC1DP_RANKS_PER_PROC=str(per))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "xchg_worker.py"),
            out, json.dumps(kw), str(steps), mode]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return [np.load(out + ".rank%d.npz" % k) for k in range(nproc)]
+    return [np.load(out + ".rank%d.npz" % k) for k in range(nproc * per)]
 
 
 @pytest.mark.parametrize("nproc,mode,kind,nx", [(2, "step", 1, 128), (3, "step", 1, 128), (2, "calls", 1, 128),
@@ -111,3 +113,46 @@ def test_exchange_posted_from_the_marker_launch_equals_the_field_launchs_own(amd
             else:
                 assert np.max(np.abs(ra["hist"] / rb["hist"] - 1.0)) < tol
                 assert np.max(np.abs(ra["x"] - rb["x"])) < 1e-10
+
+
+@pytest.mark.parametrize("nproc,per,mode,nx", [(4, 2, "step", 64), (4, 2, "calls", 64), (4, 2, "step", 1024), (4, 2, "calls", 1024),
+                                               (4, 1, "step", 64), (2, 3, "step", 96)],
+                         ids=["8-ranks-step-nx64", "8-ranks-calls-nx64", "8-ranks-step-nx1024", "8-ranks-calls-nx1024",
+                              "4-processes-step", "6-ranks-2x3-step"])
+def test_exchange_at_the_targets_rank_count(amd, tmp_path, nproc, per, mode, nx):
+    """the target machine is 8 GPUs and `make run` starts four ranks (Makefile:39) -- eight exchange
+    slots and flags, the 8-lane poll of exchange_wait_sum, the 8-rank summation order of the solve, eight tails posting into
+    eight areas, through step() and through the three call sites.  A GPU box admits SIX processes on its card at once (this
+    test's own included), so eight separate processes cannot run here: the eight ranks are FOUR processes of TWO ranks, each
+    rank a context with its own host thread -- every rank still reaches six of its seven peers through hipIpc, the seventh
+    directly (include/pic1dp_hip.h: ranks of one process).  Also four processes of one rank (one short of the limit, on
+    purpose) and two of three.  Bit-identical E / chargeden / energy history on all ranks; 1e-10 against one engine holding the same reference
+    blocks as virtual ranks (replaces MPI_Allreduce, src/pic1dp_interaction.F90:130-135)."""
+    world = nproc * per
+    kw = dict(nparticle_max=10_000 * world + 3, nx=nx)        # (not a multiple of the rank count: PETSC_DECIDE blocks of two sizes)
+    steps = 6
+    ranks = run_ranks(tmp_path, nproc, kw, steps, mode, 29700 + world * 7 + (nx > 100) * 3 + (mode == "calls"), per=per)
+    assert len(ranks) == world
+    for r in ranks[1:]:
+        for k in ("E", "cd", "hist") + (("fields",) if mode == "calls" else ()):
+            assert np.array_equal(r[k], ranks[0][k]), k
+    expect = 2 + steps if mode == "step" else 1 + 2 * steps
+    assert all(int(r["exchanges"]) == expect for r in ranks)
+    assert all(int(r["tails"]) == (steps if mode == "step" else 0) for r in ranks)   # the six sums' tail posts (one kept mode)
+    assert all(int(r["memkind"]) == 1 for r in ranks)
+    eng = amd.Pic1dp(amd.make_input(**kw), npe=world)
+    eng.particle_load()
+    eng.interaction_collect_charge()
+    eng.field_solve_electric()
+    e0 = eng.field_energy()
+    eng.step(steps)
+    assert abs(float(ranks[0]["e0"]) / e0 - 1.0) < 1e-12
+    if mode == "step":
+        assert np.max(np.abs(ranks[0]["hist"] / eng.energy_history() - 1.0)) < 1e-10
+    assert abs(float(ranks[0]["energy"]) / eng.field_energy() - 1.0) < 1e-10
+    f = eng.get_field()
+    assert np.max(np.abs(ranks[0]["E"] - f["electric"])) <= 1e-10 * np.max(np.abs(f["electric"]))
+    assert np.max(np.abs(ranks[0]["cd"] - f["chargeden"])) <= 1e-10 * np.max(np.abs(f["chargeden"]))
+    x = eng.particles_download()["x"]
+    got = np.concatenate([r["x"] for r in ranks])
+    assert got.shape == x.shape and np.max(np.abs(got - x)) < 1e-9
