@@ -6,10 +6,16 @@
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 Headline workload (BASELINE.json): configs[2] = bump-on-tail, 10^8 markers, 1024 grid
-cells, the configuration the metric is quoted on; it fits one GPU.  For N > 1 every
-GPU holds 10^8 markers (weak scaling) and the per-GPU charge vector is summed once
-per sub-step (RCCL all-reduce on the engine's stream, or the library's one-hop
-exchange).  The other GPU configurations of BASELINE.json are selectable:
+cells, the configuration the metric is quoted on; it fits one GPU.  For N > 1 `value`
+is the SAME 10^8 markers split over the N GPUs ("scaling": "strong" -- the metric is
+"at 10^8 particles, 1/2/4/8 MI355X" and north_star's ">= 6x from 1 -> 8 GPUs" is a
+statement about exactly that curve), the per-GPU charge vector summed once per
+sub-step (RCCL all-reduce on the engine's stream, or the library's one-hop exchange);
+the weak reading (10^8 markers PER GPU) is measured in the same run and listed beside
+it (`weak_per_gpu`; --headline weak swaps the two).  The other GPU configurations of
+BASELINE.json are selectable, and the two multi-GPU ones are measured by the driver's
+plain command as well: `--gpus 4` adds a `configs3_c4` object, `--gpus 8` a
+`configs4_c5` object (--extra-configs):
     c2  bump-on-tail, 10^7 markers per GPU, nx 256                      (weak)
     c4  two-stream (iptcldist 2, v0 = 3), 10^8 markers IN TOTAL, nx 512 (strong)
     c5  Landau damping (Maxwellian, lx = 4 pi), 10^8 per GPU, nx 4096   (weak)
@@ -26,8 +32,11 @@ contract keys:
                      mean launch duration from HIP events on the engine's stream, vs
                      8 TB/s; the SURVEY 8(d) price of 80 B per update is reported as
                      reference_priced_GBs, never as the fraction
-  strong_1e8_total : 10^8 markers IN TOTAL split over the N GPUs (the other reading of
-                     "at 10^8 particles, 1/2/4/8 MI355X"), measured in the same run
+  weak_per_gpu     : N > 1: 10^8 markers PER GPU (the other reading of "at 10^8 particles,
+                     1/2/4/8 MI355X"), measured in the same run with the same charge sum
+  strong_1e8_total : 10^8 markers IN TOTAL split over the N GPUs -- `value` itself for
+                     N > 1 (kept as an object of its own for N = 1 and --headline weak)
+  configs3_c4 / configs4_c5 : BASELINE configs[3] (N = 4) / configs[4] (N = 8), 20 steps
   exchange         : the same two workloads with the one-hop charge exchange instead of
                      the RCCL all-reduce (N > 1)
   attribution      : device time per step of the particle kernels, the charge sum and
@@ -80,6 +89,16 @@ def parse():
     ap.add_argument("--nx", type=int, default=0)
     ap.add_argument("--strong-total", type=int, default=10**8, help="markers of the strong_1e8_total object")
     ap.add_argument("--no-strong", action="store_true")
+    ap.add_argument("--headline", default="auto", choices=["auto", "strong", "weak"],
+                    help="N > 1, config c3: which reading of 'at 10^8 particles, N GPUs' is `value` -- strong (10^8 in total, "
+                         "what north_star's >= 6x speed-up 1 -> 8 is a statement about; auto) or weak (10^8 per GPU); the "
+                         "other one is measured beside it")
+    ap.add_argument("--extra-configs", default="auto",
+                    help="BASELINE multi-GPU configurations measured beside the headline (20 steps each): auto = c4 when "
+                         "N = 4 (configs[3]), c5 when N = 8 (configs[4]); a comma list insists (tests); none: nothing")
+    ap.add_argument("--extra-particles", type=int, default=0,
+                    help="(tests) marker count of the extra configurations: per GPU for c5, in total for c4")
+    ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--rehearse-with-host", action="store_true",
                     help="(tests) --allreduce auto also rehearses the host-staged sum, so that the choice by rehearsal "
                          "can run where RCCL cannot (ranks sharing one GPU)")
@@ -499,10 +518,18 @@ def main():
     if a.nx:
         phys["nx"] = a.nx
     strong_cfg = "total" in cfg
+    # N > 1 on the metric's own configuration: `value` is the strong-scaling figure (10^8 markers in total), the weak one
+    # (10^8 per GPU) is the object measured beside it; --headline weak swaps them.  N = 1: the two coincide.
+    headline_strong = False
     if strong_cfg:
         total = a.particles or cfg["total"]
+        other_total, other_key = None, None
     else:
-        total = (a.particles or cfg["per_gpu"]) * world
+        weak_total = (a.particles or cfg["per_gpu"]) * world
+        headline_strong = world > 1 and a.config == "c3" and not a.no_strong and a.headline != "weak"
+        total = a.strong_total if headline_strong else weak_total
+        other_total = weak_total if headline_strong else a.strong_total
+        other_key = "weak_per_gpu" if headline_strong else "strong_1e8_total"
     per_gpu = total // world
 
     dist = None
@@ -660,7 +687,8 @@ def main():
         calls_elapsed = timed(job, a.steps, job.call_sites)
     attr = attribution(job)
 
-    # ---- strong scaling beside the weak headline: 10^8 markers IN TOTAL over N GPUs ------
+    # ---- the other reading of "10^8 markers, N GPUs" beside the headline: weak (10^8 per GPU) beside the strong headline
+    # of N > 1, or strong (10^8 in total) beside a weak one (N = 1: same run; --headline weak; c2 / c5) ------
     strong = None
     sjob = None
     if not a.no_strong and not strong_cfg:
@@ -668,7 +696,7 @@ def main():
             strong = {"value": total * 2.0 * a.steps / elapsed, "ms_per_step": elapsed / a.steps * 1e3,
                       "same_run_as_headline": True}
         else:
-            sjob = Job(a, "strong", pic1dp_amd.make_input(nparticle_max=a.strong_total, **phys), rank, world, device,
+            sjob = Job(a, other_key, pic1dp_amd.make_input(nparticle_max=other_total, **phys), rank, world, device,
                        dist, shared)
             if job.kind != sjob.kind:        # the two objects are measured with the same charge sum
                 sjob.use("rccl" if job.kind == "rccl" else ("p2p" if job.kind.startswith("one-hop") else "host"))
@@ -681,15 +709,17 @@ def main():
             stab = kernel_table(sjob.eng)
             sjob.eng.kernel_stats_enable(False)
             s_energy = sjob.eng.field_energy()
-            strong = {"value": a.strong_total * 2.0 * a.steps / s_el, "ms_per_step": s_el / a.steps * 1e3,
+            strong = {"value": other_total * 2.0 * a.steps / s_el, "ms_per_step": s_el / a.steps * 1e3,
                       "same_run_as_headline": False, "repeats": repeats,
                       "ms_per_step_min": min(s_blocks) / a.steps * 1e3, "ms_per_step_max": max(s_blocks) / a.steps * 1e3,
                       "particle_kernel_avg_ms": {k: v[0] / v[1] for k, v in stab.items() if v[1]},
                       "field_energy_end": s_energy, "attribution": attribution(sjob)}
-        strong.update({"unit": "updates/s", "scaling": "strong", "particles_total": a.strong_total,
-                       "particles_per_gpu": a.strong_total // world, "allreduce": job.kind,
-                       "what": "the headline physics with %g markers IN TOTAL split over the %d GPU(s)"
-                               % (a.strong_total, world)})
+        s_tot = other_total if sjob is not None else total
+        strong.update({"unit": "updates/s", "scaling": "weak" if headline_strong else "strong", "particles_total": s_tot,
+                       "particles_per_gpu": s_tot // world, "allreduce": job.kind,
+                       "what": ("the headline physics with %g markers PER GPU on the %d GPUs (weak scaling)" % (s_tot // world, world))
+                               if headline_strong else
+                               ("the headline physics with %g markers IN TOTAL split over the %d GPU(s)" % (s_tot, world))})
 
     # ---- the one-hop exchange beside RCCL (measured LAST: a failed exchange leaves a run
     # that cannot go on, and everything else is already measured) -----------------------
@@ -699,7 +729,8 @@ def main():
         if job.have_p2p and (sjob is None or sjob.have_p2p):
             exchange = {}
             from pic1dp_amd import parallel
-            for label, j, tot in (("weak", job, total), ("strong_1e8_total", sjob, a.strong_total)):
+            head_label = "strong_1e8_total" if headline_strong else ("strong_total" if strong_cfg else "weak")
+            for label, j, tot in ((head_label, job, total), ("weak" if headline_strong else "strong_1e8_total", sjob, other_total)):
                 if j is None:
                     continue
                 # a rank whose exchange fails (a peer that never delivers: the kernels give up
@@ -738,6 +769,48 @@ def main():
                                 "of the headline's sum (%s)" % headline_kind)
         else:
             exchange = {"unavailable": job.p2p_why or (sjob.p2p_why if sjob else None)}
+
+    # ---- BASELINE.json's own multi-GPU configurations, measured by the driver's plain command: configs[3] (two-stream,
+    # 10^8 markers in total, nx 512) when N = 4, configs[4] (Landau, 10^8 per GPU, nx 4096: "the scaling-curve run") when
+    # N = 8 -- a short run each (three blocks of --extra-steps steps) with the headline's charge sum and the same attribution
+    def measure_extra(name):
+        cx = CONFIGS[name]
+        px = dict(cx["inp"])
+        strong_x = "total" in cx
+        if a.extra_particles:
+            tot = a.extra_particles * (1 if strong_x else world)
+        else:
+            tot = cx["total"] if strong_x else cx["per_gpu"] * world
+        xj = Job(a, name, pic1dp_amd.make_input(nparticle_max=tot, **px), rank, world, device, dist, shared)
+        want_kind = "rccl" if headline_kind == "rccl" else ("p2p" if headline_kind.startswith("one-hop") else "host")
+        if world > 1 and xj.kind != headline_kind:
+            xj.use(want_kind)
+        xj.init_field()
+        x_settle = max(30, min(2000, int(0.1 / (max(tot // world, 1) * 2.0 / 2.0e11))))
+        xj.run(x_settle)
+        xb = [timed(xj, a.extra_steps) for _ in range(3)]
+        x_el = sorted(xb)[1]
+        x_attr = attribution(xj)
+        x_energy = xj.eng.field_energy()
+        x_kernel = xj.eng.kernel_bytes(6)["name"]
+        xj.eng.close()
+        return {"value": tot * 2.0 * a.extra_steps / x_el, "unit": "updates/s", "ms_per_step": x_el / a.extra_steps * 1e3,
+                "ms_per_step_blocks": [b / a.extra_steps * 1e3 for b in xb], "steps": a.extra_steps, "warmup": x_settle,
+                "scaling": "strong" if strong_x else "weak", "particles_total": tot, "particles_per_gpu": tot // world,
+                "nx": px["nx"], "allreduce": xj.kind, "marker_kernel": x_kernel, "attribution": x_attr,
+                "field_energy_end": x_energy, "steps_before_field_energy_end": x_settle + 3 * a.extra_steps + 3 + x_attr["steps"],
+                "what": "BASELINE configs[%d]: %s, %g markers %s over %d GPU(s), nx=%d"
+                        % (cx["index"], cx["what"], tot if strong_x else tot // world, "in total" if strong_x else "per GPU",
+                           world, px["nx"])}
+
+    extras = {}
+    if a.extra_configs == "auto":
+        extra_names = ["c4"] if world == 4 else (["c5"] if world == 8 else [])
+    else:
+        extra_names = [n for n in a.extra_configs.split(",") if n in CONFIGS]
+    for name in extra_names:
+        if name != a.config and not (exchange and any("error" in v for v in exchange.values() if isinstance(v, dict))):
+            extras["configs%d_%s" % (CONFIGS[name]["index"], name)] = measure_extra(name)
 
     if rank == 0:
         value = total * 2.0 * a.steps / elapsed
@@ -845,12 +918,22 @@ def main():
             "ms_per_step_blocks": [b / a.steps * 1e3 for b in blocks_s],
             "value_note": "median of %d back-to-back timed blocks of %d steps each (every block bracketed by barrier + "
                           "device sync, max over ranks); kernel averages are over all blocks" % (repeats, a.steps),
-            "scaling": "strong" if strong_cfg else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if (strong_cfg or headline_strong) else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "speedup_basis": (("value(N) / value(1) is the STRONG-scaling speed-up: the same %g markers in total on 1, 2, 4, 8 "
+                               "GPUs -- the curve north_star's '>= 6x from 1 -> 8 GPUs' is judged on; the weak reading (%g "
+                               "markers per GPU) is weak_per_gpu, measured in this run with the same charge sum")
+                              % (total, (other_total or 0) // world)) if headline_strong else
+                             ("one GPU: the strong and the weak reading of '10^8 markers on N GPUs' coincide" if world == 1 else
+                              "value is %s-scaled (--headline / --config)" % ("strong" if strong_cfg else "weak")),
             "config": {
-                "workload": "%s delta-f, %g markers %s, nx=%d (BASELINE configs[%d]); multirand constant seeds "
+                "workload": "%s delta-f, %g markers %s, nx=%d (BASELINE configs[%d])%s; multirand constant seeds "
                             "(al_int=3, seed_type=1), one reference rank block per GPU"
-                            % (cfg["what"], total if strong_cfg else per_gpu,
-                               "in total" if strong_cfg else "per GPU", phys["nx"], cfg["index"]),
+                            % (cfg["what"], total if (strong_cfg or headline_strong) else per_gpu,
+                               ("IN TOTAL over the %d GPUs" % world) if (strong_cfg or headline_strong) else "per GPU",
+                               phys["nx"], cfg["index"],
+                               ": strong scaling of the metric's own configuration, the figure the >= 6x target of 1 -> 8 "
+                               "GPUs is judged on" if headline_strong else ""),
                 "particles_total": total, "particles_per_gpu": per_gpu, "nx": phys["nx"],
                 "nmode": 1, "dt": 0.05,
                 "parallelism": "particle shard x%d, replicated grid, charge vector summed over GPUs once per "
@@ -905,15 +988,27 @@ def main():
             "attribution": attr,
             "field_energy_end": energy, "steps_before_field_energy_end": settle + a.warmup + repeats * a.steps,
         }
-        if strong is not None:
-            # the strong figure is the one measured with the headline's charge sum; the one-hop exchange measured beside
-            # it is listed, never promoted
-            xs = (exchange or {}).get("strong_1e8_total")
+        # the strong figure is the one measured with the headline's charge sum; the one-hop exchange measured beside
+        # it is listed, never promoted
+        xs = (exchange or {}).get("strong_1e8_total")
+        if headline_strong:
+            sv = {"value": value, "ms_per_step": elapsed / a.steps * 1e3}
+            out["strong_1e8_total"] = dict(sv, unit="updates/s", scaling="strong", particles_total=total,
+                                           particles_per_gpu=per_gpu, allreduce=headline_kind, same_run_as_headline=True,
+                                           field_energy_end=energy,
+                                           what="`value` itself: %g markers IN TOTAL split over the %d GPUs" % (total, world))
+            if xs and "value" in xs:
+                out["strong_1e8_total"]["by_charge_sum"] = {
+                    headline_kind: sv, "one-hop exchange": {"value": xs["value"], "ms_per_step": xs["ms_per_step"]}}
+            if strong is not None:
+                out["weak_per_gpu"] = strong
+        elif strong is not None:
             if xs and "value" in xs and not strong.get("same_run_as_headline"):
                 strong["by_charge_sum"] = {
                     headline_kind: {"value": strong["value"], "ms_per_step": strong["ms_per_step"]},
                     "one-hop exchange": {"value": xs["value"], "ms_per_step": xs["ms_per_step"]}}
             out["strong_1e8_total"] = strong
+        out.update(extras)
         if exchange is not None:
             out["exchange"] = exchange
         if calls_elapsed:

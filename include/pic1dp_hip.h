@@ -144,6 +144,9 @@ enum {
 /* ---- library ---------------------------------------------------------- */
 int pic1dp_hip_abi_version(void);
 const char *pic1dp_hip_last_error(void);
+/* 1 when the library is a -DPIC1DP_TUNING build (it then also reads the measurement knobs of
+ * tools/README.md from the environment), 0 for the product build, which compiles none of them */
+int pic1dp_hip_tuning_build(void);
 /* number of visible HIP devices (0 when none; never fails) */
 int pic1dp_hip_device_count(void);
 /* fill `in` with the values of the reference's input file
@@ -198,6 +201,15 @@ int pic1dp_hip_local_sizes(pic1dp_ctx *ctx, int32_t ispecies, int64_t *nalloc,
  * block (seeded with that block's mype), then H2D.  Uses the multirand_*
  * fields of the input. */
 int pic1dp_hip_particle_load(pic1dp_ctx *ctx);
+/* Members of an ENSEMBLE of otherwise identical runs: reference block b of the next
+ * particle_load draws from the stream multirand_init(..., mype = b + offset, ...)
+ * instead of mype = b (src/pic1dp_particle.F90:159-160).  offset 0 (default) is the
+ * reference's constant-seed run (seed_type 1) the parity tests are about; the
+ * reference itself gets its ensembles from seed_type 2 / 3 (clock, /dev/urandom:
+ * src/multirand.F90:291-306) and compares their growth rates (tools/runinfo.py:
+ * 94-122,136-231) -- this is the reproducible form of that.  Block sizes, weights
+ * and everything else are those of the npe-rank load. */
+int pic1dp_hip_set_seed_offset(pic1dp_ctx *ctx, int32_t offset);
 /* alternative for a host that ran the reference's own particle_load:
  * hand over HOST arrays of one species (n = allocated slots, np = valid) --
  * the VecGetArrayF90 view of particle_x/v/p/w (src/pic1dp_particle.F90:34-36) */

@@ -11,7 +11,7 @@ from . import _lib
 _lib.load()  # fail loudly, now, if the HIP library is absent
 
 from ._lib import Input, Layout, Pic1dpError  # noqa: E402,F401
-from .engine import Pic1dp, device_count, make_input  # noqa: E402,F401
+from .engine import Pic1dp, device_count, make_input, tuning_build  # noqa: E402,F401
 from . import parallel  # noqa: E402,F401
 
-__all__ = ["Pic1dp", "make_input", "device_count", "Input", "Layout", "Pic1dpError", "parallel"]
+__all__ = ["Pic1dp", "make_input", "device_count", "tuning_build", "Input", "Layout", "Pic1dpError", "parallel"]

@@ -75,6 +75,7 @@ SIGNATURES = {
     "pic1dp_hip_abi_version": [],
     "pic1dp_hip_last_error": [],            # returns const char*
     "pic1dp_hip_device_count": [],
+    "pic1dp_hip_tuning_build": [],
     "pic1dp_hip_input_defaults": [_INP],
     "pic1dp_hip_input_size": [],
     "pic1dp_hip_input_validate": [_INP, C.POINTER(Layout)],
@@ -97,6 +98,7 @@ SIGNATURES = {
     "pic1dp_hip_step": [_P, C.c_int32],
     "pic1dp_hip_set_step_mode": [_P, C.c_int32],
     "pic1dp_hip_set_output_fusion": [_P, C.c_int32],
+    "pic1dp_hip_set_seed_offset": [_P, C.c_int32],
     "pic1dp_hip_predict_kind": [_P, C.POINTER(C.c_int32)],
     "pic1dp_hip_get_field_half": [_P, _P],
     "pic1dp_hip_set_field_solver": [_P, C.c_int32],

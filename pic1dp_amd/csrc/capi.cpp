@@ -95,6 +95,13 @@ int ensure_second_set(pic1dp_ctx *c) {
 extern "C" {
 
 int pic1dp_hip_abi_version(void) { return PIC1DP_ABI_VERSION; }
+int pic1dp_hip_tuning_build(void) {
+#ifdef PIC1DP_TUNING
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 const char *pic1dp_hip_last_error(void) { return g_err.c_str(); }
 
@@ -303,7 +310,7 @@ static int chain_selftest(pic1dp_ctx *c) {
   if (std::memcmp(got[0], want, sizeof(double) * kr) != 0) return -2;
   const bool a_ok = std::memcmp(got[0] + 16, want, sizeof(double) * kr) == 0;
   const bool b_ok = std::memcmp(got[1] + 16, want + kr, sizeof(double) * kr) == 0;
-  if (const char *dbg = std::getenv("PIC1DP_CHAIN_SELFTEST_VERBOSE"))
+  if (const char *dbg = tuning_env("PIC1DP_CHAIN_SELFTEST_VERBOSE"))
     if (std::atoi(dbg) != 0)
       std::fprintf(stderr, "pic1dp: chain self-test: matrix unit set A %s, set B (cancellation, subnormals) %s; one-lane chain set B %s\n",
                    a_ok ? "identical" : "DIFFERS", b_ok ? "identical" : "DIFFERS",
@@ -369,22 +376,12 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   c->grid.dt_full = in->dt;
   c->grid.nx = nx;
   c->grid.rlx = 1.0 / in->lx;
-  // copies of the per-workgroup rho tile: as many (up to 8) as leave two workgroups per CU
-  // their LDS (E0, Eh and the copies within 80 KiB); PIC1DP_RHO_COPIES overrides
-  c->grid.rcopies = 1;
-  if (const char *e = std::getenv("PIC1DP_RHO_COPIES")) {
-    const int k = std::atoi(e);
-    if (k == 1 || k == 2 || k == 4 || k == 8) c->grid.rcopies = k;
-  }
-  if (const char *e = std::getenv("PIC1DP_OSUB")) c->osub_req = std::max(0, std::atoi(e));
-  if (const char *e = std::getenv("PIC1DP_WAVE_PRIO")) c->wave_prio = std::atoi(e) != 0;
-  if (const char *e = std::getenv("PIC1DP_DYN_TAIL")) c->dyn_tail = c->dyn_tail_full = std::max(0, std::min(16, std::atoi(e)));
-  if (const char *e = std::getenv("PIC1DP_DYN_TAIL_FULL")) c->dyn_tail_full = std::max(0, std::min(16, std::atoi(e)));
-  if (const char *e = std::getenv("PIC1DP_PAIR_PLAIN")) c->pair_plain = std::atoi(e) != 0;
-  while (c->grid.rcopies > 1 && step_lds_bytes(nx, true, c->grid.rcopies) > 80 * 1024) c->grid.rcopies >>= 1;
-  if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_MB"))
+  if (const char *e = tuning_env("PIC1DP_OSUB")) c->osub_req = std::max(0, std::atoi(e));
+  if (const char *e = tuning_env("PIC1DP_DYN_TAIL")) c->dyn_tail = c->dyn_tail_full = std::max(0, std::min(16, std::atoi(e)));
+  if (const char *e = tuning_env("PIC1DP_DYN_TAIL_FULL")) c->dyn_tail_full = std::max(0, std::min(16, std::atoi(e)));
+  if (const char *e = tuning_env("PIC1DP_NT_THRESHOLD_MB"))
     c->nt_threshold_half = c->nt_threshold_full = std::atof(e) * 1048576.0;
-  if (const char *e = std::getenv("PIC1DP_NT_THRESHOLD_FULL_MB")) c->nt_threshold_full = std::atof(e) * 1048576.0;
+  if (const char *e = tuning_env("PIC1DP_NT_THRESHOLD_FULL_MB")) c->nt_threshold_full = std::atof(e) * 1048576.0;
 
   // particle storage: valid markers of the owned blocks packed first, block
   // tails (allocated but unloaded slots) behind them
@@ -399,7 +396,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   // one-workgroup field kernel then reads and re-zeroes 8 x nx words on the critical path.  So: eight
   // copies for small grids only.  PIC1DP_RHO_GLOBAL_COPIES overrides.
   c->grid.gcopies = nx <= 256 ? 8 : 1;
-  if (const char *e = std::getenv("PIC1DP_RHO_GLOBAL_COPIES")) {
+  if (const char *e = tuning_env("PIC1DP_RHO_GLOBAL_COPIES")) {
     const int k = std::atoi(e);
     if (k >= 1 && k <= 64 && (k & (k - 1)) == 0) c->grid.gcopies = k;
   }
@@ -447,7 +444,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   HIP_TRY_C(hipMalloc(&c->d_E0, sizeof(double) * nx));
   HIP_TRY_C(hipMalloc(&c->d_rho_dummy, sizeof(double) * rho_doubles));
   if (const char *e = std::getenv("PIC1DP_LAZY_CALLS")) c->lazy_calls = std::atoi(e) != 0;
-  if (const char *e = std::getenv("PIC1DP_CARRY")) c->carry = std::max(0, std::atoi(e));
+  if (const char *e = tuning_env("PIC1DP_CARRY")) c->carry = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("PIC1DP_PREDICT")) c->predict = std::atoi(e);
   HIP_TRY_C(hipMalloc(&c->d_mode_re, sizeof(double) * nm));
   HIP_TRY_C(hipMalloc(&c->d_mode_im, sizeof(double) * nm));
@@ -480,17 +477,16 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
       }
     }
     // one pass per step: with prediction tiles where they fit the LDS (k_step_one), as six sums for larger
-    // grids with one kept mode (k_step_sums); PIC1DP_PRED_KIND=1|2 insists on one of them (tests)
-    const bool private_fits = 2 * (step_one_private_lds_bytes(nx, c->grid.rcopies) + kStaticLds) <= kCuLds;
+    // grids with one kept mode (k_step_sums); PIC1DP_PRED_KIND=1|2|3 insists on tiles | sums | sums in registers (tests)
+    const bool private_fits = 2 * (step_one_private_lds_bytes(nx) + kStaticLds) <= kCuLds;
     // The prediction tiles cost 2 + 4 nm LDS atomics at random cells per marker.  Measured against the two passes
     // (profiles/r04/experiments/ab_kept_modes.log, 1e8 markers / nx 1024, ms per step): two kept modes 1.23 against 1.46,
-    // three 1.49 against 1.45, four 2.05 (nx 512) against 1.46 -- so the tiles are the default up to two kept modes,
-    // and for three and four only when PIC1DP_PRED_KIND=1 asks for the one pass by name (k_step_one is built for them).
-    constexpr int kPredDefaultModes = 2;
-    if (nm <= kPredDefaultModes && step_one_lds_bytes(nx, c->grid.rcopies, nm) <= PARTICLE_LDS_CAP)
+    // three 1.49 against 1.45, four 2.05 (nx 512) against 1.46 -- so the tiles serve up to two kept modes and three and
+    // more take the two passes (the three- and four-mode instantiations of round 4 were retired in round 6).
+    if (nm <= PRED_MAX_MODES && step_one_lds_bytes(nx, nm) <= PARTICLE_LDS_CAP)
       c->pred_kind = 1;
     // (the six sums travel in the head of an nx-vector on the call-site path: nx >= 8)
-    else if (nm == 1 && nx >= 8 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP)
+    else if (nm == 1 && nx >= 8 && step_sums_lds_bytes(nx) <= PARTICLE_LDS_CAP)
       c->pred_kind = 2;
     // One kept mode: the six sums in thread-private LDS slots (k_step_one<PRIV>) beat the tiles, whose six atomics per
     // marker at random cells pay ~3x in bank conflicts: -2 % at 1e8 markers / nx 1024 (profiles/r03/experiments/
@@ -499,14 +495,15 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     // -- wherever the slots of two workgroups fit (nx >= 8: the sums travel in the head of an nx-vector on the
     // call-site path).
     if (c->pred_kind == 1 && nm == 1 && nx >= 8 && private_fits) c->pred_kind = 2;
+    bool sums_in_registers = false;
     if (const char *e = std::getenv("PIC1DP_PRED_KIND")) {
       const int k = std::atoi(e);
-      if (k == 2 && nm == 1 && nx >= 8 && step_sums_lds_bytes(nx, c->grid.rcopies) <= PARTICLE_LDS_CAP) c->pred_kind = 2;
+      if ((k == 2 || k == 3) && nm == 1 && nx >= 8 && step_sums_lds_bytes(nx) <= PARTICLE_LDS_CAP) c->pred_kind = 2;
+      if (k == 3) sums_in_registers = true;  // k_step_sums also where the private slots would fit (tests: the large-grid kernel at a small grid)
       // 1: the tiles wherever they fit (else the choice above stands)
-      if (k == 1 && nm <= PRED_MAX_MODES && step_one_lds_bytes(nx, c->grid.rcopies, nm) <= PARTICLE_LDS_CAP) c->pred_kind = 1;
+      if (k == 1 && nm <= PRED_MAX_MODES && step_one_lds_bytes(nx, nm) <= PARTICLE_LDS_CAP) c->pred_kind = 1;
     }
-    if (c->pred_kind == 2 && private_fits) c->pred_private = 1;
-    if (const char *e = std::getenv("PIC1DP_PRED_PRIVATE")) c->pred_private = c->pred_private && std::atoi(e) != 0;
+    if (c->pred_kind == 2 && private_fits && !sums_in_registers) c->pred_private = 1;
     if (c->pred_kind) {  // the tables: E = 2*(cos re + (-sin) im) (src/pic1dp_field.F90:251-257)
       std::vector<double> ta(fre.size()), tb(fim.size());
       for (size_t i = 0; i < fre.size(); ++i) ta[i] = 2.0 * fre[i], tb[i] = 2.0 * fim[i];
@@ -553,7 +550,7 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
   f.nspecies = ns;
   f.deltaf = in->deltaf;
   f.npe = c->lay.npe;  // the summation order of the reference run being reproduced (PIC1DP_FIELD_ONE_RANK_ORDER=1: tests)
-  if (const char *e = std::getenv("PIC1DP_FIELD_ONE_RANK_ORDER"))
+  if (const char *e = tuning_env("PIC1DP_FIELD_ONE_RANK_ORDER"))
     if (std::atoi(e) != 0) f.npe = 1;
   f.tab_lds = (static_cast<size_t>(2) * nm * nx * sizeof(double) <= 96 * 1024) ? 1 : 0;
   f.lx = in->lx;
@@ -665,6 +662,13 @@ int pic1dp_hip_local_sizes(pic1dp_ctx *c, int32_t isp, int64_t *nalloc, int64_t 
 }
 
 
+int pic1dp_hip_set_seed_offset(pic1dp_ctx *c, int32_t offset) {
+  CHECK_CTX(c);
+  if (offset < 0) return fail(PIC1DP_ERR_ARG, "seed offset < 0");
+  c->seed_offset = offset;
+  return 0;
+}
+
 int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
@@ -700,7 +704,7 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
     const int mype = c->blk0 + b;
     const int64_t n = block_alloc(in.nparticle_max, mype, npe);
     Multirand g;
-    if ((rc = init_block_rng(in, mype, g)) != 0) break;
+    if ((rc = init_block_rng(in, mype + c->seed_offset, g)) != 0) break;
     for (int s = 0; s < ns && !rc; ++s) {
       Species &S = c->sp[s];
       load_block_species(in, s, g, n, hx, hv, hp, hw, nthreads);

@@ -115,7 +115,8 @@ int optimize_on_device(pic1dp_ctx *c, const bool due[3]) {
   const int ns = in.nspecies, nb = c->nblk, nv = in.nv;
   if (int rc = ensure_second_set(c)) return rc;  // the re-packing target
   // PIC1DP_OPT_TIMING=1: wall clock of the event's phases to stderr (tools/opt_event_bench.py)
-  const bool timing = std::getenv("PIC1DP_OPT_TIMING") && std::atoi(std::getenv("PIC1DP_OPT_TIMING")) != 0;
+  const char *te = tuning_env("PIC1DP_OPT_TIMING");
+  const bool timing = te && std::atoi(te) != 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
   double t_hist = 0.0, t_blocks = 0.0;

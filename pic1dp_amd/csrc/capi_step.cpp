@@ -10,7 +10,7 @@ LaunchCfg particle_launch(const pic1dp_ctx *c, int64_t np, bool with_E, bool wit
   const int nx = c->in.nx;
   LaunchCfg lc{};
   lc.lds = sizeof(double) * ((with_E ? static_cast<size_t>((nx + 2) & ~1) : 0) +
-                             (with_rho ? static_cast<size_t>(nx) * c->grid.rcopies + 1 : 0));  // + guard cell
+                             (with_rho ? static_cast<size_t>(nx) + 1 : 0));  // + guard cell
   int by_lds = lc.lds ? static_cast<int>(kCuLds / (lc.lds + kStaticLds)) : 8;
   if (by_lds < 1) by_lds = 1;
   int threads = c->threads_req > 0 ? c->threads_req : 512;
@@ -353,7 +353,7 @@ int pic1dp_hip_solve_field(pic1dp_ctx *c) {
   // and a time step through the three call sites is two launches (round 5; three and a copy before)
   if (pending == 2 && c->call_pair && c->lazy_calls && c->field_solver == 0 && c->lz == LZ_CLEAN && pred_usable(c) &&
       c->pred_kind == 2 && c->in.nmode == 1) {
-    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, c->pair_plain, 0};
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, 0};
     HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));
     field_written(c, true);
     c->pred_version = 0;  // consumed
@@ -427,9 +427,9 @@ int pic1dp_hip_substep(pic1dp_ctx *c, int32_t irk) {
 }
 
 // LDS bytes of the whole-step kernels: E0 tile, Eh tile (full only), rho tile
-size_t pic1dp_host::step_lds_bytes(int nx, bool full, int rcopies) {
+size_t pic1dp_host::step_lds_bytes(int nx, bool full) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
-  return sizeof(double) * ((full ? 2 : 1) * ne + ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) +
+  return sizeof(double) * ((full ? 2 : 1) * ne + ((static_cast<size_t>(nx) + 2) & ~static_cast<size_t>(1)) +
                            2);  // (+ the drawn chunks' counter, 16-byte slot)
 }
 
@@ -460,7 +460,7 @@ static int64_t oversubscribed(const pic1dp_ctx *c, int64_t np, int64_t resident,
 
 static LaunchCfg step_launch(const pic1dp_ctx *c, int64_t np, bool full) {
   LaunchCfg lc{};
-  lc.lds = step_lds_bytes(c->in.nx, full, c->grid.rcopies);
+  lc.lds = step_lds_bytes(c->in.nx, full);
   int by_lds = static_cast<int>(kCuLds / (lc.lds + kStaticLds));
   if (by_lds < 1) by_lds = 1;
   // two workgroups of 768 threads per CU (24 waves): measured inside one process
@@ -559,9 +559,9 @@ static bool fuse_capable(const pic1dp_ctx *c) {
 // workgroups that fill the CUs (the grid is that, or a multiple: oversubscribed())
 static LaunchCfg pred_launch(const pic1dp_ctx *c, int64_t np, bool priv, int64_t *resident) {
   LaunchCfg lc{};
-  lc.lds = priv ? step_one_private_lds_bytes(c->in.nx, c->grid.rcopies)
-                : (c->pred_kind == 2 ? step_sums_lds_bytes(c->in.nx, c->grid.rcopies)
-                                     : step_one_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nmode));
+  lc.lds = priv ? step_one_private_lds_bytes(c->in.nx)
+                : (c->pred_kind == 2 ? step_sums_lds_bytes(c->in.nx)
+                                     : step_one_lds_bytes(c->in.nx, c->in.nmode));
   bool two = 2 * (lc.lds + kStaticLds) <= kCuLds;  // both workgroups resident: each also holds the static exp table
   int th2 = 768;
   int th1 = 1024;
@@ -602,8 +602,8 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
   // the diagnostics of output_all inside k_step_full: when asked for, the LDS holds them, and the
   // tuning build of the marker loop is the default one
   if (diag) {
-    const size_t need = step_lds_bytes(c->in.nx, true, c->grid.rcopies) +
-                        step_diag_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nx_opd, c->in.nv_opd);
+    const size_t need = step_lds_bytes(c->in.nx, true) +
+                        step_diag_lds_bytes(c->in.nx, c->in.nx_opd, c->in.nv_opd);
     if (!full || c->in.nx_opd < 1 || c->in.nv_opd < 2 || need > PARTICLE_LDS_CAP) diag = false;
   }
   if (diag)
@@ -622,7 +622,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
   double state_bytes = 0.0;
   for (int s = 0; s < c->in.nspecies; ++s) state_bytes += 32.0 * static_cast<double>(c->sp[s].np);
   int stream_nt = state_bytes > (full ? c->nt_threshold_full : c->nt_threshold_half) ? 1 : 0;
-  if (const char *e = std::getenv("PIC1DP_NT_FORCE")) {  // tuning only, read per launch (tools/ab_nt.py)
+  if (const char *e = tuning_env("PIC1DP_NT_FORCE")) {  // tuning build only, read per launch (tools/ab_nt.py)
     const int f = std::atoi(e);
     if (f == 0) stream_nt = 0;
     if (f == 1) stream_nt = 1;
@@ -652,7 +652,6 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
     // the drawn chunk tail of every whole-step kernel: half a workgroup's chunks, all of them for k_step_full (two passes
     // per step at 1e8 markers: 0.913 -> 0.898 ms with 16/16 against 8/16, profiles/r05/experiments/ab_dyn_tail_other.log)
     a.dyn_tail = (full && !pred) ? c->dyn_tail_full : c->dyn_tail;
-    a.wave_prio = c->wave_prio;
     // a species with general divisor constants and an exp-bearing f0 is FP64-issue-bound: its
     // -f0'/f0 at the step-start velocity goes from the first kernel to the second through
     // memory (8 B per marker) instead of being evaluated twice.  Measured at 1e8 markers
@@ -698,27 +697,13 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       // traffic cost: measured (profiles/r03/experiments/ab_one_exp.log), PIC1DP_CARRY=1 / 0 insists either way.
       const bool exp_bearing = c->in.deltaf && (c->in.iptcldist == 2 || c->in.iptcldist == 3);
       const bool carry_one = c->carry < 0 ? (S.sc.one_exp ? kCarryOneExpDefault : true) : c->carry > 0;
-      if (exp_bearing && carry_one && (c->pred_kind == 2 || c->in.nmode <= 2)) {  // (the tiles of 3, 4 modes: built without the carry)
+      if (exp_bearing && carry_one) {
         if (!S.t2) HIP_TRY(hipMalloc(&S.t2, sizeof(double) * static_cast<size_t>(S.nalloc + 2)));
         a.t2 = S.t2;
         a.t2_mode = S.t2_version == read_version ? 2 : 1;
         S.t2_version = c->state_version;
       }
       lc = pred_launch(c, S.np, priv, nullptr);
-#ifdef PIC1DP_TUNE_SUMS2  // timing experiment only: the solve still reads the tiles' layout
-      if (c->pred_kind == 1 && c->in.nmode == 2 && a.t2 == nullptr && std::getenv("PIC1DP_SUMS2")) {
-        const size_t ne = static_cast<size_t>((c->in.nx + 2) & ~1);
-        a.sums2 = 1;
-        a.dyn_tail = c->dyn_tail;
-        lc.threads = PIC1DP_PRIV2_THREADS;
-        lc.lds = sizeof(double) * (2 * ne + (static_cast<size_t>(c->in.nx) + 1) * 4 +
-                                   ((static_cast<size_t>(c->in.nx) * c->grid.rcopies + 2) & ~static_cast<size_t>(1)) +
-                                   20 * static_cast<size_t>(PIC1DP_PRIV2_THREADS) + 16);
-        const int bpc = 2 * (lc.lds + kStaticLds) <= kCuLds ? 2 : 1;
-        const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
-        lc.blocks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(static_cast<int64_t>(c->num_cu) * bpc, need)));
-      }
-#endif
       if (tail_mode != 0 && s == tail_species && !a.fused.on) {
         StepTail &t = a.tail;
         t.mode = tail_mode;
@@ -746,7 +731,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
       a.dist_out = c->d_dist + ntot * s;
       a.dist_partial = c->d_diag_part + static_cast<size_t>(6) * diag_max_blocks(c) * s;
       HIP_TRY(hipMemsetAsync(a.dist_out, 0, sizeof(double) * ntot, c->st));
-      lc.lds += step_diag_lds_bytes(c->in.nx, c->grid.rcopies, c->in.nx_opd, c->in.nv_opd);
+      lc.lds += step_diag_lds_bytes(c->in.nx, c->in.nx_opd, c->in.nv_opd);
       lc.threads = 1024;
       int64_t blocks = c->num_cu;
       const int64_t need = ((S.np >> 1) + lc.threads - 1) / lc.threads;
@@ -944,7 +929,7 @@ static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred) {
                     c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (pair) {
     // (cd_h: the tiles' scratch; with the six sums only the call sites want the half-step charge density's kept mode)
-    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->pred_kind == 2 ? nullptr : c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, c->pair_plain, 0};
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->pred_kind == 2 ? nullptr : c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, 0};
     if (will_pack) {  // both charge sums of the step came in ONE all-reduce (pack_doubles)
       pa.pack = c->d_pack;
       HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));

@@ -32,6 +32,7 @@ namespace pic1dp_host {
 // the message pic1dp_hip_last_error() hands out (thread-local, capi.cpp); returns code
 int fail(int code, const char *fmt, ...);
 
+
 #define HIP_TRY(expr)                                                                     \
   do {                                                                                    \
     hipError_t e_ = (expr);                                                               \
@@ -106,9 +107,7 @@ struct pic1dp_ctx {
   // one pass per step (kernels_step.hip k_step_one): mode tables with E = sum re_m A_m + im_m B_m, the
   // prediction accumulators [nspecies][1 + 2 nm][nx], the combined half-step charge density
   double *d_tabA = nullptr, *d_tabB = nullptr, *d_pred = nullptr, *d_cd_h = nullptr, *d_mode_h = nullptr;
-  int pair_plain = 0;              // PIC1DP_PAIR_PLAIN
   int osub_req = 0;                // PIC1DP_OSUB: grid size of the marker kernels in units of the resident one (0: auto)
-  int wave_prio = 0;               // PIC1DP_WAVE_PRIO (experiment): the one-pass kernels' waves lower their issue priority as they progress
   int dyn_tail_full = 16;          // ... of k_step_full (PIC1DP_DYN_TAIL sets both, PIC1DP_DYN_TAIL_FULL this one)
   int dyn_tail = 8;                // PIC1DP_DYN_TAIL: sixteenths of a workgroup's 64-pair chunks its waves DRAW from an LDS counter (every whole-step kernel)
   int pred_kind = 0;               // 0 no one-pass step here, 1 prediction tiles (k_step_one), 2 six sums (k_step_sums)
@@ -211,6 +210,7 @@ struct pic1dp_ctx {
   int chain_selftest = 0;                  // create()'s verdict on the serial sums through the matrix unit: 1 identical, 0 differs, -1 could not run
   int32_t itime = 0;
   double time = 0.0;
+  int seed_offset = 0;                     // ensemble member: block b draws from stream mype = b + seed_offset (pic1dp_hip_set_seed_offset)
   GridConst grid{};
   FieldArgs fa{};
   // comm
@@ -296,9 +296,9 @@ struct Span {
       // timing only (the pairs are read after a stream synchronisation): no system-scope fence at the event -- with it
       // every bracketed launch pays a write-back of the caches its markers live in (a 70 us step at the reference's default
       // size: +10-28 %), and the time it reports contains that write-back
+      // (A/B at the reference's default size: profiles/r05/experiments, tools/ab_event_fence.sh of that round)
       auto make = [](hipEvent_t *e) {
-        static const bool fenced = std::getenv("PIC1DP_EVENT_FENCE") != nullptr;  // (A/B: the default events)
-        if (!fenced && hipEventCreateWithFlags(e, hipEventDisableSystemFence) == hipSuccess) return true;
+        if (hipEventCreateWithFlags(e, hipEventDisableSystemFence) == hipSuccess) return true;
         (void)hipGetLastError();
         return hipEventCreate(e) == hipSuccess;
       };
@@ -330,7 +330,7 @@ int materialize(pic1dp_ctx *c);           // a noted push becomes memory
 int materialize_cd(pic1dp_ctx *c);        // what collect_charge left to the next solve_field becomes field_chargeden
 int rebuild_half_step_chargeden(pic1dp_ctx *c);  // the whole vector where only the kept mode's content was formed
 void field_written(pic1dp_ctx *c, bool by_solve);  // d_E changed: versions, what a noted push may still assume
-size_t step_lds_bytes(int nx, bool full, int rcopies = 1);  // dynamic LDS of a whole-step kernel
+size_t step_lds_bytes(int nx, bool full);  // dynamic LDS of a whole-step kernel
 // ---- capi_comm.cpp ----
 int allreduce_charge(pic1dp_ctx *c);
 int allreduce_doubles(pic1dp_ctx *c, double *d, size_t n);

@@ -540,21 +540,13 @@ __device__ __forceinline__ bool draw_chunk(const PairRows &r, unsigned *ctr, int
   return true;
 }
 
-// The workgroup's LDS copy of rho may be replicated (g.rcopies = 1, 2, 4 or 8 copies,
-// lane l deposits into copy l % rcopies): neighbouring lanes of a wave that hit the same
-// cell then hit different addresses, which matters for small grids (at nx = 192 a wave's
-// 64 lanes share 192 cells).  The copies are added up in the flush.
-__device__ __forceinline__ double *my_rho_copy(double *sR, const GridConst &g) {
-  return sR + (threadIdx.x & (g.rcopies - 1)) * g.nx;
-}
+// The workgroup's LDS tile of rho: nx cells + a guard cell (= cell 0) behind them.  (Replicated tiles -- lane l depositing
+// into copy l % k -- were measured in rounds 1-2 and bought nothing at any grid: HISTORY.md.)
 __device__ __forceinline__ void zero_rho(double *sR, const GridConst &g) {
-  for (int i = threadIdx.x; i < g.nx * g.rcopies + 1; i += blockDim.x) sR[i] = 0.0;  // + the guard cell
+  for (int i = threadIdx.x; i < g.nx + 1; i += blockDim.x) sR[i] = 0.0;  // + the guard cell
 }
 __device__ __forceinline__ void flush_rho(const double *sR, double *rho, const GridConst &g) {
   // one global atomic per cell per workgroup; start cell rotated by workgroup
-#ifdef PIC1DP_TUNE_NOFLUSH  // tuning build, measurement only: the LDS tiles are not flushed (wrong charge)
-  return;
-#endif
   const int nx = g.nx;
   rho += static_cast<size_t>(blockIdx.x & (g.gcopies - 1)) * g.gstride;
   const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);
@@ -562,8 +554,7 @@ __device__ __forceinline__ void flush_rho(const double *sR, double *rho, const G
     int j = i + rot;
     if (j >= nx) j -= nx;
     double val = sR[j];
-    for (int c = 1; c < g.rcopies; ++c) val += sR[c * nx + j];
-    if (j == 0) val += sR[g.rcopies * nx];  // the guard cell behind the last copy is cell 0
+    if (j == 0) val += sR[nx];  // the guard cell behind the tile is cell 0
     if (val != 0.0) glb_add(&rho[j], val);  // rho: this workgroup's copy of the accumulator
   }
 }

@@ -7,6 +7,21 @@
 #include <cstdint>
 #include <cstdlib>
 
+// Environment variables.  The product library reads the fifteen of INTEGRATION.md section 6 with std::getenv: switches
+// between paths that exist for a functional reason (eager / lazy call sites, two passes / one, tiles / sums, the solve in a
+// launch of its own, ...), which the differential tests hold against each other, and operational settings.  Everything a
+// MEASUREMENT wants to vary beyond them (launch shapes, thresholds, schedules; tools/ab_*.sh) goes through tuning_env(),
+// which only a -DPIC1DP_TUNING build looks at -- `PIC1DP_EXTRA_FLAGS=-DPIC1DP_TUNING PIC1DP_LIB_OUT=.../v_tuning.so python
+// pic1dp_amd/build.py --force`, loaded with PIC1DP_LIB; the default build compiles none of it.
+#ifdef PIC1DP_TUNING
+inline const char *tuning_env(const char *name) { return std::getenv(name); }
+#else
+inline const char *tuning_env(const char *) { return nullptr; }
+#endif
+#if defined(PIC1DP_TUNE_STAMPS) && !defined(PIC1DP_TUNING)
+#error "-DPIC1DP_TUNE_STAMPS instruments the marker kernels: it belongs to a tuning build (-DPIC1DP_TUNING), never to the product"
+#endif
+
 namespace pic1dp {
 
 // Constants of one species' push, pre-formed on the host exactly as the
@@ -41,8 +56,6 @@ struct GridConst {
   double lx, dnx, dt_full;
   double rlx;    // RN(1/lx), for the exact division by the constant lx
   int nx;
-  int rcopies;   // copies of the workgroup's LDS rho tile (1, 2, 4, 8; lane l deposits into copy l % rcopies);
-                 // the tile region is nx * rcopies + 1 doubles: a guard cell (= cell 0) behind the last copy
   int gcopies, gstride;  // copies of the species accumulators in memory (power of two) and doubles between them:
                          // workgroup b flushes into copy b % gcopies (fewer atomics per address), the field
                          // kernels add the copies up
@@ -78,11 +91,9 @@ __host__ __device__ constexpr int64_t tidx2(int64_t j) {
 // doubles of a slab holding n markers, and where array k (0 x, 1 v, 2 w, 3 p) starts
 inline int64_t slab_array_stride(int64_t n) {
   if (TILE_LOG2) return TILE;
-  // untiled A/B build only: arrays a 2 MiB multiple (+ PIC1DP_SLAB_STAGGER bytes) apart
+  // untiled A/B build only (-DPIC1DP_TILE_LOG2=0): arrays a 2 MiB multiple apart
   const int64_t unit = (2 << 20) / 8;
-  int64_t stagger = 0;
-  if (const char *e = std::getenv("PIC1DP_SLAB_STAGGER")) stagger = (std::atoll(e) & ~static_cast<long long>(255)) / 8;
-  return (n + unit - 1) / unit * unit + stagger;
+  return (n + unit - 1) / unit * unit;
 }
 inline int64_t slab_doubles(int64_t n) {
   return TILE_LOG2 ? (n + TILE - 1) / TILE * 4 * TILE : 4 * slab_array_stride(n);
@@ -250,27 +261,24 @@ struct StepArgs {
   StepTail tail;     // pred_kind 2 only, several ranks: the last workgroup packs / posts this rank's charge (mode 0: no)
   DistScale dscale;  // k_step_full<DIAG>: the histograms as fixed-point sums (diag_fx != 0)
   int diag_fx;
-  int wave_prio;     // k_step_one, k_step_sums (experiment, PIC1DP_WAVE_PRIO): a wave's issue priority falls with its progress
   int dyn_tail;      // every whole-step kernel: sixteenths of a workgroup's chunks that its waves draw from an LDS counter (0: all dealt)
-#ifdef PIC1DP_TUNE_SUMS2
-  int sums2;         // tuning build: two kept modes as twenty private sums (marker kernel only, tools/ab_sums2.sh)
-#endif
 };
-constexpr int PRED_MAX_MODES = 4;  // kept modes k_step_one's prediction tiles are instantiated for (1 .. 4)
+constexpr int PRED_MAX_MODES = 2;  // kept modes k_step_one's prediction tiles are instantiated for (1, 2; three and four were
+                                    // built in round 4 and lost to the two passes by measurement: HISTORY.md)
 // pred_kind 2: the six sums (padded to 8) are kept in this many copies -- workgroup b of the marker kernel adds into
 // copy b % PRED_SUM_COPIES, the field kernels add the copies up: six addresses shared by all workgroups serialise
 constexpr int PRED_SUM_COPIES = 16;
 // dynamic LDS of k_step_sums: E0, A, B tiles (with guard cell), rho copies, reduction scratch
-inline size_t step_sums_lds_bytes(int nx, int rcopies) {
+inline size_t step_sums_lds_bytes(int nx) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
-  return sizeof(double) * (3 * ne + ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) + 96);  // [6][16] scratch
+  return sizeof(double) * (3 * ne + ((static_cast<size_t>(nx) + 2) & ~static_cast<size_t>(1)) + 96);  // [6][16] scratch
 }
 // dynamic LDS of k_step_one: E0, Eh tiles (with guard cell), the tables cell by cell (nx + 1 cells of 2 nm), rho
 // copies, the prediction accumulators cell by cell (nx + 2 cells of 1 + 2 nm)
-inline size_t step_one_lds_bytes(int nx, int rcopies, int nm) {
+inline size_t step_one_lds_bytes(int nx, int nm) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
   return sizeof(double) * (2 * ne + (static_cast<size_t>(nx) + 1) * 2 * nm +
-                           ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) +
+                           ((static_cast<size_t>(nx) + 2) & ~static_cast<size_t>(1)) +
                            (static_cast<size_t>(nx) + 2) * (1 + 2 * nm) + 2);  // (+ the drawn chunks' counter)
 }
 // dynamic LDS of k_step_one<PRIV>: E0, Eh tiles, the one mode's tables cell by cell (nx + 1 cells of 2), rho copies,
@@ -278,19 +286,16 @@ inline size_t step_one_lds_bytes(int nx, int rcopies, int nm) {
 #ifndef PIC1DP_PRIV_THREADS
 #define PIC1DP_PRIV_THREADS 768  // (tuning builds: 1024 = one workgroup of sixteen waves per CU, tools/ab_variant_libs.sh)
 #endif
-#if defined(PIC1DP_TUNE_SUMS2) && !defined(PIC1DP_PRIV2_THREADS)
-#define PIC1DP_PRIV2_THREADS 512  // (tuning build: workgroup of the twenty-sum kernel for two kept modes, tools/ab_sums2.sh)
-#endif
 constexpr int STEP_PRIVATE_THREADS = PIC1DP_PRIV_THREADS;  // k_step_one<PRIV> is launched with exactly this many threads per workgroup
-inline size_t step_one_private_lds_bytes(int nx, int rcopies, int threads = STEP_PRIVATE_THREADS) {
+inline size_t step_one_private_lds_bytes(int nx, int threads = STEP_PRIVATE_THREADS) {
   const size_t ne = static_cast<size_t>((nx + 2) & ~1);
   return sizeof(double) * (2 * ne + (static_cast<size_t>(nx) + 1) * 2 +
-                           ((static_cast<size_t>(nx) * rcopies + 2) & ~static_cast<size_t>(1)) +
+                           ((static_cast<size_t>(nx) + 2) & ~static_cast<size_t>(1)) +
                            6 * static_cast<size_t>(threads) + 16);
 }
 // dynamic LDS of the DIAG variant beyond the grid tiles: histograms + reduction scratch
-inline size_t step_diag_lds_bytes(int nx, int rcopies, int nxo, int nvo) {
-  (void)nx, (void)rcopies;  // the rho region of step_lds_bytes ends 16-byte aligned
+inline size_t step_diag_lds_bytes(int nx, int nxo, int nvo) {
+  (void)nx;  // the rho region of step_lds_bytes ends 16-byte aligned
   return sizeof(double) * (3 * static_cast<size_t>(nxo) * nvo + 3 * static_cast<size_t>(nvo) + 16);
 }
 // full = false: first sub-step (deposit of the half-step state, nothing stored)
@@ -317,7 +322,6 @@ struct PairArgs {
   double *pack;     // null, or what k_charge_pack made, already summed over ranks
   int kind;         // 1 tiles, 2 sums
   PredTab pt;       // kind 2
-  int plain;        // 1: k_field_solve_pair also where the lean k_field_solve_pair1 applies (PIC1DP_PAIR_PLAIN; tests)
   int posted;       // kind 2 with x1: the marker launch's tail has stored this rank's vector and flag already (StepTail mode 2)
 };
 // doubles k_charge_pack writes / one exchange of a one-pass step carries per rank:

@@ -182,7 +182,7 @@ hipError_t launch_ptcldist(const double *x, const double *v, const double *p, co
   const int blocks = ptcldist_blocks(np, nxo, nvo, num_cu);
   // x, v, p, w against the 256 MiB Infinity Cache: beyond it the pass streams (PIC1DP_DIAG_NT=0 / 1 insists)
   bool nt = 32.0 * static_cast<double>(np) > 288.0 * 1048576.0;
-  if (const char *e = std::getenv("PIC1DP_DIAG_NT")) nt = std::atoi(e) != 0;
+  if (const char *e = tuning_env("PIC1DP_DIAG_NT")) nt = std::atoi(e) != 0;
   DistScale fx{};
   const bool use_fx = lds && make_dist_scale(np, blocks, deltaf, bound_p, bound_w, &fx);
   if (fixed_point) *fixed_point = use_fx;

@@ -772,79 +772,15 @@ k_field_solve_pair1(const FieldArgs f, const XchgArgs x1, const PairArgs pa) {
   }
 }
 
-// k_field_solve_pair for k_step_sums' prediction: the field of the new state from its deposited charge, then --
-// with the kept mode just found -- the half-step field of the NEXT step from the six sums: no second forward
-// transform, the sums ARE the projections (pred_forward_sums), only the inverse (:251-257).
-// SRC: 0 one rank (charge from the local accumulators, sums from pa.pred), 1 one-hop exchange (charge2 and the
-// six sums travel together, one exchange of nx + 8 doubles), 2 packed (pa.pack holds both, already all-reduced)
-template <int SRC>
-__global__ void __launch_bounds__(FIELD_THREADS)
-k_field_solve_pair_sums(const FieldArgs f, const XchgArgs x1, const PairArgs pa) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *sCD = reinterpret_cast<double *>(smem);
-  double *sMode = sCD + f.nx;
-  double *sScr = sMode + 2 * f.nmode;
-  double *sTab = sScr + 16;
-  const int nx = f.nx;
-  double *sV = sTab + (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * nx : 0);  // SRC 1: [charge2 | six sums | pad]
-  __shared__ double sK[8];
-  if constexpr (SRC == 1) {
-    if (!pa.posted) {
-      for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) sV[ix] = charge_local_one(f, ix);
-      if (threadIdx.x < 8) {
-        sV[nx + threadIdx.x] = pred_sum_take(pa.pred, threadIdx.x);
-      }
-      __syncthreads();  // element i of the packed vector belongs to thread i % blockDim in the exchange
-    }
-    exchange_vectors(x1, sV, nx + 8, pa.posted != 0);
-    __syncthreads();
-    if (threadIdx.x < 8) sK[threadIdx.x] = sV[nx + threadIdx.x];
-    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
-      const double c = sV[ix];
-      f.charge[ix] = c;
-      const double cd = chargeden_from(f, c);
-      f.chargeden[ix] = cd;
-      sCD[ix] = cd;
-    }
-  } else if constexpr (SRC == 2) {
-    if (threadIdx.x < 8) sK[threadIdx.x] = pa.pack[nx + threadIdx.x];
-    for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {
-      const double c = pa.pack[ix];
-      f.charge[ix] = c;
-      const double cd = chargeden_from(f, c);
-      f.chargeden[ix] = cd;
-      sCD[ix] = cd;
-    }
-  } else {
-    if (threadIdx.x < 8) sK[threadIdx.x] = pred_sum_take(pa.pred, threadIdx.x);
-    solve_fill_chargeden<true, false>(f, sCD);
-  }
-  __syncthreads();
-  solve_body(f, sCD, sMode, sScr, sTab);
-  __syncthreads();  // E, mode_re / mode_im (also in sMode: re, im) are final
-  if (threadIdx.x == 0) {
-    double ac, as;
-    pred_forward_sums(f, pa.pt, sK, sMode[0], sMode[1], ac, as);
-    const double im_h = ac * f.sc_im * f.grad_inv[0];   // :234, :243-247
-    const double re_h = as * f.sc_re * f.grad_inv[0];   // :239
-    sMode[0] = re_h;
-    sMode[1] = im_h;
-    pa.mode_h[0] = re_h;
-    pa.mode_h[1] = im_h;
-  }
-  __syncthreads();
-  for (int ix = threadIdx.x; ix < nx; ix += blockDim.x) {  // inverse, :251-257
-    double sacc = 0.0;
-    sacc = sacc + f.fre[ix] * sMode[0];
-    sacc = sacc + f.fim[ix] * sMode[1];
-    pa.E_h[ix] = sacc * 2.0;
-  }
-}
-
-// k_field_solve_pair_sums trimmed like k_field_solve_pair1, and launched with as many threads as the grid has
-// cells (up to 1024: at nx = 4096 every thread owns four cells and has all its loads in flight at once -- with 256
-// threads each of the kernel's loops is four dependent round trips): charge -> products, [chain | the six sums
-// fetched beside it], both inverse transforms in one loop.  41 -> 33 us at nx 4096, of which the chain is 23.
+// The pair solve for the six-sum prediction (k_step_one<PRIV>, k_step_sums; one kept mode): the field of the new state
+// from its deposited charge in the reference's order, then -- with the kept mode just found -- the half-step field of the
+// NEXT step from the six sums: no second forward transform, the sums ARE the projections (pred_forward_sums), only the
+// inverse (:251-257).  SRC: 0 one rank (charge from the local accumulators, sums from pa.pred), 1 one-hop exchange
+// (charge2 and the six sums travel together, one exchange of nx + 8 doubles), 2 packed (pa.pack holds both, already
+// all-reduced).  Laid out like k_field_solve_pair1 and launched with as many threads as the grid has cells (up to 1024: at
+// nx = 4096 every thread owns four cells and has all its loads in flight at once -- with 256 threads each of the kernel's
+// loops is four dependent round trips): charge -> products, [chain | the six sums fetched beside it], both inverse
+// transforms in one loop.
 template <int SRC>
 __global__ void __launch_bounds__(1024)
 k_field_solve_pair_sums1(const FieldArgs f, const XchgArgs x1, const PairArgs pa) {
@@ -1250,7 +1186,7 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
   size_t lds = sizeof(double) * (static_cast<size_t>(f.nx) + 2 * f.nmode + 16 +
                                  (f.tab_lds ? 2 * static_cast<size_t>(f.nmode) * f.nx : 0));
   const XchgArgs none{};
-  if (pa.kind != 2 && f.nmode == 1 && f.tab_lds && !pa.plain) {  // the lean kernel of the usual case
+  if (pa.kind != 2 && f.nmode == 1 && f.tab_lds) {  // the lean kernel of the usual case
     const size_t ne = (static_cast<size_t>(f.nx) + 1) & ~static_cast<size_t>(1);
     size_t l1 = sizeof(double) * (2 * ne + (FIELD_THREADS / 64) * 6 + 8 + 16 + ((2 * static_cast<size_t>(f.npe) + 1) & ~static_cast<size_t>(1)));
     if (x1) {
@@ -1268,7 +1204,8 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
     }
     return hipGetLastError();
   }
-  if (pa.kind == 2 && f.nmode == 1 && !pa.plain) {  // the lean kernel
+  if (pa.kind == 2) {  // the six sums of ONE kept mode
+    if (f.nmode != 1) return hipErrorInvalidValue;
     const size_t ne = (static_cast<size_t>(f.nx) + 1) & ~static_cast<size_t>(1);
     size_t l1 = sizeof(double) * (2 * ne + 8 + 16 + ((2 * static_cast<size_t>(f.npe) + 1) & ~static_cast<size_t>(1)));
     const int threads = f.nx > 2048 ? 1024 : (f.nx > 1024 ? 512 : FIELD_THREADS);
@@ -1292,23 +1229,6 @@ hipError_t launch_field_solve_pair(const FieldArgs &f, const PairArgs &pa, const
         if (e != hipSuccess) return e;
       }
       hipLaunchKernelGGL(k_field_solve_pair_sums1<0>, dim3(1), dim3(threads), l1, st, f, none, pa);
-    }
-    return hipGetLastError();
-  }
-  if (pa.kind == 2) {
-    if (f.nmode != 1) return hipErrorInvalidValue;
-    if (x1) {
-      lds += sizeof(double) * pack_doubles(f.nx, 1, 2);
-      if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_field_solve_pair_sums<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-      }
-      hipLaunchKernelGGL(k_field_solve_pair_sums<1>, dim3(1), dim3(FIELD_THREADS), lds, st, f, *x1, pa);
-    } else if (pa.pack) {
-      hipLaunchKernelGGL(k_field_solve_pair_sums<2>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, pa);
-    } else {
-      hipLaunchKernelGGL(k_field_solve_pair_sums<0>, dim3(1), dim3(FIELD_THREADS), lds, st, f, none, pa);
     }
     return hipGetLastError();
   }

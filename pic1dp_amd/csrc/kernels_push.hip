@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(1024) k_push(const PushArgs a) {
   if constexpr (FUSED) zero_rho(sR0, a.g);
   if (threadIdx.x == 0) sE[nx] = a.E[0];
   __syncthreads();
-  double *sR = my_rho_copy(sR0, a.g);
+  double *sR = sR0;
 
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
@@ -89,7 +89,7 @@ k_deposit(double *x, const double *q, double *rho, int64_t np, const GridConst g
   double *sR0 = reinterpret_cast<double *>(smem);
   zero_rho(sR0, g);
   __syncthreads();
-  double *sR = my_rho_copy(sR0, g);
+  double *sR = sR0;
   const int64_t npair = np >> 1;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   double2 *x2 = reinterpret_cast<double2 *>(x);

@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
   double *sE = reinterpret_cast<double *>(smem);
   const int nx = a.g.nx;
   double *sR0 = sE + ((nx + 2) & ~1);
-  unsigned *sDraw = reinterpret_cast<unsigned *>(sR0 + ((nx * a.g.rcopies + 2) & ~1));  // the drawn chunks' counter
+  unsigned *sDraw = reinterpret_cast<unsigned *>(sR0 + ((nx + 2) & ~1));  // the drawn chunks' counter
   for (int i = threadIdx.x; i < nx; i += blockDim.x) sE[i] = a.E0[i];
   zero_rho(sR0, a.g);
   if (threadIdx.x == 0) {
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(1024) k_step_half(const StepArgsDev a) {
     *sDraw = 0u;
   }
   __syncthreads();
-  double *sR = my_rho_copy(sR0, a.g);
+  double *sR = sR0;
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   const int64_t npair = a.np >> 1;
   const double2 *x2 = reinterpret_cast<const double2 *>(a.x);
@@ -179,8 +179,8 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
   // behind the rho copies (16-byte aligned): the drawn chunks' counter; DIAG: the histograms, then the block_sum scratch
-  unsigned *sDraw = reinterpret_cast<unsigned *>(sR0 + ((nx * a.g.rcopies + 2) & ~1));
-  double *sH = sR0 + ((nx * a.g.rcopies + 2) & ~1) + 2;
+  unsigned *sDraw = reinterpret_cast<unsigned *>(sR0 + ((nx + 2) & ~1));
+  double *sH = sR0 + ((nx + 2) & ~1) + 2;
   const int ntot = DIAG ? 3 * a.dg.nxo * a.dg.nvo + 3 * a.dg.nvo : 0;
   const DistBins bins{sH, a.dg.nxo * a.dg.nvo, a.dg.nvo};
   DistSums sums;
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(1024) k_step_full(const StepArgsDev a) {
     for (int i = threadIdx.x; i < ntot; i += blockDim.x) sH[i] = 0.0;
   if (threadIdx.x == 0) *sDraw = 0u;
   __syncthreads();
-  double *sR = my_rho_copy(sR0, a.g);
+  double *sR = sR0;
   const int64_t npair = a.np >> 1;
   double2 *x2 = reinterpret_cast<double2 *>(a.x);
   double2 *v2 = reinterpret_cast<double2 *>(a.v);
@@ -551,86 +551,11 @@ __device__ __forceinline__ double pred_one_private(const One &n, double p, int i
   return t2;
 }
 
-#ifdef PIC1DP_TUNE_SUMS2
-// Tuning build -DPIC1DP_TUNE_SUMS2 (tools/ab_sums2.sh): the sums form for TWO kept modes -- the
-// projections of the predicted charge on both modes' tables, 2 x 2 x (1 + 2 x 2) = 20 sums per rank, in thread-private
-// slots of a workgroup of PRIV2_THREADS.  K[b][0] = sum q T_b(x'), K[b][1 + a] = sum c T_a(x) T_b(x') with
-// T = [A_0 B_0 A_1 B_1].  Only the marker kernel exists (its timing is what the experiment asks for): the solve still
-// reads the tiles' layout, so the fields of such a run mean nothing.
-constexpr int PRIV2_THREADS = PIC1DP_PRIV2_THREADS;
-template <int DIST, int MODE, int POW2>
-__device__ __forceinline__ double pred_one_private2(const One &n, double p, int ix, double wl, const double *sAB, double *sS,
-                                                    const StepArgsDev &a) {
-  constexpr int stride = PRIV2_THREADS;
-  const int nx = a.g.nx;
-  double t2 = 0.0;
-  double u[4] = {0.0, 0.0, 0.0, 0.0};
-  if constexpr (MODE != MODE_FULLF) {
-    const double tmp1 = (MODE == MODE_DF_LIN) ? p : (p - n.w);
-    if constexpr (POW2 == 0) {
-      if (a.s.fastc) {
-        DivFast dv;
-        t2 = dlnf0<DIST, POW2>(n.v, a.s, dv);
-        if (!dv.ok()) {
-          DivTrue dt;
-          t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
-        }
-      } else {
-        DivTrue dt;
-        t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
-      }
-    } else {
-      DivTrue dt;
-      t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
-    }
-    const double c = tmp1 * t2 * (a.pred_k * a.s.Z);
-    const double *gl = sAB + 4 * ix;
-    const double wlr = 1.0 - wl;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const double2 tl = *reinterpret_cast<const double2 *>(gl + 2 * m), tr = *reinterpret_cast<const double2 *>(gl + 4 + 2 * m);
-      u[2 * m] = c * fma(tr.x, wlr, tl.x * wl);
-      u[2 * m + 1] = c * fma(tr.y, wlr, tl.y * wl);
-    }
-  }
-  const double xh = fma(a.dt_half, n.v, n.x);
-  const double sh = xh * a.snx;
-  const double fh = floor(sh);
-  int ih = static_cast<int>(fh);
-  const double wr = sh - fh, wh = 1.0 - wr;
-  ih = ih < 0 ? ih + nx : ih;
-  ih = ih >= nx ? ih - nx : ih;
-  if (static_cast<unsigned>(ih) >= static_cast<unsigned>(nx)) {
-    ih = ih % nx;
-    if (ih < 0) ih += nx;
-  }
-  const double *hl = sAB + 4 * ih;
-  const double q = a.s.Z * (MODE == MODE_FULLF ? p : n.w);
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const double2 ul = *reinterpret_cast<const double2 *>(hl + 2 * m), ur = *reinterpret_cast<const double2 *>(hl + 4 + 2 * m);
-    const double T[2] = {fma(ur.x, wr, ul.x * wh), fma(ur.y, wr, ul.y * wh)};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      double *s = sS + (5 * (2 * m + h)) * stride;
-      lds_add(s, q * T[h]);
-      if constexpr (MODE != MODE_FULLF) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lds_add(s + (1 + k) * stride, u[k] * T[h]);
-      }
-    }
-  }
-  return t2;
-}
-#endif
 
 // the private sums of one marker: six for one kept mode (tuning build: twenty for two)
 template <int DIST, int MODE, int POW2, int NM>
 __device__ __forceinline__ double priv_sums(const One &n, double p, int ix, double wl, const double *sAB, double *sS,
                                             const StepArgsDev &a) {
-#ifdef PIC1DP_TUNE_SUMS2
-  if constexpr (NM == 2) return pred_one_private2<DIST, MODE, POW2>(n, p, ix, wl, sAB, sS, a);
-#endif
   return pred_one_private<DIST, MODE, POW2>(n, p, ix, wl, sAB, sS, a);
 }
 
@@ -640,13 +565,8 @@ __device__ __forceinline__ double priv_sums(const One &n, double p, int ix, doub
 template <int DIST, int MODE, int POW2, bool NT, int T2, int NM, bool PRIV = false, bool FUSED = false>
 __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
   static_assert(!FUSED || PRIV, "the fused solve serves the six-sum prediction");
-#ifdef PIC1DP_TUNE_SUMS2
-  constexpr int NS = NM == 2 ? 20 : 6, PT = NM == 2 ? PRIV2_THREADS : PRIV_THREADS;  // private sums, threads they are laid out for
-  static_assert(!FUSED || NM == 1, "");
-#else
   constexpr int NS = 6, PT = PRIV_THREADS;
   static_assert(!PRIV || NM == 1, "six sums: one kept mode");
-#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   STAMP(a, 0);
   STAMP_HWID(a);
@@ -658,7 +578,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   double *sEh = sE0 + ne;
   double *sAB = sEh + ne;                                        // [nx + 1][2 nm]: A_0 B_0 (A_1 B_1) per cell
   double *sR0 = sAB + static_cast<size_t>(nx + 1) * 2 * nm;
-  double *sP = sR0 + ((nx * a.g.rcopies + 2) & ~1);              // [nx + 2][1 + 2 nm]: R0 RA_m RB_m per cell
+  double *sP = sR0 + ((nx + 2) & ~1);              // [nx + 2][1 + 2 nm]: R0 RA_m RB_m per cell
                                                                  // PRIV: [6][blockDim] private sums, then [16] scratch
   if constexpr (!FUSED) {
     for (int i = threadIdx.x; i < nx; i += blockDim.x) {
@@ -696,7 +616,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   if (threadIdx.x == 0) *sDraw = 0u;
   __syncthreads();
   STAMP(a, 1);
-  double *sR = my_rho_copy(sR0, a.g);
+  double *sR = sR0;
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
   constexpr bool CARRY_IN = (T2 == 2) && HAS_W;
@@ -721,21 +641,8 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     dealt -= drawn_rows;
     drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
   }
-  // PIC1DP_WAVE_PRIO (experiment): a wave's issue priority falls with its progress (quarters of its trips), so that of the
-  // two workgroups that share a CU the one that is behind wins the issue slots -- they stay together instead of the older
-  // one finishing a third earlier and the younger one running the last stretch alone at half the occupancy
-  const int trips_q = a.wave_prio ? max(1, (dealt + (drawn_total / max(1, static_cast<int>(blockDim.x >> 6))) + 3) >> 2) : 0;
-  int next_q = 0;
-  if (a.wave_prio) __builtin_amdgcn_s_setprio(3);
   int64_t j = first + threadIdx.x;
   for (int k = 0;; ++k, j += stride) {
-    if (a.wave_prio && k >= next_q) {  // (wave-uniform)
-      next_q += trips_q;
-      const int q = k / trips_q;
-      if (q == 1) __builtin_amdgcn_s_setprio(2);
-      else if (q == 2) __builtin_amdgcn_s_setprio(1);
-      else if (q >= 3) __builtin_amdgcn_s_setprio(0);
-    }
     if (k >= dealt) {
       int c = 0;
       if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(sDraw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -796,19 +703,6 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   if constexpr (PRIV) {  // the six sums: wave k adds up the slots of sum k (12 reads per lane, a wave reduction), one
                          // global atomic each -- no barrier beyond the one above
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#ifdef PIC1DP_TUNE_SUMS2
-    if constexpr (NM == 2) {
-      for (int k = wave; k < NS; k += PT / 64) {
-        const double *s = sP + k * PT + lane;
-        double t = 0.0;
-#pragma unroll
-        for (int j = 0; j < PT / 64; ++j) t += s[64 * j];
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-        if (lane == 0) glb_add(a.pred + (blockIdx.x % PRED_SUM_COPIES) * 24 + k, t);
-      }
-      return;
-    }
-#endif
     if (wave < 6) {
       const double *s = sP + wave * PRIV_THREADS + lane;
       double t = 0.0;
@@ -922,7 +816,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   double *sA = sE0 + ne;
   double *sB = sA + ne;
   double *sR0 = sB + ne;
-  double *sScr = sR0 + ((nx * a.g.rcopies + 2) & ~1);  // [6][16] reduction scratch
+  double *sScr = sR0 + ((nx + 2) & ~1);  // [6][16] reduction scratch
   unsigned *sDraw = reinterpret_cast<unsigned *>(sScr);  // the chunk counter of the drawn tail: the head of the scratch,
                                                          // which the reductions need only behind the loop's barrier
   if constexpr (!FUSED) {
@@ -951,7 +845,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
   __syncthreads();
   STAMP(a, 1);
   const ModeField sEh{sA, sB, re_h, im_h};
-  double *sR = my_rho_copy(sR0, a.g);
+  double *sR = sR0;
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
   constexpr bool CARRY_IN = (T2 == 2) && HAS_W;
@@ -974,21 +868,8 @@ __global__ void __launch_bounds__(1024) PIC1DP_SUMS_ATTR k_step_sums(const StepA
     dealt -= drawn_rows;
     drawn_total = drawn_rows * static_cast<int>(blockDim.x >> 6);
   }
-  // PIC1DP_WAVE_PRIO (experiment): a wave's issue priority falls with its progress (quarters of its trips), so that of the
-  // two workgroups that share a CU the one that is behind wins the issue slots -- they stay together instead of the older
-  // one finishing a third earlier and the younger one running the last stretch alone at half the occupancy
-  const int trips_q = a.wave_prio ? max(1, (dealt + (drawn_total / max(1, static_cast<int>(blockDim.x >> 6))) + 3) >> 2) : 0;
-  int next_q = 0;
-  if (a.wave_prio) __builtin_amdgcn_s_setprio(3);
   int64_t j = first + threadIdx.x;
   for (int k = 0;; ++k, j += stride) {
-    if (a.wave_prio && k >= next_q) {  // (wave-uniform)
-      next_q += trips_q;
-      const int q = k / trips_q;
-      if (q == 1) __builtin_amdgcn_s_setprio(2);
-      else if (q == 2) __builtin_amdgcn_s_setprio(1);
-      else if (q >= 3) __builtin_amdgcn_s_setprio(0);
-    }
     if (k >= dealt) {
       int c = 0;
       if ((threadIdx.x & 63) == 0) c = static_cast<int>(__hip_atomic_fetch_add(sDraw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1060,7 +941,7 @@ hipError_t stamp_hook(StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
   if (!s.dev) {
     hipError_t e = hipMalloc(&s.dev, sizeof(unsigned long long) * 8 * kStampGrid);
     if (e != hipSuccess) return e;
-    if (const char *a = std::getenv("PIC1DP_STAMP_AT")) s.at = std::atol(a);
+    if (const char *a = tuning_env("PIC1DP_STAMP_AT")) s.at = std::atol(a);
   }
   if (s.launches == s.at + 1 && s.at >= 0) {
     hipError_t e = hipStreamSynchronize(st);
@@ -1068,7 +949,7 @@ hipError_t stamp_hook(StepArgsDev &d, const LaunchCfg &lc, hipStream_t st) {
     std::vector<unsigned long long> h(static_cast<size_t>(8) * s.blocks);
     e = hipMemcpy(h.data(), s.dev, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return e;
-    if (const char *fn = std::getenv("PIC1DP_STAMP_FILE")) {
+    if (const char *fn = tuning_env("PIC1DP_STAMP_FILE")) {
       if (FILE *f = std::fopen(fn, "w")) {
         std::fprintf(f, "# blocks %d threads %d\n", s.blocks, s.threads);
         for (int b = 0; b < s.blocks; ++b) {
@@ -1104,31 +985,35 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d0, const LaunchCfg &lc
   return hipGetLastError();
 }
 
-static_assert(PRED_MAX_MODES == 4, "k_step_one is instantiated for one to four kept modes");
+// -f0'/f0 carried to the next step through memory (T2 = 1, 2): what the reference-order form of the exp-bearing
+// distributions does by default (DIST 2, 3).  For every other distribution the carry is a measured-and-dropped variant
+// (DIST 4, 5: the one-exp form evaluates again, 56 B instead of 72; DIST 0, 1 have nothing worth carrying): built for a
+// tuning build's PIC1DP_CARRY only -- two thirds of the one-pass instantiations of those units (round 6).
+#ifdef PIC1DP_TUNING
+template <int DIST>
+constexpr bool kCarryBuilt = true;
+#else
+template <int DIST>
+constexpr bool kCarryBuilt = DIST == 2 || DIST == 3;
+#endif
+
+static_assert(PRED_MAX_MODES == 2, "k_step_one is instantiated for one and two kept modes");
 static_assert(PRIV_THREADS == STEP_PRIVATE_THREADS, "slot stride of k_step_one<PRIV> = its workgroup size");
 template <int DIST, int MODE, int POW2, int NM>
 hipError_t launch_step_one(const StepArgsDev &d, int t2m, const LaunchCfg &lc, hipStream_t st) {
-  if constexpr (NM > 2) {  // three and four kept modes (on request: two passes measure faster): without the carry
-    if (t2m != 0) return hipErrorInvalidValue;
-    return d.nt ? launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, NM>, d, lc, st)
-                : launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, NM>, d, lc, st);
-  }
-#ifdef PIC1DP_TUNE_SUMS2
-  if constexpr (NM == 2) {
-    if (d.sums2) {
-      if (t2m != 0) return hipErrorInvalidValue;
-      return d.nt ? launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 2, true>, d, lc, st)
-                  : launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 2, true>, d, lc, st);
-    }
-  }
-#endif
   if (d.nt) {
-    if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, NM>, d, lc, st);
-    if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, NM>, d, lc, st);
+    if constexpr (kCarryBuilt<DIST>) {
+      if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, NM>, d, lc, st);
+      if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, NM>, d, lc, st);
+    }
+    if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
     return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, NM>, d, lc, st);
   }
-  if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, NM>, d, lc, st);
-  if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, NM>, d, lc, st);
+  if constexpr (kCarryBuilt<DIST>) {
+    if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, NM>, d, lc, st);
+    if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, NM>, d, lc, st);
+  }
+  if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
   return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, NM>, d, lc, st);
 }
 
@@ -1138,50 +1023,72 @@ hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc,
     const int t2m = d.t2 ? d.t2_mode : 0;
     if (d.fused.on) {  // ... and the previous step's field solved in the prologue
       if (d.nt) {
-        if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, 1, true, true>, d, lc, st);
-        if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, 1, true, true>, d, lc, st);
+        if constexpr (kCarryBuilt<DIST>) {
+          if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, 1, true, true>, d, lc, st);
+          if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, 1, true, true>, d, lc, st);
+        }
+        if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
         return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 1, true, true>, d, lc, st);
       }
-      if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, 1, true, true>, d, lc, st);
-      if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, 1, true, true>, d, lc, st);
+      if constexpr (kCarryBuilt<DIST>) {
+        if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, 1, true, true>, d, lc, st);
+        if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, 1, true, true>, d, lc, st);
+      }
+      if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
       return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 1, true, true>, d, lc, st);
     }
     if (d.nt) {
-      if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, 1, true>, d, lc, st);
-      if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, 1, true>, d, lc, st);
+      if constexpr (kCarryBuilt<DIST>) {
+        if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 2, 1, true>, d, lc, st);
+        if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, 1, true>, d, lc, st);
+      }
+      if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
       return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 1, true>, d, lc, st);
     }
-    if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, 1, true>, d, lc, st);
-    if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, 1, true>, d, lc, st);
+    if constexpr (kCarryBuilt<DIST>) {
+      if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, 1, true>, d, lc, st);
+      if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, 1, true>, d, lc, st);
+    }
+    if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
     return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 1, true>, d, lc, st);
   }
   if (full && d.pred && d.pred_nm < 0) {  // one pass per step, prediction as six sums (large grids)
     const int t2m = d.t2 ? d.t2_mode : 0;
     if (d.fused.on) {
       if (d.nt) {
-        if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 2, true>, d, lc, st);
-        if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1, true>, d, lc, st);
+        if constexpr (kCarryBuilt<DIST>) {
+          if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 2, true>, d, lc, st);
+          if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1, true>, d, lc, st);
+        }
+        if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
         return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 0, true>, d, lc, st);
       }
-      if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 2, true>, d, lc, st);
-      if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 1, true>, d, lc, st);
+      if constexpr (kCarryBuilt<DIST>) {
+        if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 2, true>, d, lc, st);
+        if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 1, true>, d, lc, st);
+      }
+      if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
       return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 0, true>, d, lc, st);
     }
     if (d.nt) {
-      if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 2>, d, lc, st);
-      if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1>, d, lc, st);
+      if constexpr (kCarryBuilt<DIST>) {
+        if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 2>, d, lc, st);
+        if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1>, d, lc, st);
+      }
+      if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
       return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 0>, d, lc, st);
     }
-    if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 2>, d, lc, st);
-    if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 1>, d, lc, st);
+    if constexpr (kCarryBuilt<DIST>) {
+      if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 2>, d, lc, st);
+      if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 1>, d, lc, st);
+    }
+    if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
     return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 0>, d, lc, st);
   }
   if (full && d.pred) {  // one pass per step: also predicts the next step's first-sub-step charge
     const int t2m = d.t2 ? d.t2_mode : 0;
     if (d.pred_nm == 1) return launch_step_one<DIST, MODE, POW2, 1>(d, t2m, lc, st);
     if (d.pred_nm == 2) return launch_step_one<DIST, MODE, POW2, 2>(d, t2m, lc, st);
-    if (d.pred_nm == 3) return launch_step_one<DIST, MODE, POW2, 3>(d, t2m, lc, st);
-    if (d.pred_nm == 4) return launch_step_one<DIST, MODE, POW2, 4>(d, t2m, lc, st);
     return hipErrorInvalidValue;  // PRED_MAX_MODES
   }
   if (full && d.dist_out) {  // with the diagnostics of output_all (their histograms as fixed-point sums where the host knows bounds)

@@ -48,7 +48,7 @@ SpeciesConst make_species_const(const SpeciesInput &in, int s) {
            is_pow2(c.two_tm2) && is_pow2(c.stm) && is_pow2(c.stm2);
   c.unit = c.m == 1.0 && T == 1.0 && T2 == 1.0 && c.tm == 1.0 && c.tm2 == 1.0 && c.stm == 1.0 &&
            c.stm2 == 1.0 && c.two_tm == 2.0 && c.two_tm2 == 2.0;
-  if (const char *e = std::getenv("PIC1DP_UNIT_SPECIALISATION")) c.unit = c.unit && std::atoi(e) != 0;
+  if (const char *e = tuning_env("PIC1DP_UNIT_SPECIALISATION")) c.unit = c.unit && std::atoi(e) != 0;
   // general divisors: a/c through div_const (device_math.hpp) if every one of the
   // eight is in a sane range and a randomised host comparison with the true
   // quotient finds no difference (the theorem behind it holds for every finite
@@ -63,7 +63,7 @@ SpeciesConst make_species_const(const SpeciesInput &in, int s) {
     }
     c.fastc = ok ? 1 : 0;
   }
-  if (const char *e = std::getenv("PIC1DP_FAST_DIVC")) c.fastc = c.fastc && std::atoi(e) != 0;
+  if (const char *e = tuning_env("PIC1DP_FAST_DIVC")) c.fastc = c.fastc && std::atoi(e) != 0;
 
   // One-exp form of -f0'/f0 (device_math.hpp dlnf0_one_exp).  L(v) = (fq2 v + fq1) v + fq0 is the log of the
   // ratio of the second Maxwellian to the first, tmp2 = (fm1 v + fm0) + (fd1 v + fd0) tanh(L / 2).

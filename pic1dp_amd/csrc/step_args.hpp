@@ -30,11 +30,7 @@ struct StepArgsDev {
   StepTail tail;                // kernels.hpp: the last workgroup packs / posts this rank's charge
   DistScale dscale;             // k_step_full<DIAG, FX>
   int diag_fx;
-  int wave_prio;                // (experiment) issue priority by progress
   int dyn_tail;                 // sixteenths of a workgroup's chunks drawn from an LDS counter
-#ifdef PIC1DP_TUNE_SUMS2  // tuning build (tools/ab_sums2.sh): two kept modes as twenty private sums (marker kernel only)
-  int sums2;
-#endif
 #ifdef PIC1DP_TUNE_STAMPS  // tuning build (tools/stamp_probe.sh): [gridDim][8] wall-clock stamps of the phases of a workgroup
   unsigned long long *stamps;
 #endif

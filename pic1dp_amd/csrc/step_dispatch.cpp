@@ -35,12 +35,8 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.fused = a.fused;
   d.tail = a.tail;
   d.dyn_tail = a.dyn_tail;
-  d.wave_prio = a.wave_prio;
   d.dscale = a.dscale;
   d.diag_fx = a.diag_fx;
-#ifdef PIC1DP_TUNE_SUMS2
-  d.sums2 = a.sums2;
-#endif
   // full-f evaluates no f0 derivative: one instantiation (in the DIST 0 unit) serves every distribution
   if (!a.deltaf) return launch_step_dist<0>(d, a.deltaf, a.linear, full, lc, st);
   switch (a.iptcldist) {

@@ -105,6 +105,11 @@ class Pic1dp:
     def particle_load(self):
         check(self.L.pic1dp_hip_particle_load(self._ctx))
 
+    def set_seed_offset(self, offset):
+        """ensemble member: reference block b of the next particle_load draws from RNG stream mype = b + offset
+        (0: the reference's constant-seed run)"""
+        check(self.L.pic1dp_hip_set_seed_offset(self._ctx, int(offset)))
+
     def particles_upload(self, x, v, p, w, ispecies=0, np_valid=None):
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, v, p, w)]
         n = arrs[0].size
@@ -460,3 +465,8 @@ class Pic1dp:
 
 def device_count():
     return _lib.load().pic1dp_hip_device_count()
+
+
+def tuning_build():
+    """True when the loaded library is a -DPIC1DP_TUNING build (it then reads the measurement knobs of tools/README.md)"""
+    return _lib.load().pic1dp_hip_tuning_build() == 1

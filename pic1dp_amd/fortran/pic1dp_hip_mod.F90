@@ -58,6 +58,10 @@ interface
     import
     integer(c_int) :: ierr
   end function pic1dp_hip_abi_version
+  function pic1dp_hip_tuning_build() bind(C, name="pic1dp_hip_tuning_build") result(ierr)
+    import
+    integer(c_int) :: ierr
+  end function pic1dp_hip_tuning_build
   function pic1dp_hip_device_count() bind(C, name="pic1dp_hip_device_count") result(ierr)
     import
     integer(c_int) :: ierr
@@ -402,6 +406,12 @@ interface
     integer(c_int32_t), intent(out) :: kind
     integer(c_int) :: ierr
   end function pic1dp_hip_predict_kind
+  function pic1dp_hip_set_seed_offset(ctx, offset) bind(C, name="pic1dp_hip_set_seed_offset") result(ierr)
+    import
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: offset
+    integer(c_int) :: ierr
+  end function pic1dp_hip_set_seed_offset
   function pic1dp_hip_set_output_fusion(ctx, on) bind(C, name="pic1dp_hip_set_output_fusion") result(ierr)
     import
     type(c_ptr), value :: ctx

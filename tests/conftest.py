@@ -54,6 +54,17 @@ def amd():
     return pic1dp_amd
 
 
+@pytest.fixture
+def tuning(amd):
+    """tests that vary a MEASUREMENT knob (launch shapes, thresholds, schedules: tools/README.md) need a -DPIC1DP_TUNING
+    build of the library -- the product build compiles none of them (round 6).  Build one with
+    `PIC1DP_EXTRA_FLAGS=-DPIC1DP_TUNING PIC1DP_LIB_OUT=$PWD/pic1dp_amd/lib/v_tuning.so python pic1dp_amd/build.py --force`
+    and run the suite with PIC1DP_LIB pointing at it; with the product library these tests are skipped."""
+    if not amd.tuning_build():
+        pytest.skip("needs a -DPIC1DP_TUNING build of the library (PIC1DP_LIB=.../v_tuning.so): the product build has no such knob")
+    return True
+
+
 @pytest.fixture(scope="session")
 def probe():
     """libpic1dp_probe.so (measurement / test support, include/pic1dp_probe.h): array evaluations of the

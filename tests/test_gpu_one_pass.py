@@ -20,8 +20,8 @@ def engine(amd, monkeypatch, predict, kind=None, npe=1, **kw):
     thread-private LDS slots where E0, Eh and the tables fit the LDS, else k_step_sums) -- the library's own choice
     is the sums from nx = 512 up with one kept mode, the tiles below and with two kept modes"""
     monkeypatch.setenv("PIC1DP_PREDICT", "1" if predict else "0")
-    if kind and predict:         # 1: the tiles wherever they fit; 2: the six sums (k_step_one<PRIV> / k_step_sums)
-        monkeypatch.setenv("PIC1DP_PRED_KIND", str(kind))
+    if kind and predict:         # 1: the tiles wherever they fit; 2: the six sums (k_step_one<PRIV> / k_step_sums);
+        monkeypatch.setenv("PIC1DP_PRED_KIND", str(kind))      # 3: the six sums in registers (k_step_sums) at any grid
     else:
         monkeypatch.delenv("PIC1DP_PRED_KIND", raising=False)
     e = amd.Pic1dp(amd.make_input(**kw), npe=npe)
@@ -228,25 +228,24 @@ def test_chargeden_asked_for_between_push2_and_collect_charge(amd, monkeypatch):
                          ids=["nx96", "nx1000", "nx2050_full_f", "two_species"])
 @pytest.mark.parametrize("kind", KINDS, ids=["tiles", "sums"])
 @pytest.mark.parametrize("npe", [1, 4, 9], ids=lambda v: "npe%d" % v)
-def test_lean_pair_solve_equals_the_plain_one(oracle_mod, amd, monkeypatch, kw, kind, npe):
-    """k_field_solve_pair1 / k_field_solve_pair_sums1 (one kept mode: everything that does not wait for the
-    serial sums in front of them) against k_field_solve_pair / k_field_solve_pair_sums: the predicted half-step field and the run to rounding; and the field of the
-    new state from ITS charge density against the oracle's solve bit for bit, both kernels"""
+def test_pair_solve_new_state_field_bit_identical_to_the_oracle(oracle_mod, amd, monkeypatch, kw, kind, npe):
+    """k_field_solve_pair1 / k_field_solve_pair_sums1 (one kept mode: everything that does not wait for the serial sums in
+    front of them, both fields of a one-pass step in one launch): the field of the new state from ITS charge density against
+    the oracle's solve bit for bit, in the order of an npe-rank reference run; the predicted half-step field and the run
+    against the two-pass engine to rounding.  (Until round 6 the comparison was with the unoptimised kernels of the same
+    launch, PIC1DP_PAIR_PLAIN: retired with them.)"""
     kw = dict(kw, nparticle_max=N)
     if kind == 2 and kw["nx"] == 1000:
         kw["nx"] = 4096               # the grid the sums are for: 1024 threads, four cells each
-    monkeypatch.setenv("PIC1DP_PAIR_PLAIN", "1")
-    a = engine(amd, monkeypatch, True, kind, npe, **kw)
-    monkeypatch.delenv("PIC1DP_PAIR_PLAIN")
+    a = engine(amd, monkeypatch, False, None, npe, **kw)
     b = engine(amd, monkeypatch, True, kind, npe, **kw)
-    assert a.predict_kind() == kind and b.predict_kind() == kind
+    assert a.predict_kind() == 0 and b.predict_kind() == kind
     field = oracle_mod.Field(oracle_mod.make_input(**kw))
     for it in range(4):
         a.step(1)
         b.step(1)
         fa, fb = a.get_field(), b.get_field()
         assert relerr(fa["electric"], fb["electric"]) < 1e-11, it
-        assert relerr(a.get_field_half(), b.get_field_half()) < 1e-11, it
         for f in (fa, fb):
             E, re, im = field.solve(f["chargeden"], npe)   # in the order of an npe-rank reference run
             assert np.array_equal(f["electric"], E) and np.array_equal(f["mode_re"], re) and np.array_equal(f["mode_im"], im)
@@ -307,9 +306,9 @@ def test_prediction_is_dropped_when_it_no_longer_applies(amd, monkeypatch, kind)
 @pytest.mark.parametrize("kw,predicted", [
     (dict(nmode=2, modes=[1, 3], init_nmode=2, init_mode=[1, 3], init_mode_cos=[0.0, 2e-6], init_mode_sin=[1e-5, 0.0]), True),
     (dict(nmode=3, modes=[1, 2, 5], init_nmode=3, init_mode=[1, 2, 5], init_mode_cos=[0.0, 2e-6, 1e-6],
-          init_mode_sin=[1e-5, 0.0, 3e-6]), True),              # three and four kept modes: tiles too (round 4)
-    (dict(nmode=4, modes=[1, 2, 3, 7], init_nmode=2, init_mode=[1, 7], init_mode_cos=[0.0, 2e-6], init_mode_sin=[1e-5, 0.0]), True),
-    (dict(nmode=5, modes=[1, 2, 3, 4, 5]), False),              # more kept modes than the tiles are built for: two passes
+          init_mode_sin=[1e-5, 0.0, 3e-6]), False),             # three and more kept modes: two passes (the tiles are built
+    (dict(nmode=4, modes=[1, 2, 3, 7], init_nmode=2, init_mode=[1, 7], init_mode_cos=[0.0, 2e-6], init_mode_sin=[1e-5, 0.0]), False),
+    (dict(nmode=5, modes=[1, 2, 3, 4, 5]), False),              # for one and two: round 4's three / four lost by measurement)
     (dict(nspecies=2, iptcldist=0, species_charge=[-1.0, 1.0], species_mass=[1.0, 25.0], species_temperature=[1.0, 0.5],
           species_temperature2=[1.0, 1.0], species_density=[1.0, 1.0], species_v0=[0.0, 0.0], lx=4 * np.pi), True),
     (dict(nx=4096), True),                                      # eight tiles of 32 KiB do not fit the LDS: six sums
@@ -325,7 +324,6 @@ def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind)
     kw = dict(dict(nparticle_max=N, nx=96), **kw)
     if kind == 2 and kw.get("nmode", 1) in (2, 3, 4) and kw["nx"] < 4096:
         pytest.skip("two to four kept modes: the tiles' case")
-    # (three and four kept modes: one pass when PIC1DP_PRED_KIND=1 asks for it -- `kind` does here; by default two passes)
     a = engine(amd, monkeypatch, True, kind, **kw)
     assert a.predict_kind() == (0 if not predicted else 2 if (kind == 2 or kw["nx"] == 4096) else 1)
     b = engine(amd, monkeypatch, False, **kw)
@@ -344,15 +342,14 @@ def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind)
 @pytest.mark.parametrize("kw,kind", [
     (dict(nx=2542), 1), (dict(nx=2543), 2),                                   # the last grid the tiles hold, the first for the sums
     (dict(nx=1694, nmode=2, modes=[1, 3]), 1), (dict(nx=1695, nmode=2, modes=[1, 3]), 0),
-    (dict(nx=1015, nmode=4, modes=[1, 2, 3, 5]), 1), (dict(nx=1016, nmode=4, modes=[1, 2, 3, 5]), 0),
+    (dict(nx=512, nmode=4, modes=[1, 2, 3, 5]), 0),                           # three and more kept modes: two passes
     (dict(nx=5063), 2), (dict(nx=5064), 0)],                                  # the last grid for the sums, then two passes
-    ids=["tiles_last", "sums_first", "two_modes_last", "two_modes_beyond", "four_modes_last", "four_modes_beyond", "sums_last",
-         "beyond"])
+    ids=["tiles_last", "sums_first", "two_modes_last", "two_modes_beyond", "four_modes_two_passes", "sums_last", "beyond"])
 def test_one_pass_at_the_lds_limits(amd, monkeypatch, kw, kind):
     """the grids at which the one-pass kernels' LDS tiles just fit and just do not (kernels.hpp step_one_lds_bytes,
     step_sums_lds_bytes against PARTICLE_LDS_CAP): the choice, and the run against the two-pass engine"""
     kw = dict(kw, nparticle_max=N)
-    a = engine(amd, monkeypatch, True, 1 if kw.get("nmode", 1) > 2 else None, **kw)   # (3, 4 kept modes: on request)
+    a = engine(amd, monkeypatch, True, None, **kw)
     assert a.predict_kind() == kind
     b = engine(amd, monkeypatch, False, **kw)
     a.step(5)
@@ -426,19 +423,21 @@ def test_prediction_of_markers_that_cross_several_boxes(amd, monkeypatch, kind):
 # ---------------------------------------------------------------------------
 def fused_pair(amd, monkeypatch, npe=1, env=None, **kw):
     """two engines on the same input: the solve inside the marker launches, and in launches of its own"""
-    for k, v in (env or {}).items():
+    env = dict(env or {})
+    kind = int(env.pop("PIC1DP_PRED_KIND", "2"))
+    for k, v in env.items():
         monkeypatch.setenv(k, v)
     monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "2")      # (1, the default, fuses where the serial sums are short enough)
-    a = engine(amd, monkeypatch, True, 2, npe=npe, **kw)
+    a = engine(amd, monkeypatch, True, kind, npe=npe, **kw)
     monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "0")
-    b = engine(amd, monkeypatch, True, 2, npe=npe, **kw)
+    b = engine(amd, monkeypatch, True, kind, npe=npe, **kw)
     monkeypatch.delenv("PIC1DP_FUSE_SOLVE")
     return a, b
 
 
 FUSED_CASES = [
     ("bump_private_slots", dict(), 1, {}),
-    ("bump_register_sums", dict(), 1, {"PIC1DP_PRED_PRIVATE": "0"}),
+    ("bump_register_sums", dict(), 1, {"PIC1DP_PRED_KIND": "3"}),
     ("bump_four_rank_order", dict(), 4, {}),
     ("bump_reference_order_dlnf0_carry", dict(), 1, {"PIC1DP_DLNF0": "ref"}),
     ("two_stream2_nonpow2", dict(iptcldist=2, species_density=[1.0], species_v0=[3.0], species_temperature=[0.9],
@@ -481,8 +480,8 @@ def test_fused_solve_bit_identical_to_the_field_kernel(amd, monkeypatch, name, k
 @pytest.mark.parametrize("threads,bpc,osub", [(64, 0, None), (128, 0, None), (256, 0, None), (1024, 0, None), (512, 2, None),
                                               (0, 0, "1"), (0, 0, "3")],
                          ids=["t64", "t128", "t256", "t1024", "t512x2", "osub1", "osub3"])
-def test_fused_solve_over_launch_shapes(amd, monkeypatch, threads, bpc, osub):
-    """pic1dp_hip_set_launch / PIC1DP_OSUB together with the solve in the marker launch's prologue.  A
+def test_fused_solve_over_launch_shapes(amd, monkeypatch, request, threads, bpc, osub):
+    """pic1dp_hip_set_launch / PIC1DP_OSUB (a tuning build's knob) together with the solve in the marker launch's prologue.  A
     launch shape asked for by hand selects the register-sum kernel (k_step_sums<FUSED>) with that workgroup size; the
     prologue zeroes the rotated accumulator sets with strided stores whatever the size, and a workgroup of one wave --
     which has no first AND last wave for the prologue's two jobs -- must not fuse at all.  One wave of markers per
@@ -490,6 +489,7 @@ def test_fused_solve_over_launch_shapes(amd, monkeypatch, threads, bpc, osub):
     accumulator set to have been read, deposited into and zeroed several times."""
     kw = dict(nparticle_max=96, nx=32)
     if osub:
+        request.getfixturevalue("tuning")
         monkeypatch.setenv("PIC1DP_OSUB", osub)
     monkeypatch.setenv("PIC1DP_FUSE_SOLVE", "2")
     a = engine(amd, monkeypatch, True, 2, **kw)
@@ -540,7 +540,7 @@ def test_fused_solve_many_markers_small_workgroups(oracle_mod, amd, monkeypatch)
         assert np.max(np.abs(a.energy_history() / np.array(eo) - 1.0)) < 1e-10, threads
 
 
-@pytest.mark.parametrize("nx,env", [(1024, {}), (96, {}), (2500, {}), (1024, {"PIC1DP_PRED_PRIVATE": "0"})],
+@pytest.mark.parametrize("nx,env", [(1024, {}), (96, {}), (2500, {}), (1024, {"PIC1DP_PRED_KIND": "3"})],
                          ids=["nx1024_private_slots", "nx96_private_slots", "nx2500_register_sums", "nx1024_register_sums"])
 def test_fused_solve_many_markers(oracle_mod, amd, monkeypatch, nx, env):
     """at a realistic marker count (the order of the charge atomics differs between runs): every step's field energy
@@ -598,12 +598,11 @@ def test_fused_solve_with_output_steps(oracle_mod, amd, monkeypatch):
 
 @pytest.mark.parametrize("modes", [[1, 2, 3], [1, 2, 3, 5]], ids=["three_modes", "four_modes"])
 @pytest.mark.parametrize("mname,mkw", MODES, ids=[m[0] for m in MODES])
-def test_one_pass_three_and_four_kept_modes_against_oracle(oracle_mod, amd, monkeypatch, modes, mname, mkw):
-    """the reference allows any input_nmode (src/pic1dp_input.F90:75-80); with three and four kept
-    modes the step can still be ONE pass over the markers (prediction tiles R0, RA_m, RB_m per kept mode,
-    src/pic1dp_field.F90:231-257; PIC1DP_PRED_KIND=1 -- the two passes stay the default there, they measure faster:
-    profiles/r04/experiments/ab_kept_modes.log) -- against the oracle directly: field energy at every one of 80 steps within 1e-10,
-    every kept mode's amplitude and the markers at the end"""
+def test_three_and_four_kept_modes_against_oracle(oracle_mod, amd, monkeypatch, modes, mname, mkw):
+    """the reference allows any input_nmode (src/pic1dp_input.F90:75-80).  With three and four kept modes
+    a step is the two passes (k_step_half + k_step_full; the prediction tiles built for them in round 4 measured slower,
+    profiles/r04/experiments/ab_kept_modes.log, and were retired in round 6) -- also when the tiles are asked for by name --
+    against the oracle directly: field energy at every one of 80 steps within 1e-10, the field and the markers at the end"""
     nm = len(modes)
     kw = dict(nparticle_max=N, nx=128, nmode=nm, modes=modes, init_nmode=nm, init_mode=modes,
               init_mode_cos=[0.0, 2e-6, 1e-6, 5e-7][:nm], init_mode_sin=[1e-5, 3e-6, 0.0, 2e-6][:nm], **mkw)
@@ -613,10 +612,8 @@ def test_one_pass_three_and_four_kept_modes_against_oracle(oracle_mod, amd, monk
     assert sim.load() == 0
     sim.collect_charge()
     sim.solve_field()
-    eng = engine(amd, monkeypatch, True, **kw)
-    assert eng.predict_kind() == 0           # the library's own choice: two passes measure faster from three kept modes on
     eng = engine(amd, monkeypatch, True, 1, **kw)
-    assert eng.predict_kind() == 1           # ... the one pass on request
+    assert eng.predict_kind() == 0           # no one-pass kernel for three and more kept modes, asked for or not
     eng.kernel_stats_enable(True)
     nsteps = 80
     eo = []
@@ -625,7 +622,7 @@ def test_one_pass_three_and_four_kept_modes_against_oracle(oracle_mod, amd, monk
         eo.append(sim.field_energy())
     eng.step(nsteps)
     assert np.max(np.abs(eng.energy_history() / np.array(eo) - 1.0)) < 1e-10
-    assert eng.kernel_stats(3)[1] == 1 and eng.kernel_stats(6)[1] == nsteps and eng.kernel_stats(4)[1] == 0
+    assert eng.kernel_stats(3)[1] == nsteps and eng.kernel_stats(4)[1] == nsteps and eng.kernel_stats(6)[1] == 0
     f = eng.get_field()
     so = sim.get_field()
     assert relerr(f["electric"], so[0]) < 1e-10
@@ -721,7 +718,7 @@ def test_call_sites_two_launches_per_step(oracle_mod, amd, monkeypatch, kind):
 
 @pytest.mark.parametrize("path", ["two_passes", "tiles", "tiles_two_modes"])
 @pytest.mark.parametrize("drawn", ["4", "16"])
-def test_chunks_drawn_in_the_other_whole_step_kernels(amd, monkeypatch, drawn, path):
+def test_chunks_drawn_in_the_other_whole_step_kernels(amd, monkeypatch, tuning, drawn, path):
     """the drawn chunk tail in k_step_half / k_step_full (two passes per step) and in the tiles' k_step_one, and in the
     diagnostics pass (k_ptcldist): every pair exactly once whoever takes it -- markers, energies and histograms against the
     same engine with every chunk dealt, to the order of the charge atomics"""
@@ -747,7 +744,7 @@ def test_chunks_drawn_in_the_other_whole_step_kernels(amd, monkeypatch, drawn, p
 
 
 @pytest.mark.parametrize("drawn", ["4", "16"])
-def test_chunks_drawn_from_the_lds_counter(oracle_mod, amd, monkeypatch, drawn):
+def test_chunks_drawn_from_the_lds_counter(oracle_mod, amd, monkeypatch, tuning, drawn):
     """tuning knob PIC1DP_DYN_TAIL: the last n/16 of a workgroup's 64-pair chunks are drawn by its
     waves from an LDS counter instead of dealt -- every pair exactly once whoever takes it: the run against the oracle
     (1e-10 at every step) and the markers against the default engine's (the same arithmetic per marker: only the order of

@@ -227,13 +227,16 @@ def fortran_host_exe():
     return exe
 
 
-@pytest.mark.parametrize("nranks,fused", [(2, "0"), (3, "2")], ids=["two_ranks_call_sites", "three_ranks_whole_step"])
+@pytest.mark.parametrize("nranks,fused", [(2, "0"), (3, "2"), (4, "0"), (4, "3")],
+                         ids=["two_ranks_call_sites", "three_ranks_whole_step", "four_ranks_call_sites", "four_ranks_steps_to_output"])
 def test_fortran_host_as_one_of_n_ranks(oracle_mod, amd, tmp_path, nranks, fused):
     """the reference is an MPI program (src/pic1dp.F90:43-52; `mpiexec -n 4`, run/Makefile:41): N processes of the
     shipped Fortran host -- rank / size from the environment, each owning its PETSC_DECIDE block, the charge
     summed by the library's one-hop exchange (here between processes sharing the box's one GPU), the exchange
     handles all-gathered and the diagnostics reduced to rank 0 through host_ranks.F90 (files standing in for the
-    MPI the image lacks) -- write on rank 0 the pic1dp.out of the N-rank oracle run"""
+    MPI the image lacks) -- write on rank 0 the pic1dp.out of the N-rank oracle run.  Four ranks: the reference's own launch
+    line (`NPE_RUN := 4`, Makefile:39) and the most this box admits with one process per rank (six processes on the card at
+    once, this test's own included; the eight-rank exchange runs as four processes of two ranks, test_gpu_exchange.py)"""
     exe = fortran_host_exe()
     from pic1dp_amd import output
     rdv = tmp_path / "rendezvous"

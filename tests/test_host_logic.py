@@ -377,3 +377,35 @@ def test_optimisation_planners_equal_the_routines_on_markers(probe, kind, typere
                 assert after > np_
             elif name != "merge_few" or np_ > 10000:
                 assert after < np_
+
+
+def test_environment_variables_of_the_product_library_are_the_documented_fifteen():
+    """the product library reads at most fifteen environment variables, each with a reason to exist in
+    INTEGRATION.md section 6; everything a measurement varies beyond them goes through tuning_env(), which only a
+    -DPIC1DP_TUNING build looks at (kernels.hpp), and is named in INTEGRATION.md and tools/README.md"""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "pic1dp_amd", "csrc")
+    product, tuning = set(), set()
+    for path in glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.hip")):
+        if os.path.basename(path) in ("probe.hip", "optcheck.cpp"):     # the probe library: measurement code by definition
+            continue
+        src = open(path).read()
+        product |= set(re.findall(r'std::getenv\("(PIC1DP_[A-Z0-9_]+)"\)', src))
+        tuning |= set(re.findall(r'tuning_env\("(PIC1DP_[A-Z0-9_]+)"\)', src))
+        assert not re.findall(r'(?<!std::)getenv\(', src.replace("tuning_env(", "")), path     # no third way to the environment
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 6. Environment variables of the library"):]
+    table = sec[:sec.index("**Tuning build**")]
+    documented = set()
+    for line in table.splitlines():
+        if line.startswith("| `PIC1DP_"):
+            documented |= set(re.findall(r"`(PIC1DP_[A-Z0-9_]+)`", line.split("|")[1]))
+    assert product == documented, (sorted(product - documented), sorted(documented - product))
+    assert len(product) <= 15, sorted(product)
+    tuning_doc = sec[sec.index("**Tuning build**"):sec.index("**Retired in round 6**")]
+    readme = open(os.path.join(ROOT, "tools", "README.md")).read()
+    for name in tuning:
+        assert "`%s`" % name in tuning_doc, name
+        assert name in readme, name
+    assert not (product & tuning)

@@ -10,9 +10,8 @@ echo "run $r $cfg nt off             : $(PIC1DP_NT_FORCE=0 q $cfg 200)"
 echo "run $r $cfg nt on              : $(PIC1DP_NT_FORCE=1 q $cfg 200)"
 echo "run $r $cfg rho global copies 8: $(PIC1DP_RHO_GLOBAL_COPIES=8 q $cfg 200)"
 echo "run $r $cfg rho global copies 1: $(PIC1DP_RHO_GLOBAL_COPIES=1 q $cfg 200)"
-echo "run $r $cfg rho lds copies 2   : $(PIC1DP_RHO_COPIES=2 q $cfg 200)"
 echo "run $r $cfg osub 2             : $(PIC1DP_OSUB=2 q $cfg 200)"
 echo "run $r $cfg osub 1             : $(PIC1DP_OSUB=1 q $cfg 200)"
 echo "run $r $cfg tiles              : $(PIC1DP_PRED_KIND=1 q $cfg 200)"
-echo "run $r $cfg register sums      : $(PIC1DP_PRED_PRIVATE=0 q $cfg 200)"
+echo "run $r $cfg register sums      : $(PIC1DP_PRED_KIND=3 q $cfg 200)"
 done; done

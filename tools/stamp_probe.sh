@@ -1,8 +1,8 @@
 #!/bin/bash
 # stamp_probe.sh [out dir] -- the fixed cost of the one-pass marker kernel, decomposed: per-workgroup wall-clock stamps of
-# ONE launch (a -DPIC1DP_TUNE_STAMPS build, pic1dp_amd/lib/v_stamps.so) at the small configurations and the strong-scaling
+# ONE launch (a -DPIC1DP_TUNING -DPIC1DP_TUNE_STAMPS build, pic1dp_amd/lib/v_stamps.so) at the small configurations and the strong-scaling
 # share, next to the launch's duration by HIP events in the default build.
-#   PIC1DP_EXTRA_FLAGS=-DPIC1DP_TUNE_STAMPS PIC1DP_LIB_OUT=pic1dp_amd/lib/v_stamps.so python pic1dp_amd/build.py --force
+#   PIC1DP_EXTRA_FLAGS="-DPIC1DP_TUNING -DPIC1DP_TUNE_STAMPS" PIC1DP_LIB_OUT=pic1dp_amd/lib/v_stamps.so python pic1dp_amd/build.py --force
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$R/gpurun_out/stamps}
 mkdir -p "$OUT"

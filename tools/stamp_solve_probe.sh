@@ -1,6 +1,6 @@
 #!/bin/bash
 # stamp_solve_probe.sh [out dir] -- the solve in the prologue, stage by stage (tools/stamp_solve_report.py), on a build
-#   PIC1DP_EXTRA_FLAGS="-DPIC1DP_TUNE_STAMPS -DPIC1DP_TUNE_STAMPS_SOLVE" PIC1DP_LIB_OUT=$PWD/pic1dp_amd/lib/v_stamps.so python pic1dp_amd/build.py --force
+#   PIC1DP_EXTRA_FLAGS="-DPIC1DP_TUNING -DPIC1DP_TUNE_STAMPS -DPIC1DP_TUNE_STAMPS_SOLVE" PIC1DP_LIB_OUT=$PWD/pic1dp_amd/lib/v_stamps.so python pic1dp_amd/build.py --force
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$R/gpurun_out/stamps_solve}
 mkdir -p "$OUT"
