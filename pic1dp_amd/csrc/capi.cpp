@@ -674,7 +674,8 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   HIP_TRY(hipSetDevice(c->device));
   if (int rc = materialize_cd(c)) return rc;  // deposits of the old markers are consumed, not mixed with the new ones
   HIP_TRY(hipStreamSynchronize(c->st));  // kernels of an earlier run may still be writing the arrays
-  c->lz = LZ_CLEAN;  // a noted push of markers that are about to be replaced is void
+  if (int rc = set_call_state(c, Seq::Clean, Owed::Nothing)) return rc;  // a noted push of markers that are about to be replaced is
+                                                                         // void, and so is a half-step field waiting to be adopted
   c->state_version++;
   const pic1dp_input &in = c->in;
   const int npe = c->lay.npe, ns = in.nspecies;
@@ -744,9 +745,9 @@ int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, con
   if (n != S.nalloc) return fail(PIC1DP_ERR_ARG, "n = %lld but this process owns %lld slots", (long long)n, (long long)S.nalloc);
   if (np < 0 || np > n) return fail(PIC1DP_ERR_ARG, "np out of range");
   HIP_TRY(hipSetDevice(c->device));
+  if (int rc = materialize_cd(c)) return rc;   // (first: what collect_charge left pending is settled before the sequence is left)
   if (c->loaded)
     if (int rc = materialize(c)) return rc;
-  if (int rc = materialize_cd(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   c->state_version++;
   // an upload (re)starts from set 0 for every species: slots beyond np live there
@@ -926,7 +927,7 @@ int pic1dp_hip_set_electric(pic1dp_ctx *c, const double *E) {
   if (!E) return fail(PIC1DP_ERR_ARG, "null array");
   HIP_TRY(hipSetDevice(c->device));
   if (int rc = settle_half_pair(c)) return rc;   // (d_E0 keeps the step-start field a noted push(1) saw)
-  if (c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2)
+  if (lz_of(c->seq) == LZ_PUSH1 || lz_of(c->seq) == LZ_PUSH2)
     if (int rc = materialize(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(c->d_E, E, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
@@ -939,10 +940,11 @@ int pic1dp_hip_set_chargeden(pic1dp_ctx *c, const double *cd) {
   if (!cd) return fail(PIC1DP_ERR_ARG, "null array");
   HIP_TRY(hipSetDevice(c->device));
   if (int rc = materialize_cd(c)) return rc;  // pending deposits are consumed, then overwritten
-  // a half-step field waiting to be adopted, or adopted as far as the host can tell but not yet copied (half_solved): memory
+  // a half-step field waiting to be adopted, or adopted as far as the host can tell but not yet copied (Seq::*PairSolved): memory
   // first becomes what the eager calls leave -- the adoption writes field_chargeden too --, then the host's vector rules
   if (int rc = settle_half_pair(c)) return rc;
-  if (c->cd_lazy == 5) c->cd_lazy = 0;
+  if (c->owed == Owed::AdoptHalfField)
+    if (int rc = set_owed(c, Owed::Nothing)) return rc;
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipMemcpy(c->d_chargeden, cd, sizeof(double) * c->in.nx, hipMemcpyHostToDevice));
   c->cd_kept_mode_only = false;

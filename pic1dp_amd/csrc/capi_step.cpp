@@ -116,18 +116,32 @@ static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer);
 // ---------------------------------------------------------------------------
 // field_chargeden (and d_charge, and zeroed accumulators) as collect_charge would have left them at once
 int pic1dp_host::materialize_cd(pic1dp_ctx *c) {
-  const int pending = c->cd_lazy;
-  if (pending == 5) return 0;  // (a half-step FIELD waiting to be adopted by solve_field, ctx.hpp half_pair: no charge to settle)
-  c->cd_lazy = 0;
-  if (pending == 0) return 0;
-  if (pending == 4) {  // the six sums of a predicted push(1): the kept mode's content of chargeden, directly
+  const Owed pending = c->owed;
+  if (pending == Owed::AdoptHalfField) return 0;  // (a half-step FIELD waiting to be adopted by solve_field: no charge to settle)
+  if (pending == Owed::Nothing) return 0;
+  if (int rc = set_owed(c, Owed::Nothing)) return rc;
+  if (pending == Owed::PredSums) {  // the six sums of a predicted push(1): the kept mode's content of chargeden, directly
     HIP_TRY(launch_pred_chargeden(c->fa, c->pred_tab, c->d_pred, nullptr, c->st));
     return 0;
   }
-  if (pending == 3) HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
-  HIP_TRY(launch_chargeden(c->fa, pending == 2, c->st));
+  if (pending == Owed::PredTiles) HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
+  HIP_TRY(launch_chargeden(c->fa, pending == Owed::SumScale, c->st));
   return 0;
 }
+
+// THE place the call sites' state is written: a pair that cannot occur (ctx.hpp kCallStateLegal) is an internal error
+// here, at the call that would have produced it, instead of a wrong field some calls later
+int pic1dp_host::set_call_state(pic1dp_ctx *c, Seq seq, Owed owed) {
+  if (seq >= Seq::N || owed >= Owed::N || !kCallStateLegal[static_cast<int>(seq)][static_cast<int>(owed)])
+    return fail(PIC1DP_ERR_STATE, "internal: call-site state (%d, %d) cannot occur (from (%d, %d))", static_cast<int>(seq),
+                static_cast<int>(owed), static_cast<int>(c->seq), static_cast<int>(c->owed));
+  if (seq != Seq::Clean && !c->lazy_calls) return fail(PIC1DP_ERR_STATE, "internal: a push noted by eager call sites");
+  c->seq = seq;
+  c->owed = owed;
+  return 0;
+}
+int pic1dp_host::set_seq(pic1dp_ctx *c, Seq seq) { return set_call_state(c, seq, c->owed); }
+int pic1dp_host::set_owed(pic1dp_ctx *c, Owed owed) { return set_call_state(c, c->seq, owed); }
 
 // checks only: for the call sites that take part in the lazy scheme themselves
 static int require_loaded_keep_lazy(pic1dp_ctx *c) {
@@ -176,27 +190,27 @@ static int enqueue_wrap_only(pic1dp_ctx *c) {
   return 0;
 }
 
-// Call sites (ctx.hpp half_pair): the half-step field the pair solve left in d_Ehn / d_mode_h, and the step-start
+// Call sites (ctx.hpp Seq, the Pair states): the half-step field the pair solve left in d_Ehn / d_mode_h, and the step-start
 // field still in field_electric, put where the eager calls would have them -- d_E0 <- E, and, once the host has called
 // solve_field for the half step, E <- the half-step field with its kept modes.  Everything that looks at the field, or
 // leaves the sequence push(1), collect_charge, solve_field, push(2), collect_charge, comes through here first.
 int pic1dp_host::settle_half_pair(pic1dp_ctx *c) {
-  if (!c->half_pair) return 0;
+  if (!pair_of(c->seq)) return 0;
   const size_t nx = c->in.nx;
   HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * nx, hipMemcpyDeviceToDevice, c->st));
-  const bool solved = c->half_solved;
-  c->half_pair = c->half_solved = false;
+  const bool solved = solved_of(c->seq);
+  if (int rc = set_seq(c, unpaired(c->seq))) return rc;
   // solve_field has been called for the half step: field_electric has to BE the half-step field now (field_version was
-  // bumped when it was called); not yet called: it stays pending (cd_lazy 5) and copies when it comes
+  // bumped when it was called); not yet called: it stays owed (AdoptHalfField) and copies when it comes
   if (solved) return adopt_half_field(c);
   return 0;
 }
 // for readers of the field only: nothing to do until the host has called solve_field for the half step -- until then
 // field_electric is the step-start field, which is what d_E holds
-int pic1dp_host::settle_field_view(pic1dp_ctx *c) { return c->half_pair && c->half_solved ? settle_half_pair(c) : 0; }
+int pic1dp_host::settle_field_view(pic1dp_ctx *c) { return solved_of(c->seq) ? settle_half_pair(c) : 0; }
 // field_electric and its kept modes <- the half-step field the pair solve left in d_Ehn / d_mode_h, and field_chargeden
 // <- the kept mode's content of the half-step charge density it left in d_cd_h (what collect_charge leaves there when it
-// is served from the six sums, cd_lazy 4): a solve_field that solves from field_chargeden again reproduces the half-step
+// is served from the six sums, Owed::PredSums): a solve_field that solves from field_chargeden again reproduces the half-step
 // field, as it does after eager calls
 int pic1dp_host::adopt_half_field(pic1dp_ctx *c) {
   const size_t nx = c->in.nx, nm = c->in.nmode;
@@ -209,9 +223,9 @@ int pic1dp_host::adopt_half_field(pic1dp_ctx *c) {
 
 int pic1dp_host::materialize(pic1dp_ctx *c) {
   if (int rc = settle_half_pair(c)) return rc;
-  const int lz = c->lz;
-  c->lz = LZ_CLEAN;
+  const int lz = lz_of(c->seq);
   if (lz == LZ_CLEAN) return 0;
+  if (int rc = set_seq(c, Seq::Clean)) return rc;
   if (lz == LZ_PUSH1) return enqueue_push(c, 1, false);           // the field has not changed since
   // LZ_HALF / LZ_PUSH2: push(1) saw d_E0; its deposit wrapped x
   if (int rc = enqueue_push(c, 1, false, c->d_E0)) return rc;
@@ -223,30 +237,26 @@ int pic1dp_host::materialize(pic1dp_ctx *c) {
 // the deposit of collect_charge / charge_local into the species accumulators:
 // the whole-step kernel of a noted push, or the plain wrap + deposit
 static int deposit_or_step(pic1dp_ctx *c) {
-  if (c->lz == LZ_PUSH1) {
+  if (c->seq == Seq::Push1) {
     HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
     if (int rc = step_particles(c, false, c->d_E, c->d_Eh)) return rc;
-    c->lz = LZ_HALF;
-    return 0;
+    return set_seq(c, Seq::Half);
   }
-  if (c->lz == LZ_PUSH2) {
-    if (c->half_pair && !c->half_solved)  // (push(2) without the solve_field of the half step: it sees the old field)
+  if (lz_of(c->seq) == LZ_PUSH2) {
+    if (c->seq == Seq::Push2Pair)  // (push(2) without the solve_field of the half step: it sees the old field)
       if (int rc = settle_half_pair(c)) return rc;
     c->state_version++;
     const bool diag = diag_in_step(c) && output_follows(c);
-    if (c->half_pair) {  // the half-step field came out of the previous step's pair solve (ctx.hpp): E0 is still in d_E
-      c->half_pair = c->half_solved = false;
+    if (c->seq == Seq::Push2PairSolved) {  // the half-step field came out of the previous step's pair solve: E0 is still in d_E
       std::swap(c->d_Eh, c->d_Ehn);
       c->eh_modes = 2;  // its kept mode: d_mode_h
       if (int rc = step_particles(c, true, c->d_E, c->d_Eh, diag, !diag)) return rc;
-      c->lz = LZ_CLEAN;
-      return 0;
+      return set_seq(c, Seq::Clean);
     }
     // Eh = d_E: the kept modes describe it when the mode-filter solve wrote it last
     c->eh_modes = (c->field_solver == 0 && c->modes_field_version == c->field_version) ? 1 : 0;
     if (int rc = step_particles(c, true, c->d_E0, c->d_E, diag, !diag)) return rc;
-    c->lz = LZ_CLEAN;
-    return 0;
+    return set_seq(c, Seq::Clean);
   }
   if (int rc = materialize(c)) return rc;
   return enqueue_deposit(c);
@@ -259,29 +269,27 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   // (step_particles); "collect charge" then covers the reduction and scaling only
   // after a noted push(1) whose charge the previous step's kernel has predicted (k_step_one): no
   // pass over the markers at all -- combine, reduce, scale
-  if (c->half_pair && !(c->lz == LZ_PUSH2 && c->half_solved))  // out of sequence: memory as the eager calls leave it
+  if (pair_of(c->seq) && c->seq != Seq::Push2PairSolved)  // out of sequence: memory as the eager calls leave it
     if (int rc = settle_half_pair(c)) return rc;
   // after a noted push(1) whose half-step FIELD the previous solve_field has already solved (the pair, below): nothing
   // to launch at all
   // (the six sums of one kept mode: with the tiles collect_charge owes the host the whole half-step charge density)
-  if (c->lz == LZ_PUSH1 && c->call_pair && c->lazy_calls && c->lay.nranks == 1 && c->comm == nullptr && predict_capable(c) &&
+  if (c->seq == Seq::Push1 && c->call_pair && c->lazy_calls && c->lay.nranks == 1 && c->comm == nullptr && predict_capable(c) &&
       c->pred_kind == 2 && c->in.nmode == 1 && c->eh_version == c->state_version && c->eh_field_version == c->field_version) {
-    c->lz = LZ_HALF;
-    c->half_pair = true;
-    c->half_solved = false;
-    c->cd_lazy = 5;               // what the solve_field that follows has to do: adopt the half-step field
     c->cd_kept_mode_only = true;  // (field_chargeden is not the half step's: asking for it rebuilds, get_field)
-    return 0;
+    return set_call_state(c, Seq::HalfPair, Owed::AdoptHalfField);  // what the solve_field that follows has to do: adopt the half-step field
   }
-  if (c->lz == LZ_PUSH1 && pred_usable(c)) {
+  if (c->seq == Seq::Push1 && pred_usable(c)) {
     HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
-    c->lz = LZ_HALF;
+    if (int rc = set_call_state(c, Seq::Half, Owed::Nothing)) return rc;   // (a stale AdoptHalfField ends here)
     Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
     if (int rc = pred_to_chargeden(c, c->fa, c->lazy_calls != 0)) return rc;
     return tm.end();
   }
   c->cd_kept_mode_only = false;  // a deposit follows: the whole vector again
-  const bool noted = c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2;
+  if (c->owed == Owed::AdoptHalfField)   // (left over by an inspection that settled a pair before its solve_field: void now)
+    if (int rc = set_owed(c, Owed::Nothing)) return rc;
+  const bool noted = lz_of(c->seq) == LZ_PUSH1 || lz_of(c->seq) == LZ_PUSH2;
   if (noted)
     if (int rc = deposit_or_step(c)) return rc;
   Span tm(c, PIC1DP_IWT_COLLECT_CHARGE, c->timers_on);
@@ -290,10 +298,11 @@ int pic1dp_hip_collect_charge(pic1dp_ctx *c) {
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (multi)
     if (int rc = reduce_charge(c)) return rc;
-  if (c->lazy_calls)  // the species sum (one rank) and the scaling: in the launch of the solve_field that follows
-    c->cd_lazy = multi ? 1 : 2;
-  else
+  if (c->lazy_calls) {  // the species sum (one rank) and the scaling: in the launch of the solve_field that follows
+    if (int rc = set_owed(c, multi ? Owed::Scale : Owed::SumScale)) return rc;
+  } else {
     HIP_TRY(launch_chargeden(c->fa, !multi, c->st));
+  }
   return tm.end();
 }
 
@@ -319,10 +328,10 @@ int pic1dp_hip_set_field_solver(pic1dp_ctx *c, int32_t kind) {
   if (kind != 0 && kind != 1) return fail(PIC1DP_ERR_ARG, "field solver must be 0 (reference mode filter) or 1 (finite differences)");
   if (kind == 1 && (c->in.nx < 3 || c->in.nx > 4096))
     return fail(PIC1DP_ERR_ARG, "the finite-difference solver needs 3 <= nx <= 4096");
-  if (c->cd_lazy == 5 && kind != c->field_solver) {  // a half-step field of the OTHER solver waits to be adopted (ctx.hpp
-    HIP_TRY(hipSetDevice(c->device));                // half_pair): the half-step charge is deposited for real instead
+  if (c->owed == Owed::AdoptHalfField && kind != c->field_solver) {  // a half-step field of the OTHER solver waits to be adopted:
+    HIP_TRY(hipSetDevice(c->device));                                // the half-step charge is deposited for real instead
     if (int rc = rebuild_half_step_chargeden(c)) return rc;
-    c->cd_lazy = 0;
+    if (int rc = set_owed(c, Owed::Nothing)) return rc;
   }
   c->field_solver = kind;
   return 0;
@@ -331,27 +340,24 @@ int pic1dp_hip_set_field_solver(pic1dp_ctx *c, int32_t kind) {
 int pic1dp_hip_solve_field(pic1dp_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(hipSetDevice(c->device));
-  if (c->half_pair) {
-    if (c->lz == LZ_HALF && !c->half_solved && c->cd_lazy == 5) {  // the half-step field is solved already (the pair below)
-      c->half_solved = true;
-      c->cd_lazy = 0;
-      c->call_pair_skips++;
-      field_written(c, true);  // from now on field_electric IS the half-step field, as far as anybody can tell
-      return 0;
-    }
-    if (int rc = settle_half_pair(c)) return rc;
+  if (c->seq == Seq::HalfPair) {  // the half-step field is solved already (the pair below): nothing to launch
+    if (int rc = set_call_state(c, Seq::HalfPairSolved, Owed::Nothing)) return rc;
+    c->call_pair_skips++;
+    field_written(c, true);  // from now on field_electric IS the half-step field, as far as anybody can tell
+    return 0;
   }
+  if (int rc = settle_half_pair(c)) return rc;
   // a noted push has to see the field of its own moment
-  if (c->lz == LZ_PUSH1 || c->lz == LZ_PUSH2)
+  if (lz_of(c->seq) == LZ_PUSH1 || lz_of(c->seq) == LZ_PUSH2)
     if (int rc = materialize(c)) return rc;
   Span tm(c, PIC1DP_IWT_FIELD_ELECTRIC, c->timers_on);
   FieldArgs f = c->fa;
-  const int pending = c->cd_lazy;  // what collect_charge left to this launch
-  c->cd_lazy = 0;
+  const Owed pending = c->owed;  // what collect_charge left to this launch
+  if (int rc = set_owed(c, Owed::Nothing)) return rc;
   // One rank, behind the collect_charge of push(2) whose kernel has predicted the next half-step charge: BOTH fields in
   // one launch, as pic1dp_hip_step solves them -- the next step's push(1), collect_charge, solve_field then launch nothing
   // and a time step through the three call sites is two launches (round 5; three and a copy before)
-  if (pending == 2 && c->call_pair && c->lazy_calls && c->field_solver == 0 && c->lz == LZ_CLEAN && pred_usable(c) &&
+  if (pending == Owed::SumScale && c->call_pair && c->lazy_calls && c->field_solver == 0 && c->seq == Seq::Clean && pred_usable(c) &&
       c->pred_kind == 2 && c->in.nmode == 1) {
     PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, 0};
     HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));
@@ -361,16 +367,16 @@ int pic1dp_hip_solve_field(pic1dp_ctx *c) {
     c->eh_field_version = c->field_version;
     return tm.end();
   }
-  if (pending == 5) {  // (the fast path above was left by an inspection in between: the field is adopted by copying)
+  if (pending == Owed::AdoptHalfField) {  // (the fast path above was left by an inspection in between: the field is adopted by copying)
     if (int rc = adopt_half_field(c)) return rc;
-  } else if (pending == 3 && c->field_solver == 0) {
+  } else if (pending == Owed::PredTiles && c->field_solver == 0) {
     HIP_TRY(launch_field_solve_pred(f, c->d_pred, c->in.nmode, c->st));
-  } else if (pending == 4 && c->field_solver == 0) {
+  } else if (pending == Owed::PredSums && c->field_solver == 0) {
     HIP_TRY(launch_field_solve_pred_sums(f, c->pred_tab, c->d_pred, c->st));
   } else {
-    if (pending == 4) HIP_TRY(launch_pred_chargeden(c->fa, c->pred_tab, c->d_pred, nullptr, c->st));
-    if (pending == 3) HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
-    if (int rc = enqueue_field_solve(c, f, pending == 2, pending == 0 || pending == 4)) return rc;
+    if (pending == Owed::PredSums) HIP_TRY(launch_pred_chargeden(c->fa, c->pred_tab, c->d_pred, nullptr, c->st));
+    if (pending == Owed::PredTiles) HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
+    if (int rc = enqueue_field_solve(c, f, pending == Owed::SumScale, pending == Owed::Nothing || pending == Owed::PredSums)) return rc;
   }
   field_written(c, true);
   return tm.end();
@@ -380,14 +386,8 @@ int pic1dp_hip_push(pic1dp_ctx *c, int32_t irk) {
   CHECK_CTX(c);
   if (irk != 1 && irk != 2) return fail(PIC1DP_ERR_ARG, "irk must be 1 or 2");
   if (int rc = require_loaded_keep_lazy(c)) return rc;
-  if (irk == 1 && c->lz == LZ_CLEAN && lazy_ok(c)) {
-    c->lz = LZ_PUSH1;
-    return 0;
-  }
-  if (irk == 2 && c->lz == LZ_HALF) {
-    c->lz = LZ_PUSH2;
-    return 0;
-  }
+  if (irk == 1 && c->seq == Seq::Clean && lazy_ok(c)) return set_seq(c, Seq::Push1);
+  if (irk == 2 && lz_of(c->seq) == LZ_HALF) return set_seq(c, push2_noted(c->seq));
   if (int rc = materialize(c)) return rc;
   return enqueue_push(c, irk, false);
 }
@@ -794,16 +794,14 @@ static int pred_reduce(pic1dp_ctx *c) {
 // prediction -> chargeden of the next first sub-step (f.chargeden: field_chargeden, or a scratch vector).
 // Tiles: combined locally, summed over ranks, scaled.  Six sums: summed over ranks, then the kept mode's
 // content of that charge density -- all the solve looks at (k_pred_chargeden).
-// defer (call sites, f = c->fa): leave the scaling of the summed charge to the solve_field that follows (cd_lazy)
+// defer (call sites, f = c->fa): leave the scaling of the summed charge to the solve_field that follows (Owed)
 static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer = false) {
   c->pred_version = 0;  // consumed: the accumulators are zero again afterwards
   const bool multi = c->lay.nranks > 1 || c->comm != nullptr;
   if (c->pred_kind == 2) {
     if (f.chargeden == c->d_chargeden) c->cd_kept_mode_only = true;
-    if (defer && !multi && c->field_solver == 0 && f.tab_lds) {
-      c->cd_lazy = 4;  // the sums' combination, chargeden and the solve in the launch of the solve_field that follows
-      return 0;
-    }
+    if (defer && !multi && c->field_solver == 0 && f.tab_lds)  // the sums' combination, chargeden and the solve in the
+      return set_owed(c, Owed::PredSums);                       // launch of the solve_field that follows
     if (!multi) {
       HIP_TRY(launch_pred_chargeden(f, c->pred_tab, c->d_pred, nullptr, c->st));
       return 0;
@@ -813,17 +811,13 @@ static int pred_to_chargeden(pic1dp_ctx *c, const FieldArgs &f, bool defer = fal
     HIP_TRY(launch_pred_chargeden(f, c->pred_tab, nullptr, c->d_charge, c->st));
     return 0;
   }
-  if (defer && !multi && c->field_solver == 0 && 2 * c->in.nmode <= 256) {
-    c->cd_lazy = 3;  // all of it in the launch of the solve_field that follows
-    return 0;
-  }
+  if (defer && !multi && c->field_solver == 0 && 2 * c->in.nmode <= 256)
+    return set_owed(c, Owed::PredTiles);  // all of it in the launch of the solve_field that follows
   HIP_TRY(launch_pred_combine(c->fa, c->d_pred, c->in.nmode, c->st));
   if (multi)
     if (int rc = pred_reduce(c)) return rc;
-  if (defer)
-    c->cd_lazy = 1;
-  else
-    HIP_TRY(launch_chargeden(f, false, c->st));
+  if (defer) return set_owed(c, Owed::Scale);
+  HIP_TRY(launch_chargeden(f, false, c->st));
   return 0;
 }
 
@@ -1031,25 +1025,20 @@ int pic1dp_hip_check_state(pic1dp_ctx *c, int32_t deep) {
 #define INVARIANT(cond)                                                                                   \
   do {                                                                                                    \
     if (!(cond))                                                                                          \
-      return fail(PIC1DP_ERR_STATE, "state invariant violated: %s (lz %d cd_lazy %d half_pair %d half_solved %d)", #cond, \
-                  c->lz, c->cd_lazy, int(c->half_pair), int(c->half_solved));                             \
+      return fail(PIC1DP_ERR_STATE, "state invariant violated: %s (call-site state %d, owed %d)", #cond, \
+                  static_cast<int>(c->seq), static_cast<int>(c->owed));                                   \
   } while (0)
+  // The call sites' state is one (Seq, Owed) pair written by set_call_state alone, which refuses the pairs that cannot
+  // occur (ctx.hpp kCallStateLegal): what used to be a dozen relations between lz, cd_lazy, half_pair and half_solved
+  // checked here cannot be violated any more.  What is left relates the state to the CONTEXT it is held in:
   const bool one_rank = c->lay.nranks == 1 && c->comm == nullptr;
-  INVARIANT(c->lz >= LZ_CLEAN && c->lz <= LZ_PUSH2);
-  INVARIANT(c->lz == LZ_CLEAN || c->lazy_calls);                     // a push is only noted by the lazy call sites
-  INVARIANT(c->lz == LZ_CLEAN || c->loaded);
-  INVARIANT(c->cd_lazy >= 0 && c->cd_lazy <= 5);
-  INVARIANT(c->cd_lazy == 0 || c->lazy_calls);
-  INVARIANT(c->cd_lazy < 2 || one_rank);                             // species sum / prediction left to solve_field: one rank
-  INVARIANT(c->cd_lazy != 3 || c->pred_kind == 1);                   // tiles to combine
-  INVARIANT(c->cd_lazy != 4 || c->pred_kind == 2);                   // six sums to turn into the kept mode's chargeden
-  // the call sites' pair (ctx.hpp half_pair)
-  INVARIANT(!c->half_solved || c->half_pair);
-  INVARIANT(!c->half_pair || (c->lz == LZ_HALF || c->lz == LZ_PUSH2));
-  INVARIANT(!c->half_pair || (one_rank && c->call_pair && c->pred_kind == 2 && c->in.nmode == 1));
-  // (5 outlives half_pair when an inspection settles before solve_field has been called: the field is then adopted by copying)
-  INVARIANT(c->cd_lazy != 5 || (!c->half_solved && c->pred_kind == 2 && c->in.nmode == 1));
-  INVARIANT(!c->half_pair || (c->eh_version == c->state_version));   // the field in d_Ehn belongs to the state in memory
+  INVARIANT(kCallStateLegal[static_cast<int>(c->seq)][static_cast<int>(c->owed)]);
+  INVARIANT(c->seq == Seq::Clean || (c->lazy_calls && c->loaded));    // a push is only noted by the lazy call sites
+  INVARIANT(c->owed == Owed::Nothing || c->lazy_calls);
+  INVARIANT(c->owed < Owed::SumScale || one_rank);                    // species sum / prediction left to solve_field: one rank
+  INVARIANT(c->owed != Owed::PredTiles || c->pred_kind == 1);
+  INVARIANT((c->owed != Owed::PredSums && c->owed != Owed::AdoptHalfField && !pair_of(c->seq)) || (c->pred_kind == 2 && c->in.nmode == 1));
+  INVARIANT(!pair_of(c->seq) || (c->call_pair && c->eh_version == c->state_version));   // the field in d_Ehn belongs to the state in memory
   INVARIANT(!c->cd_kept_mode_only || c->pred_kind == 2);
   // whole-step path: nothing of a step() is left over between calls
   INVARIANT(!c->fused_pending);
@@ -1075,7 +1064,7 @@ int pic1dp_hip_check_state(pic1dp_ctx *c, int32_t deep) {
   HIP_TRY(hipMemcpy(&ticket, c->d_ticket, sizeof ticket, hipMemcpyDeviceToHost));
   INVARIANT(ticket == 0u);
   // accumulators: the sets the marker kernels do not deposit into are zero; the current one holds something only while
-  // a collect_charge has left its end to solve_field (cd_lazy 2, 3: deposits; with a usable prediction: the six sums / tiles)
+  // a collect_charge has left its end to solve_field (Owed::SumScale, PredTiles: deposits; with a usable prediction: the six sums / tiles)
   auto nonzero = [](const std::vector<double> &v, size_t off, size_t n) {
     for (size_t i = 0; i < n; ++i)
       if (v[off + i] != 0.0) return true;  // (NaN != 0: a poisoned accumulator counts)
@@ -1086,7 +1075,7 @@ int pic1dp_hip_check_state(pic1dp_ctx *c, int32_t deep) {
   for (int k = 0; k < 3; ++k) {
     const bool nz = nonzero(h, k * c->rho_set_doubles, c->rho_set_doubles);
     if (k != c->acc_idx) INVARIANT(!nz && "a species accumulator set that is not the current one holds deposits");
-    else if (c->cd_lazy != 2 && c->cd_lazy != 3 && !c->charge_pending) INVARIANT(!nz && "deposits nobody is going to sum");
+    else if (c->owed != Owed::SumScale && c->owed != Owed::PredTiles && !c->charge_pending) INVARIANT(!nz && "deposits nobody is going to sum");
   }
   if (c->d_pred_all && c->pred_set_doubles) {
     h.assign(3 * c->pred_set_doubles, 0.0);
@@ -1094,7 +1083,7 @@ int pic1dp_hip_check_state(pic1dp_ctx *c, int32_t deep) {
     for (int k = 0; k < 3; ++k) {
       const bool nz = nonzero(h, k * c->pred_set_doubles, c->pred_set_doubles);
       if (k != c->acc_idx) INVARIANT(!nz && "a prediction accumulator set that is not the current one holds sums");
-      else if (c->pred_version == 0 && c->cd_lazy != 3 && c->cd_lazy != 4 && !c->charge_pending)
+      else if (c->pred_version == 0 && c->owed != Owed::PredTiles && c->owed != Owed::PredSums && !c->charge_pending)
         INVARIANT(!nz && "prediction sums that belong to no state");
     }
   }
@@ -1134,17 +1123,17 @@ int pic1dp_host::rebuild_half_step_chargeden(pic1dp_ctx *c) {
   // markers have left the half-step state through calls outside the sequence, chargeden keeps the kept mode's
   // content and pic1dp_hip_chargeden_state says so
   if (c->lay.nranks > 1 || c->comm != nullptr) return 0;
-  if (c->lz != LZ_HALF && c->lz != LZ_PUSH2) return 0;
+  if (lz_of(c->seq) != LZ_HALF && lz_of(c->seq) != LZ_PUSH2) return 0;
   if (int rc = settle_half_pair(c)) return rc;
-  const bool push2_noted = c->lz == LZ_PUSH2;
+  const bool push2_was_noted = lz_of(c->seq) == LZ_PUSH2;
   if (int rc = enqueue_push(c, 1, false, c->d_E0)) return rc;
-  c->lz = LZ_CLEAN;  // memory now holds the half-step state (x not yet wrapped): the deposit wraps and stores it
+  if (int rc = set_seq(c, Seq::Clean)) return rc;  // memory now holds the half-step state (x not yet wrapped): the deposit wraps and stores it
   if (int rc = enqueue_deposit(c)) return rc;
   HIP_TRY(launch_chargeden(c->fa, true, c->st));
   c->cd_kept_mode_only = false;
   // a push(2) that had been noted: memory as the eager calls would have left it (the field it sees, d_E, is the one
   // solve_field wrote after the half step)
-  if (push2_noted)
+  if (push2_was_noted)
     if (int rc = enqueue_push(c, 2, false)) return rc;
   return 0;
 }
@@ -1156,9 +1145,11 @@ int pic1dp_hip_charge_local(pic1dp_ctx *c, double *charge2) {
   CHECK_CTX(c);
   if (!charge2) return fail(PIC1DP_ERR_ARG, "null array");
   if (int rc = require_loaded_keep_lazy(c)) return rc;
-  if (c->lz == LZ_PUSH1 && pred_usable(c)) {  // predicted by the previous step's kernel: no marker pass
+  if (c->owed == Owed::AdoptHalfField)   // (left over by an inspection that settled a pair before its solve_field: void now)
+    if (int rc = set_owed(c, Owed::Nothing)) return rc;
+  if (c->seq == Seq::Push1 && pred_usable(c)) {  // predicted by the previous step's kernel: no marker pass
     HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));
-    c->lz = LZ_HALF;
+    if (int rc = set_seq(c, Seq::Half)) return rc;
     if (c->pred_kind == 2) {  // the six sums in charge2[0..5], zeros behind: the host's sum over ranks sums them
       HIP_TRY(launch_pred_to_charge(c->fa, c->d_pred, c->st));
       c->charge_pending_pred = true;
@@ -1190,10 +1181,8 @@ int pic1dp_hip_charge_reduced(pic1dp_ctx *c, const double *charge1) {
     HIP_TRY(launch_pred_chargeden(c->fa, c->pred_tab, nullptr, c->d_charge, c->st));
     return 0;
   }
-  if (c->lazy_calls)
-    c->cd_lazy = 1;
-  else
-    HIP_TRY(launch_chargeden(c->fa, false, c->st));
+  if (c->lazy_calls) return set_owed(c, Owed::Scale);
+  HIP_TRY(launch_chargeden(c->fa, false, c->st));
   return 0;
 }
 

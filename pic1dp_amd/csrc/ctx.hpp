@@ -53,7 +53,61 @@ constexpr bool kCarryOneExpDefault = false;  // k_step_one with the one-exp form
 constexpr int kEnergyBlocks = 1024;
 constexpr size_t kCuLds = 160 * 1024, kStaticLds = 1024;  // LDS of a CU; static LDS of a marker kernel (the exp table)
 // states of the lazy call sites (pic1dp_ctx::lz)
-enum { LZ_CLEAN = 0, LZ_PUSH1, LZ_HALF, LZ_PUSH2 };
+// ---------------------------------------------------------------------------
+// The call sites' state (capi_step.cpp "lazy call sites").  Two variables, each an enum, and a table of
+// the pairs that can occur -- until round 6 this was lz, half_pair, half_solved and cd_lazy, 4 x 2 x 2 x 6 combinations of
+// which 18 are legal, policed from outside by pic1dp_hip_check_state; now an illegal one cannot be stored (set_call_state).
+//
+// Seq: where the host stands in the reference's sequence push(1), collect_charge, solve_field, push(2), collect_charge,
+// solve_field of a time step (src/pic1dp.F90:79-90), and -- the "Pair" states, one rank, six sums -- whether the half
+// step is being served from the PREVIOUS step's pair solve: the half-step field then lies in d_Ehn / d_mode_h,
+// field_electric still holds the step-start field, d_E0 is not filled.
+enum class Seq : uint8_t {
+  Clean,            // memory is what eager calls would have left; nothing noted
+  Push1,            // push(1) noted
+  Half,             // ... and its collect_charge served (k_step_half ran, or the prediction was taken); the half-step markers are not in memory
+  HalfPair,         // Half, served from the pair solve: nothing was launched; the host has not yet called solve_field for the half step
+  HalfPairSolved,   // ... and now it has: what it may SEE from here on is the half-step field (every reader settles first)
+  Push2,            // push(2) noted after Half
+  Push2Pair,        // push(2) noted after HalfPair (the host skipped the half step's solve_field: it pushes with the old field)
+  Push2PairSolved,  // push(2) noted after HalfPairSolved: the next collect_charge runs k_step_one with E0 = field_electric, Eh = d_Ehn
+  N
+};
+// Owed: what collect_charge has left to the launch of the solve_field that follows (one launch less per sub-step)
+enum class Owed : uint8_t {
+  Nothing,         // field_chargeden is current
+  Scale,           // d_charge holds the summed charge1: the scaling into chargeden
+  SumScale,        // (one rank) the species accumulators hold the deposits: species sum + scaling -- with a usable six-sum prediction: the pair solve
+  PredTiles,       // (one rank, tiles) the prediction accumulators hold the half-step charge as coefficients: combine + sum + scale
+  PredSums,        // (one rank, six sums) the kept mode's content of chargeden follows from the six sums
+  AdoptHalfField,  // nothing to launch: field_electric / its kept mode / chargeden <- what the pair solve left in d_Ehn / d_mode_h / d_cd_h
+  N
+};
+enum { LZ_CLEAN = 0, LZ_PUSH1, LZ_HALF, LZ_PUSH2 };   // the four positions of the sequence (Seq without the pair's colours)
+constexpr int lz_of(Seq s) {
+  return s == Seq::Clean ? LZ_CLEAN : s == Seq::Push1 ? LZ_PUSH1 : (s == Seq::Half || s == Seq::HalfPair || s == Seq::HalfPairSolved) ? LZ_HALF : LZ_PUSH2;
+}
+constexpr bool pair_of(Seq s) { return s == Seq::HalfPair || s == Seq::HalfPairSolved || s == Seq::Push2Pair || s == Seq::Push2PairSolved; }
+constexpr bool solved_of(Seq s) { return s == Seq::HalfPairSolved || s == Seq::Push2PairSolved; }
+// the same position with the pair settled (settle_half_pair: memory as the eager calls leave it)
+constexpr Seq unpaired(Seq s) { return lz_of(s) == LZ_HALF ? Seq::Half : lz_of(s) == LZ_PUSH2 ? Seq::Push2 : s; }
+// push(2) noted at a half step
+constexpr Seq push2_noted(Seq s) { return s == Seq::HalfPair ? Seq::Push2Pair : s == Seq::HalfPairSolved ? Seq::Push2PairSolved : Seq::Push2; }
+// Which (Seq, Owed) pairs occur.  Scale / SumScale: right behind a collect_charge (every other call that looks at charge
+// or markers settles them first, materialize_cd).  PredTiles / PredSums: behind the collect_charge of a noted push(1).
+// AdoptHalfField is set with HalfPair and outlives it when an inspection settles the pair before solve_field came (the
+// field is then adopted by copying); it ends with the solve_field of the half step, hence never with a Solved state.
+constexpr bool kCallStateLegal[static_cast<int>(Seq::N)][static_cast<int>(Owed::N)] = {
+    //                   Nothing Scale  SumScale PredTiles PredSums Adopt
+    /* Clean           */ {true, true,  true,    false,    false,   true},
+    /* Push1           */ {true, false, false,   false,    false,   true},
+    /* Half            */ {true, true,  true,    true,     true,    true},
+    /* HalfPair        */ {false, false, false,  false,    false,   true},
+    /* HalfPairSolved  */ {true, false, false,   false,    false,   false},
+    /* Push2           */ {true, false, false,   false,    false,   true},
+    /* Push2Pair       */ {false, false, false,  false,    false,   true},
+    /* Push2PairSolved */ {true, false, false,   false,    false,   false},
+};
 
 struct Species {
   int64_t nalloc = 0, np = 0;
@@ -137,13 +191,12 @@ struct pic1dp_ctx {
   int lazy_calls = 1;            // PIC1DP_LAZY_CALLS=0: every call launches its own kernel at once
   // Call sites, one rank: the solve_field that follows the collect_charge of push(2) solves BOTH fields in one launch
   // (the pair kernels of pic1dp_hip_step) -- the new state's into field_electric, the next step's half-step field from the
-  // prediction into d_Ehn / d_mode_h.  The next push(1) / collect_charge / solve_field then launch nothing: half_pair says
-  // that the half-step field lies in d_Ehn (field_electric still holds the step-start field, d_E0 is not filled),
-  // half_solved that the host has called solve_field for it -- what it may look at from then on is the half-step field,
-  // so every inspection first settles (capi_step.cpp settle_half_pair: copies, memory as the eager calls leave it).
+  // prediction into d_Ehn / d_mode_h.  The next push(1) / collect_charge / solve_field then launch nothing: the
+  // "Pair" states of Seq say that the half-step field lies in d_Ehn (field_electric still holds the step-start field, d_E0 is
+  // not filled), the "Solved" ones that the host has called solve_field for it -- what it may look at from then on is the
+  // half-step field, so every inspection first settles (capi_step.cpp settle_half_pair: copies, memory as eager calls leave it).
   // PIC1DP_CALL_PAIR=0: the three launches per step of rounds 2-4.
   int call_pair = 1;
-  bool half_pair = false, half_solved = false;
   int64_t call_pair_skips = 0;   // solve_field calls of a half step served without a launch (kernel_stats 11)
   // collect_charge leaves its last step to the solve_field that follows (one launch less per sub-step):
   // 0 field_chargeden is current; 1 d_charge holds the summed charge1, its scaling is pending; 2 (one rank) the
@@ -152,13 +205,13 @@ struct pic1dp_ctx {
   // scaling pending; 4 (one rank, mode-filter solve) the six sums of the prediction are pending: the kept mode's
   // content of chargeden follows from them.  materialize_cd() before anything else looks at charge, chargeden or the
   // accumulators.
-  int cd_lazy = 0;
+  Owed owed = Owed::Nothing;
   // field_chargeden holds only the kept mode's content of the half-step charge density (collect_charge after a
   // noted push(1) served from the six sums, pred_kind 2): all solve_field looks at, but not what the reference
   // holds there.  get_field rebuilds the full vector on one rank (rebuild_half_step_chargeden); cleared by
   // everything that writes field_chargeden.
   bool cd_kept_mode_only = false;
-  int lz = 0;                    // LZ_CLEAN / LZ_PUSH1 / LZ_HALF / LZ_PUSH2
+  Seq seq = Seq::Clean;          // written by set_call_state only (capi_step.cpp)
   double *d_E0 = nullptr;        // field the noted push(1) saw
   double *d_rho_dummy = nullptr; // accumulator of a wrap-only deposit
   int carry = -1;          // whole-step kernels carry -f0'/f0 between them: -1 where measured to pay, 0 never
@@ -339,6 +392,9 @@ bool xchg_active(const pic1dp_ctx *c);
 XchgArgs next_xchg_args(pic1dp_ctx *c);
 int xchg_check(pic1dp_ctx *c);
 void comm_release(pic1dp_ctx *c);         // communicator and exchange mappings, for destroy
+int set_call_state(pic1dp_ctx *c, Seq seq, Owed owed);  // the one writer of the call sites' state: refuses pairs that cannot occur
+int set_seq(pic1dp_ctx *c, Seq seq);
+int set_owed(pic1dp_ctx *c, Owed owed);
 int settle_half_pair(pic1dp_ctx *c);      // call sites: the half-step field the pair solve left aside becomes field_electric (ctx.hpp half_pair)
 int settle_field_view(pic1dp_ctx *c);     // ... for readers of the field only
 int adopt_half_field(pic1dp_ctx *c);
