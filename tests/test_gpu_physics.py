@@ -30,36 +30,82 @@ def run(amd, nsteps, **kw):
     return t, e, eng
 
 
-def test_bump_on_tail_growth_rate(amd):
-    """default input, 10^7 markers, nx 256 (BASELINE configs[1]): 2 gamma = 0.16766"""
-    t, e, eng = run(amd, 1000, nparticle_max=10**7, nx=256)
-    g2 = fit_rate(t, e, 15.0, 45.0)
-    assert abs(g2 / 0.16766 - 1.0) < 0.02, g2
-    # the perturbation started at (1e-5/k)^2 lx/2 and has grown by orders of magnitude
-    assert e[-1] > 50 * e[0]
+def ensemble_tool():
+    """tools/physics_ensemble.py: the cases, their Vlasov roots, the model fits (one statement of them for the tool and the test)"""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("physics_ensemble", os.path.join(ROOT, "tools", "physics_ensemble.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
-def test_two_stream_growth_rate(amd):
-    """two-stream2 with v0 = 3 (BASELINE configs[3] physics): purely growing mode,
-    2 gamma = 0.30505"""
-    t, e, eng = run(amd, 700, nparticle_max=10**7, nx=512, iptcldist=2, species_density=[1.0], species_v0=[3.0])
-    g2 = fit_rate(t, e, 12.0, 28.0)
-    assert abs(g2 / 0.30505 - 1.0) < 0.03, g2
+@pytest.mark.parametrize("case", ["bump", "two_stream", "landau"])
+def test_growth_rates_ensemble(amd, case):
+    """VERDICT r05 item 3 -- the only outside evidence the unpinned half of the oracle can get: the linear rates of the three
+    BASELINE.md cases at 10^8 markers as an ENSEMBLE of eight runs over RNG streams (pic1dp_hip_set_seed_offset; the
+    reference's own method with seed_type 2 / 3, tools/runinfo.py:94-122,136-231), each fitted with the model of what the
+    perturbation excites (tools/physics_ensemble.py), mean +- sigma against the root of the Vlasov dispersion relation
+    (tools/dispersion.py:130-157's function; for bump-on-tail with f0 cut at v_max as the loader cuts it,
+    src/pic1dp_particle.F90:180-181: +0.19 % on the rate, twice sigma -- it shows).  At the reference's dt = 0.05 the
+    second-order scheme sits 0.06-0.11 % below its dt -> 0 limit (measured: dt and dt / 2 on the same seeds, Richardson,
+    profiles/r06/experiments/physics_ensemble_refit.log), which is part of the expectation:
+        sigma / |2 gamma| < 0.25 %   (round 5 tested ONE run of 10^7 markers to 2 / 3 / 5 %)
+        |mean - (theory + time-step shift)| < 3 sigma_mean
+        |mean - theory| < 3 sigma
+    Seeds are fixed: the outcome is deterministic (16 members measured: bump +0.050 %, two-stream +0.021 %, Landau -0.035 %
+    of the dt -> 0 limit against theory, 2.1 / 0.7 / 0.8 sigma_mean)."""
+    pe = ensemble_tool()
+    lines = []
+    r = pe.ensemble(amd, case, 1e8, 0.05, 8, log=lines.append)
+    print("\n".join(lines))
+    th = r["theory"]
+    expected = th + pe.DT2_SHIFT[case] * abs(th)
+    assert r["sigma"] / abs(th) < 0.0025, r
+    assert abs(r["mean"] - expected) < 3.0 * r["sem"], (r["mean"], expected, r["sem"])
+    assert abs(r["mean"] - th) < 3.0 * r["sigma"], (r["mean"], th, r["sigma"])
+    assert r["rms"] < 0.004                    # the model describes the series: 0.02-0.2 % rms residual at this marker count
+    if case == "landau":                       # ... and the real frequency, omega_r = 1.41566
+        om_expected = r["omega_theory"] * (1.0 + pe.DT2_SHIFT_OMEGA_LANDAU)
+        assert abs(r["omega_mean"] - om_expected) < 3.0 * r["omega_sigma"] / np.sqrt(r["members"]), r
+        assert abs(r["omega_mean"] / r["omega_theory"] - 1.0) < 3e-4
 
 
-def test_landau_damping_rate(amd):
-    """Maxwellian, k = 0.5 (lx = 4 pi), linear delta-f (BASELINE configs[4] physics):
-    field energy decays with 2 gamma = -0.30672 while oscillating at 2 omega"""
-    t, e, eng = run(amd, 400, nparticle_max=10**7, nx=1024, iptcldist=0, species_density=[1.0],
-                    species_v0=[0.0], lx=4 * np.pi, linear=1)
-    # fit through the maxima of the oscillating energy
-    pk = [i for i in range(1, len(e) - 1) if e[i] > e[i - 1] and e[i] > e[i + 1] and 1.0 < t[i] < 16.0]
-    assert len(pk) >= 5
-    slope = np.polyfit(t[pk], np.log(e[pk]), 1)[0]
-    assert abs(slope / -0.30672 - 1.0) < 0.05, slope
-    # oscillation of E^2 at 2 omega_r, omega_r = 1.41566
-    period = np.mean(np.diff(t[pk]))
-    assert abs(period / (np.pi / 1.41566) - 1.0) < 0.03, period
+def test_oracle_growth_rate_agrees_with_theory_and_with_the_gpu(oracle_mod, amd):
+    """... and the oracle itself at the largest size it runs in about half a minute on the box's cores (bump-on-tail, 10^7
+    markers, 16 reference ranks, t <= 46): its fitted rate against the same theory -- within three sigma of ONE run of that
+    size, sigma from the ensemble's sigma at 10^8 markers times sqrt(10) (0.30 % of 2 gamma) -- and against the GPU run of the
+    same input, whose fit must agree with the oracle's far inside that (the two follow each other to ~1e-9 through the
+    linear phase): both agree with theory, not only with each other"""
+    pe = ensemble_tool()
+    kw = dict(nparticle_max=10**7, **pe.CASES["bump"]["kw"])
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw), npe=16, nthreads=16)
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    nsteps = 920
+    eo = [sim.field_energy()]
+    for _ in range(nsteps):
+        sim.step(1)
+        eo.append(sim.field_energy())
+    eng = amd.Pic1dp(amd.make_input(**kw), npe=16)
+    eng.particle_load()
+    eng.interaction_collect_charge()
+    eng.field_solve_electric()
+    e0 = eng.field_energy()
+    eng.step(nsteps)
+    eg = np.concatenate([[e0], eng.energy_history()])
+    eo = np.array(eo)
+    t = np.arange(nsteps + 1) * 0.05
+    go, gg = pe.fit_case("bump", t, eo)[0], pe.fit_case("bump", t, eg)[0]
+    th = pe.CASES["bump"]["two_gamma"]
+    expected = th + pe.DT2_SHIFT["bump"] * abs(th)
+    sigma_1e7 = 0.00095 * np.sqrt(10.0) * abs(th)
+    print("oracle 2 gamma %.6f, GPU %.6f, theory (cut f0, dt = 0.05) %.6f; sigma of one run of 1e7 markers %.6f" % (go, gg, expected, sigma_1e7))
+    assert abs(go - expected) < 3.0 * sigma_1e7
+    assert abs(gg - go) < 1e-6 * abs(go)
+    assert np.max(np.abs(eg[:400] / eo[:400] - 1.0)) < 1e-10
 
 
 def test_long_run_through_saturation(oracle_mod, amd):

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import DIST_CASES
+from conftest import DIST_CASES, ROOT
 
 PI = 3.14159265358979323846264
 
@@ -310,3 +310,27 @@ def test_oracle_series_fixture(oracle_mod):
         want = np.array([float.fromhex(h) for h in case["energy_hex"]])
         # libm may differ between images in the last bit of exp/sin: allow 1e-12
         assert np.max(np.abs(np.array(e) / want - 1.0)) < 1e-12
+
+
+def test_vlasov_roots_used_as_physics_anchors():
+    """the theory values tests/test_gpu_physics.py::test_growth_rates_ensemble holds the runs against are roots of the
+    electrostatic Vlasov dispersion function (the reference's tools/dispersion.py:130-157 solves the same function; the values
+    of BASELINE.md came from it), recomputed here by this repository's own statement of it -- and, for bump-on-tail, with f0
+    cut at |v| = v_max = 8 as the loader cuts it (src/pic1dp_particle.F90:180-181): the beam at v0 = 5 loses its tail beyond
+    three sigma and the growth rate moves by +0.19 %, twice what an ensemble of 1e8-marker runs resolves"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("physics_ensemble", os.path.join(ROOT, "tools", "physics_ensemble.py"))
+    pe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pe)
+    b, t, la = pe.CASES["bump"], pe.CASES["two_stream"], pe.CASES["landau"]
+    w = pe.vlasov_root(b["species"], b["k"], 1.17 + 0.08j)                       # BASELINE.md: 1.1693765077 + 0.0838310511 i
+    assert abs(w - (1.1693765077 + 0.0838310511j)) < 1e-9 and abs(2 * w.imag - b["two_gamma_uncut"]) < 1e-9
+    wc = pe.vlasov_root(b["species"], b["k"], 1.17 + 0.08j, vmax=pe.V_MAX)
+    assert abs(2 * wc.imag - b["two_gamma"]) < 2e-9 and abs(wc.real - b["omega"]) < 2e-9
+    assert 0.0018 < 2 * wc.imag / (2 * w.imag) - 1.0 < 0.0019                    # what the cut is worth
+    w = pe.vlasov_root(t["species"], t["k"], 0.0 + 0.15j)                        # BASELINE.md: 0 + 0.1525251736 i
+    assert abs(w.real) < 1e-9 and abs(2 * w.imag - t["two_gamma"]) < 1e-9
+    wc = pe.vlasov_root(t["species"], t["k"], 0.0 + 0.15j, vmax=pe.V_MAX)        # beams at +-3: the cut is five sigma away
+    assert abs(wc.imag / w.imag - 1.0) < 2e-5
+    w = pe.vlasov_root(la["species"], la["k"], 1.4 - 0.15j)                      # BASELINE.md: 1.4156618886 - 0.1533594669 i
+    assert abs(w.real - la["omega"]) < 1e-9 and abs(2 * w.imag - la["two_gamma"]) < 1e-9

@@ -2,19 +2,32 @@
 """physics_ensemble.py -- round 6: the linear growth / damping rates of the three BASELINE.md physics
 anchors at 10^8 markers as an ENSEMBLE over RNG streams (pic1dp_hip_set_seed_offset: member m loads reference block b from
 stream mype = b + 16 m; the reference compares runs with different seeds the same way, tools/runinfo.py:94-122,136-231),
-mean +- sigma against the roots of the Vlasov dispersion relation (tools/dispersion.py:130-157):
+mean +- sigma against the roots of the Vlasov dispersion relation (the reference's tools/dispersion.py:130-157 solves the
+same function; vlasov_root() below is this repository's own statement of it, with one addition):
 
-    bump-on-tail  2 gamma = +0.16766      (omega = 1.1693765077 + 0.0838310511 i, k = 0.36)
-    two-stream    2 gamma = +0.30505      (omega = 0 + 0.1525251736 i, v0 = 3, k = 0.36)
-    Landau        2 gamma = -0.30672, omega_r = 1.41566   (omega = 1.4156618886 - 0.1533594669 i, k = 0.5)
+    bump-on-tail  2 gamma = +0.1679723    omega = 1.1695176 + 0.0839862 i, k = 0.36, f0 CUT at |v| = v_max = 8
+                            (+0.1676621 without the cut: the loader places markers in [-v_max, v_max) only,
+                             src/pic1dp_particle.F90:180-181, and the beam at v0 = 5, T = 1 loses its tail beyond 3 sigma --
+                             0.19 % of the rate, twice the ensemble's sigma at 1e8 markers: it shows)
+    two-stream    2 gamma = +0.3050503    omega = 0 + 0.1525252 i, v0 = 3, k = 0.36 (the cut is 5 sigma away: nothing)
+    Landau        2 gamma = -0.3067189, omega_r = 1.4156619   k = 0.5
 
-and how the fitted rate moves with the time step: the RK2 (midpoint) scheme of src/pic1dp.F90:79-93 amplifies a mode
-exp(z), z = (gamma - i omega) dt, by 1 + z + z^2/2 = exp(z) (1 - z^3/6 + ...), i.e. it adds -Re(z^3)/6 / dt =
-+gamma omega^2 dt^2 / 2 (1 - gamma^2 / (3 omega^2)) to gamma: +0.17 % at dt = 0.05 for the bump-on-tail wave, a quarter of
-that at dt = 0.025 -- a bias that only shows once the markers' noise is below it.
+How the rate is read off int E^2 dx(t) matters at this precision.  The straight-line fit of tools/OutputData.py:153-170 is
+biased by what else the initial perturbation excites, the same for every member: bump-on-tail -- the backward Langmuir
+wave (Landau-damped at 0.048, beating against the growing one at omega + omega' = 2.366); two-stream -- the decaying
+partner exp(-gamma t) and a damped oscillating root (0.107, 2.103): -0.9 % on a line through [12, 28].  Hence model fits:
+    bump        e(t) = a e^{2 g t} + b e^{2 g' t} + 2 sqrt(a b) e^{(g + g') t} cos(W t + phi)
+    two-stream  sqrt(e(t)) = a e^{g t} + c e^{-g t} + b e^{-d t} cos(W t + phi)
+    Landau      e(t) = a e^{2 g t} cos^2(w t + phi)
+(residuals 0.02-0.2 % rms at 1e8 markers).  And the time step: the scheme is second order, the rates move by
+-0.11 % (bump), -0.11 % (two-stream), -0.06 % (Landau) of |2 gamma| from dt -> 0 to the reference's dt = 0.05 (runs at dt and
+dt / 2 on the same seeds; Richardson) -- NOT the +gamma omega^2 dt^2 / 2 of RK2 on a single mode (+0.17 % for the bump-on-tail wave): the
+markers stream exactly, only the field's action on the weights is a midpoint rule.
 
     python tools/physics_ensemble.py [--members 8] [--markers 1e8] [--dts 0.05,0.025] [--cases bump,two_stream,landau]
-"""
+                                     [--save DIR] [--refit DIR] [--linear]
+--save keeps every member's series; --refit DIR redoes the fits from such a directory without a GPU.
+Logs: profiles/r06/experiments/physics_ensemble*.log; the test: tests/test_gpu_physics.py::test_growth_rates_ensemble."""
 import argparse
 import os
 import sys
@@ -25,13 +38,53 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+V_MAX = 8.0          # src/pic1dp_input.F90:125
+
+
+def vlasov_root(species, k, guess, vmax=None):
+    """root omega of the electrostatic Vlasov dispersion function 1 - (1 / k^2) int f0'(v) / (v - omega / k) dv for a sum of
+    Maxwellians `species` = [(density, drift, temperature), ...] (unit mass and charge, omega_pe = 1 for unit total density):
+    the function the reference's tools/dispersion.py:130-157 solves.  vmax None: the whole velocity axis through the plasma
+    dispersion function (Faddeeva); vmax given (GROWING roots only: the pole lies off the real axis): f0 cut at |v| = vmax,
+    by quadrature -- what a run whose markers live in [-vmax, vmax) evolves."""
+    from scipy.integrate import quad
+    from scipy.optimize import fsolve
+    from scipy.special import wofz
+
+    def f0p(v):
+        return sum(-n * (v - v0) / T * np.exp(-(v - v0) ** 2 / (2.0 * T)) / np.sqrt(2.0 * np.pi * T) for n, v0, T in species)
+
+    def D(w):
+        if vmax is None:
+            out = 1.0 + 0j
+            for n, v0, T in species:
+                z = (w - k * v0) / (np.sqrt(2.0 * T) * k)
+                out += n / (k * k * T) * (1.0 + z * 1j * np.sqrt(np.pi) * wofz(z))
+            return out
+        re = quad(lambda v: (f0p(v) / (v - w / k)).real, -vmax, vmax, limit=400, points=[w.real / k])[0]
+        im = quad(lambda v: (f0p(v) / (v - w / k)).imag, -vmax, vmax, limit=400, points=[w.real / k])[0]
+        return 1.0 - (re + 1j * im) / (k * k)
+
+    x = fsolve(lambda x: [D(x[0] + 1j * x[1]).real, D(x[0] + 1j * x[1]).imag], [guess.real, guess.imag], xtol=1e-13)
+    return x[0] + 1j * x[1]
+
+
+# theory: vlasov_root(...) evaluated once (tests/test_oracle_physics.py recomputes them)
 CASES = {
-    "bump": dict(kw=dict(nx=1024), t_fit=(15.0, 45.0), two_gamma=2 * 0.0838310511, omega=1.1693765077),
-    "two_stream": dict(kw=dict(nx=512, iptcldist=2, species_density=[1.0], species_v0=[3.0]), t_fit=(12.0, 28.0),
-                       two_gamma=2 * 0.1525251736, omega=0.0),
+    "bump": dict(kw=dict(nx=1024), t_fit=(12.0, 45.0), t_line=(15.0, 45.0), two_gamma=2 * 0.0839861624, omega=1.1695176329,
+                 two_gamma_uncut=2 * 0.0838310511, species=[(0.9, 0.0, 1.0), (0.1, 5.0, 1.0)], k=0.36),
+    "two_stream": dict(kw=dict(nx=512, iptcldist=2, species_density=[1.0], species_v0=[3.0]), t_fit=(10.0, 29.0), t_line=(12.0, 28.0),
+                       two_gamma=2 * 0.1525251736, omega=0.0, species=[(0.5, 3.0, 1.0), (0.5, -3.0, 1.0)], k=0.36),
     "landau": dict(kw=dict(nx=1024, iptcldist=0, species_density=[1.0], species_v0=[0.0], lx=4 * np.pi, linear=1),
-                   t_fit=(3.0, 16.0), two_gamma=-2 * 0.1533594669, omega=1.4156618886),
+                   t_fit=(3.0, 16.0), t_line=None, two_gamma=-2 * 0.1533594669, omega=1.4156618886, species=[(1.0, 0.0, 1.0)], k=0.5),
 }
+# what the reference's time step costs the rates (measured: runs at dt and dt / 2 on the same seeds, Richardson; fraction of
+# |2 gamma| at dt = 0.05, scaling with dt^2) -- the allowance the test grants on top of the statistical error
+DT2_SHIFT = {"bump": -0.00112, "two_stream": -0.00108, "landau": -0.00058}
+DT2_SHIFT_OMEGA_LANDAU = -0.000103
+
+LINEAR = False       # --linear: the linearised delta-f equations (input_linear = 1, src/pic1dp_input.F90:43): no amplitude effects
+SAVE_DIR = None      # --save DIR: every member's int E^2 dx series as an .npz (fits can then be redone without a GPU)
 
 
 def fit_rate(t, e, t1, t2):
@@ -45,7 +98,7 @@ def fit_rate(t, e, t1, t2):
 
 def fit_damped_wave(t, e, t1, t2, two_gamma0, omega0):
     """a standing wave that decays: int E^2 dx = A exp(2 gamma t) cos^2(omega t + phi); least squares on every sample of the
-    window (scipy), start values from theory; returns 2 gamma, omega"""
+    window (scipy), start values from theory; returns 2 gamma, omega, rms residual relative to the envelope"""
     from scipy.optimize import least_squares
     m = (t >= t1) & (t <= t2)
     tt, ee = t[m], e[m]
@@ -61,58 +114,157 @@ def fit_damped_wave(t, e, t1, t2, two_gamma0, omega0):
         r = least_squares(resid, [1.0, two_gamma0, omega0, ph0], x_scale=[1.0, 0.01, 0.01, 0.1])
         if best is None or r.cost < best.cost:
             best = r
-    return best.x[1], best.x[2]
+    return best.x[1], best.x[2], float(np.sqrt(2.0 * best.cost / tt.size))
 
 
-def rk2_bias(two_gamma, omega, dt):
-    """what the midpoint scheme adds to 2 gamma of a mode exp((gamma - i omega) t): -2 Re(z^3) / (6 dt), z = (gamma - i omega) dt"""
-    z = (0.5 * two_gamma - 1j * omega) * dt
-    return -2.0 * (z ** 3).real / (6.0 * dt)
+def fit_two_waves(t, e, t1, t2, gamma0, gamma_b0=-0.05, beat0=2.366):
+    """bump-on-tail: the growing Langmuir wave and the Landau-damped one running the other way, which the standing-wave
+    perturbation excites alike: int E^2 dx = a e^{2 g t} + b e^{2 g' t} + 2 sqrt(a b) e^{(g + g') t} cos(W t + phi).
+    Returns 2 g and the rms residual relative to the growing wave's energy."""
+    from scipy.optimize import least_squares
+    m = (t >= t1) & (t <= t2)
+    tt, ee = t[m], e[m]
+
+    def resid(p):
+        la, g, lb, gb, W, ph = p
+        model = np.exp(la + 2 * g * tt) + np.exp(lb + 2 * gb * tt) + 2 * np.exp(0.5 * (la + lb) + (g + gb) * tt) * np.cos(W * tt + ph)
+        return (model - ee) / np.exp(la + 2 * g * tt)
+
+    la0 = np.log(ee[-1]) - 2 * gamma0 * tt[-1]
+    best = None
+    for ph0 in np.linspace(0.0, 2 * np.pi, 8, endpoint=False):
+        for lb_off in (-1.0, -2.5):
+            r = least_squares(resid, [la0, gamma0, la0 + lb_off, gamma_b0, beat0, ph0], x_scale=[1, 0.01, 1, 0.01, 0.01, 0.3])
+            if best is None or r.cost < best.cost:
+                best = r
+    return 2.0 * best.x[1], float(np.sqrt(2.0 * best.cost / tt.size))
 
 
-def member(pic1dp_amd, case, markers, dt, m, npe=16):
+def fit_growing_amplitude(t, e, t1, t2, gamma0, damp0=0.1, omega0=2.1):
+    """two-stream (a standing, purely growing mode): sqrt(int E^2 dx) = a e^{g t} + c e^{-g t} + b e^{-d t} cos(W t + phi) -- the
+    growing root, its decaying partner, one damped oscillating root; linear in a, c, b cos phi, b sin phi for given g, d, W.
+    Valid where the growing term dominates (the amplitude keeps its sign).  Returns 2 g and the rms residual relative to it."""
+    from scipy.optimize import least_squares
+    m = (t >= t1) & (t <= t2)
+    tt, aa = t[m], np.sqrt(e[m])
+
+    def resid(p):
+        g, d, W = p
+        cols = [np.ones_like(tt), np.exp(-2 * g * tt), np.exp(-(d + g) * tt) * np.cos(W * tt), np.exp(-(d + g) * tt) * np.sin(W * tt)]
+        A = np.stack(cols, 1)
+        y = aa * np.exp(-g * tt)
+        sc = y.mean()
+        c = np.linalg.lstsq(A / sc, y / sc, rcond=None)[0]
+        return (A @ c - y) / sc
+
+    best = None
+    for W in (0.9 * omega0, omega0, 1.1 * omega0):
+        for d in (damp0, 2 * damp0):
+            r = least_squares(resid, [gamma0, d, W], x_scale=[0.01, 0.01, 0.01])
+            if best is None or r.cost < best.cost:
+                best = r
+    return 2.0 * best.x[0], float(np.sqrt(2.0 * best.cost / tt.size))
+
+
+def fit_case(case, t, e):
+    """(2 gamma by the case's model fit, omega_r or None, rms residual, 2 gamma by the straight line or None)"""
     c = CASES[case]
-    eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=int(markers), dt=dt, **c["kw"]), npe=npe)
+    t1, t2 = c["t_fit"]
+    line = fit_rate(t, e, *c["t_line"]) if c["t_line"] else None
+    if case == "landau":
+        g2, om, rms = fit_damped_wave(t, e, t1, t2, c["two_gamma"], c["omega"])
+        return g2, om, rms, line
+    if case == "bump":
+        g2, rms = fit_two_waves(t, e, t1, t2, 0.5 * c["two_gamma"])
+    else:
+        g2, rms = fit_growing_amplitude(t, e, t1, t2, 0.5 * c["two_gamma"])
+    return g2, None, rms, line
+
+
+def member_series(pic1dp_amd, case, markers, dt, m, npe=16):
+    c = CASES[case]
+    kw = dict(c["kw"])
+    if LINEAR:
+        kw["linear"] = 1
+    eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=int(markers), dt=dt, **kw), npe=npe)
     eng.set_seed_offset(npe * m)
     eng.particle_load()
     eng.interaction_collect_charge()
     eng.field_solve_electric()
     e0 = eng.field_energy()
-    nsteps = int(round((c["t_fit"][1] + 1.0) / dt))
+    nsteps = int(round((max(c["t_fit"][1], (c["t_line"] or (0, 0))[1]) + 1.0) / dt))
     eng.step(nsteps)
     e = np.concatenate([[e0], eng.energy_history()])
     t = np.arange(nsteps + 1) * dt
     eng.close()
-    if case == "landau":
-        return fit_damped_wave(t, e, c["t_fit"][0], c["t_fit"][1], c["two_gamma"], c["omega"])
-    return fit_rate(t, e, *c["t_fit"]), None
+    if SAVE_DIR:
+        np.savez(os.path.join(SAVE_DIR, "%s%s_dt%g_m%02d.npz" % (case, "_linear" if LINEAR else "", dt, m)), t=t, e=e,
+                 markers=int(markers), npe=npe)
+    return t, e
+
+
+def summarise(case, dt, markers, fits, log=print):
+    """mean +- sigma of the members' fits against theory; returns the dict the test asserts on"""
+    c = CASES[case]
+    th = c["two_gamma"]
+    rates = np.array([f[0] for f in fits])
+    n = rates.size
+    mean, sig = float(np.mean(rates)), float(np.std(rates, ddof=1))
+    sem = sig / np.sqrt(n)
+    out = dict(case=case, dt=dt, members=n, markers=int(markers), rates=rates.tolist(), mean=mean, sigma=sig, sem=sem, theory=th,
+               rms=float(np.mean([f[2] for f in fits])))
+    log("%-10s dt %.4f  %d members x %.3g markers: 2 gamma = %+.6f +- %.6f (sigma: %.3f %% of |2 gamma|; of the mean %.6f) | theory "
+        "%+.7f: mean - theory = %+.6f = %+.2f sigma_mean = %+.3f %% | model fit over t in [%g, %g], residual %.3f %% rms"
+        % (case, dt, n, markers, mean, sig, 100 * sig / abs(th), sem, th, mean - th, (mean - th) / sem, 100 * (mean - th) / abs(th),
+           c["t_fit"][0], c["t_fit"][1], 100 * out["rms"]))
+    if fits[0][3] is not None:
+        lines = np.array([f[3] for f in fits])
+        out["line_mean"] = float(lines.mean())
+        log("           straight line through ln(int E^2 dx) over [%g, %g] (tools/OutputData.py:153-170): %+.6f +- %.6f = theory %+.3f %%"
+            % (c["t_line"][0], c["t_line"][1], lines.mean(), lines.std(ddof=1), 100 * (lines.mean() / th - 1)))
+    if "two_gamma_uncut" in c:
+        log("           (against the root of the uncut f0, %+.7f: %+.3f %%)" % (c["two_gamma_uncut"], 100 * (mean / c["two_gamma_uncut"] - 1)))
+    if fits[0][1] is not None:
+        oms = np.array([f[1] for f in fits])
+        out.update(omega_mean=float(np.mean(oms)), omega_sigma=float(np.std(oms, ddof=1)), omega_theory=c["omega"])
+        log("           omega_r = %.6f +- %.6f (sigma) | theory %.7f: %+.4f %%"
+            % (out["omega_mean"], out["omega_sigma"], c["omega"], 100 * (out["omega_mean"] / c["omega"] - 1)))
+    return out
 
 
 def ensemble(pic1dp_amd, case, markers, dt, members, log=print):
-    c = CASES[case]
-    rates, oms = [], []
-    for m in range(members):
-        g2, om = member(pic1dp_amd, case, markers, dt, m)
-        rates.append(g2)
-        if om is not None:
-            oms.append(om)
-    rates = np.array(rates)
-    mean, sig = float(np.mean(rates)), float(np.std(rates, ddof=1))
-    sem = sig / np.sqrt(members)
-    th = c["two_gamma"]
-    bias = rk2_bias(th, c["omega"], dt)
-    out = dict(case=case, dt=dt, members=members, markers=int(markers), rates=rates.tolist(), mean=mean, sigma=sig, sem=sem,
-               theory=th, rk2_bias=bias)
-    log("%-10s dt %.4f  %d members x %.3g markers: 2 gamma = %+.6f +- %.6f (sigma; %.3f %% of |2 gamma|), mean +- %.6f | theory %+.6f: "
-        "mean - theory = %+.6f = %+.2f sigma_mean (%+.3f %%) | with the RK2 term %+.6f: %+.2f sigma_mean"
-        % (case, dt, members, markers, mean, sig, 100 * sig / abs(th), sem, th, mean - th, (mean - th) / sem,
-           100 * (mean - th) / abs(th), bias, (mean - th - bias) / sem))
-    if oms:
-        oms = np.array(oms)
-        out.update(omega_mean=float(np.mean(oms)), omega_sigma=float(np.std(oms, ddof=1)), omega_theory=c["omega"])
-        log("           omega_r = %.6f +- %.6f (sigma) | theory %.6f: %+.3f %%"
-            % (out["omega_mean"], out["omega_sigma"], c["omega"], 100 * (out["omega_mean"] / c["omega"] - 1)))
-    return out
+    return summarise(case, dt, markers, [fit_case(case, *member_series(pic1dp_amd, case, markers, dt, m)) for m in range(members)], log)
+
+
+def refit(directory, log=print):
+    """the fits redone from saved series (no GPU): every (case, dt) found, and the dt -> 0 extrapolation where dt and dt / 2 are there"""
+    import glob
+    import re
+    groups = {}
+    for f in sorted(glob.glob(os.path.join(directory, "*.npz"))):
+        m = re.match(r"(bump|two_stream|landau)(_linear)?_dt([0-9.]+)_m(\d+)\.npz", os.path.basename(f))
+        if m:
+            groups.setdefault((m.group(1), bool(m.group(2)), float(m.group(3))), []).append(f)
+    res = {}
+    for (case, lin, dt), files in sorted(groups.items()):
+        fits = []
+        for f in files:
+            d = np.load(f)
+            fits.append(fit_case(case, d["t"], d["e"]))
+        if lin:
+            log("(linearised equations, input_linear = 1)")
+        res[(case, lin, dt)] = summarise(case, dt, float(np.load(files[0])["markers"]), fits, log)
+    for (case, lin, dt), r in sorted(res.items()):
+        half = res.get((case, lin, dt / 2))
+        if half and half["members"] == r["members"]:
+            x = (4.0 * np.array(half["rates"]) - np.array(r["rates"])) / 3.0      # same seeds: member by member
+            th = r["theory"]
+            log("%-10s%s dt -> 0 (Richardson from dt = %g and %g, member by member): 2 gamma = %+.6f +- %.6f (of the mean %.6f) = theory "
+                "%+.3f %% = %+.2f sigma_mean; the time step %g costs %+.3f %%"
+                % (case, " linearised" if lin else "", dt, dt / 2, x.mean(), x.std(ddof=1), x.std(ddof=1) / np.sqrt(x.size),
+                   100 * (x.mean() / th - 1), (x.mean() - th) / (x.std(ddof=1) / np.sqrt(x.size)), dt,
+                   100 * (np.mean(r["rates"]) - x.mean()) / abs(th)))
+    return res
 
 
 def main():
@@ -121,7 +273,18 @@ def main():
     ap.add_argument("--markers", type=float, default=1e8)
     ap.add_argument("--dts", default="0.05,0.025")
     ap.add_argument("--cases", default="bump,two_stream,landau")
+    ap.add_argument("--save", default="")
+    ap.add_argument("--refit", default="")
+    ap.add_argument("--linear", action="store_true")
     a = ap.parse_args()
+    global SAVE_DIR, LINEAR
+    LINEAR = a.linear
+    if a.refit:
+        refit(a.refit)
+        return
+    if a.save:
+        SAVE_DIR = a.save
+        os.makedirs(SAVE_DIR, exist_ok=True)
     import pic1dp_amd
     for case in a.cases.split(","):
         for dt in [float(x) for x in a.dts.split(",")]:
