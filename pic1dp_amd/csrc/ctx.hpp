@@ -56,7 +56,7 @@ constexpr size_t kCuLds = 160 * 1024, kStaticLds = 1024;  // LDS of a CU; static
 // ---------------------------------------------------------------------------
 // The call sites' state (capi_step.cpp "lazy call sites").  Two variables, each an enum, and a table of
 // the pairs that can occur -- until round 6 this was lz, half_pair, half_solved and cd_lazy, 4 x 2 x 2 x 6 combinations of
-// which 18 are legal, policed from outside by pic1dp_hip_check_state; now an illegal one cannot be stored (set_call_state).
+// which 20 are legal, policed from outside by pic1dp_hip_check_state; now an illegal one cannot be stored (set_call_state).
 //
 // Seq: where the host stands in the reference's sequence push(1), collect_charge, solve_field, push(2), collect_charge,
 // solve_field of a time step (src/pic1dp.F90:79-90), and -- the "Pair" states, one rank, six sums -- whether the half
@@ -93,13 +93,15 @@ constexpr bool solved_of(Seq s) { return s == Seq::HalfPairSolved || s == Seq::P
 constexpr Seq unpaired(Seq s) { return lz_of(s) == LZ_HALF ? Seq::Half : lz_of(s) == LZ_PUSH2 ? Seq::Push2 : s; }
 // push(2) noted at a half step
 constexpr Seq push2_noted(Seq s) { return s == Seq::HalfPair ? Seq::Push2Pair : s == Seq::HalfPairSolved ? Seq::Push2PairSolved : Seq::Push2; }
-// Which (Seq, Owed) pairs occur.  Scale / SumScale: right behind a collect_charge (every other call that looks at charge
-// or markers settles them first, materialize_cd).  PredTiles / PredSums: behind the collect_charge of a noted push(1).
+// Which (Seq, Owed) pairs occur.  Scale / SumScale: right behind a collect_charge (every other call that looks at the
+// charge settles it first, materialize_cd).  PredTiles / PredSums: behind the collect_charge of a noted push(1) -- and
+// still owed after a look at the MARKERS has put the half-step state into memory (particles_download materialises the
+// markers, not the charge: Clean with a prediction owed; the fuzz campaign of round 6 found that one, 5 seeds in 4 500).
 // AdoptHalfField is set with HalfPair and outlives it when an inspection settles the pair before solve_field came (the
 // field is then adopted by copying); it ends with the solve_field of the half step, hence never with a Solved state.
 constexpr bool kCallStateLegal[static_cast<int>(Seq::N)][static_cast<int>(Owed::N)] = {
     //                   Nothing Scale  SumScale PredTiles PredSums Adopt
-    /* Clean           */ {true, true,  true,    false,    false,   true},
+    /* Clean           */ {true, true,  true,    true,     true,    true},
     /* Push1           */ {true, false, false,   false,    false,   true},
     /* Half            */ {true, true,  true,    true,     true,    true},
     /* HalfPair        */ {false, false, false,  false,    false,   true},
