@@ -922,8 +922,10 @@ static int solve_phase(pic1dp_ctx *c, double *Eout, bool record, bool pred) {
   const bool pair = pred && c->pred_version == c->state_version && (!multi || fused_xchg || will_pack) &&
                     c->field_solver == 0 && 2 * c->in.nmode <= 256 && Eout == c->d_E;
   if (pair) {
-    // (cd_h: the tiles' scratch; with the six sums only the call sites want the half-step charge density's kept mode)
-    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->pred_kind == 2 ? nullptr : c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, 0};
+    // (cd_h: the tiles' scratch; with the six sums the kept mode's content of the half-step charge density -- what the call
+    // sites adopt into field_chargeden when the host's next push(1), collect_charge, solve_field are served from this solve,
+    // which they are after a step() as after the call sites' own pair: round 6's fuzz campaign found the stale copy)
+    PairArgs pa{c->d_pred, c->d_Ehn, c->d_mode_h, c->d_cd_h, nullptr, c->pred_kind, c->pred_tab, 0};
     if (will_pack) {  // both charge sums of the step came in ONE all-reduce (pack_doubles)
       pa.pack = c->d_pack;
       HIP_TRY(launch_field_solve_pair(f, pa, nullptr, c->st));

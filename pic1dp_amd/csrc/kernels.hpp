@@ -318,7 +318,7 @@ struct PairArgs {
   double *pred;     // kind 1: [nspecies][1 + 2 nmode][nx]; kind 2: [PRED_SUM_COPIES][8] the six sums; consumed (re-zeroed)
   double *E_h;      // [nx] half-step field of the next step
   double *mode_h;   // [2 nmode] its kept modes (re..., im...)
-  double *cd_h;     // [nx] its charge density (kind 1: scratch; kind 2: null, or where the call sites want the kept mode's content of it)
+  double *cd_h;     // [nx] its charge density (kind 1: scratch; kind 2: the kept mode's content of it, for the call sites' adoption)
   double *pack;     // null, or what k_charge_pack made, already summed over ranks
   int kind;         // 1 tiles, 2 sums
   PredTab pt;       // kind 2

@@ -291,6 +291,19 @@ __device__ __forceinline__ double pred_coef(double v, double w, double p, double
 // * the number of kept modes is a template parameter (1 or 2): the tile and accumulator addresses of a cell
 //   are immediate offsets of one base address instead of a run-time loop's address arithmetic (a dozen integer
 //   instructions per marker).
+#ifdef PIC1DP_TUNE_FXTILES  // EXPERIMENT (tuning build): the prediction tiles as 64-bit fixed-point sums
+constexpr double FX_S0 = 0x1p40 / 1e-9, FX_S1 = 0x1p40 / 1e-4;   // fixed scales: what the timing needs, not the product
+__device__ __forceinline__ void pred_add(double *p, double v, double s) {
+  const double t = fma(v, s, 6755399441055744.0);
+  __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(p),
+                         static_cast<unsigned long long>(__double_as_longlong(t)) - 0x4338000000000000ull, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#else
+constexpr double FX_S0 = 1.0, FX_S1 = 1.0;
+__device__ __forceinline__ void pred_add(double *p, double v, double) { lds_add(p, v); }
+#endif
+
 template <int DIST, int MODE, int POW2, int NM>
 __device__ __forceinline__ double pred_one(const One &n, double p, int ix, double wl, const double *sAB, double *sP,
                                            const StepArgsDev &a) {
@@ -309,11 +322,11 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
   double *cl = sP + __mul24(ih, np1), *cr = cl + np1;
   double t2 = 0.0;
   if constexpr (MODE == MODE_FULLF) {
-    lds_add(cl, wh * p);
-    lds_add(cr, wr * p);
+    pred_add(cl, wh * p, FX_S0);
+    pred_add(cr, wr * p, FX_S0);
   } else {
-    lds_add(cl, wh * n.w);
-    lds_add(cr, wr * n.w);
+    pred_add(cl, wh * n.w, FX_S0);
+    pred_add(cr, wr * n.w, FX_S0);
     const double tmp1 = (MODE == MODE_DF_LIN) ? p : (p - n.w);
     if constexpr (POW2 == 0) {
       if (a.s.fastc) {
@@ -339,10 +352,10 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
       const double2 tl = *reinterpret_cast<const double2 *>(gl + 2 * m), tr = *reinterpret_cast<const double2 *>(gr + 2 * m);
       const double A = fma(tr.x, wlr, tl.x * wl), B = fma(tr.y, wlr, tl.y * wl);  // (contraction is fine here)
       const double cA = c * A, cB = c * B;
-      lds_add(cl + 1 + m, wh * cA);
-      lds_add(cr + 1 + m, wr * cA);
-      lds_add(cl + 1 + nm + m, wh * cB);
-      lds_add(cr + 1 + nm + m, wr * cB);
+      pred_add(cl + 1 + m, wh * cA, FX_S1);
+      pred_add(cr + 1 + m, wr * cA, FX_S1);
+      pred_add(cl + 1 + nm + m, wh * cB, FX_S1);
+      pred_add(cr + 1 + nm + m, wr * cB, FX_S1);
     }
   }
   return t2;
@@ -720,7 +733,14 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   if (threadIdx.x < 2 * np1) {
     const int g = threadIdx.x / np1, k = threadIdx.x - g * np1;
     const int to = (nx + g) % nx;
+#ifdef PIC1DP_TUNE_FXTILES
+    if (g == 0 || to != 0 || nx > 1)
+      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&sP[to * np1 + k]),
+                             static_cast<unsigned long long>(__double_as_longlong(sP[(nx + g) * np1 + k])), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     if (g == 0 || to != 0 || nx > 1) lds_add(&sP[to * np1 + k], sP[(nx + g) * np1 + k]);
+#endif
   }
   __syncthreads();
   {
@@ -729,7 +749,11 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
       const int k = i / nx;
       int c = i - k * nx + rot;
       if (c >= nx) c -= nx;
+#ifdef PIC1DP_TUNE_FXTILES
+      const double val = static_cast<double>(__double_as_longlong(sP[c * np1 + k])) * (k == 0 ? 1.0 / FX_S0 : 1.0 / FX_S1);
+#else
       const double val = sP[c * np1 + k];
+#endif
       if (val != 0.0) glb_add(&a.pred[static_cast<size_t>(k) * nx + c], val);
     }
   }

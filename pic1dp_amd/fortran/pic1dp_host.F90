@@ -45,7 +45,7 @@ real(c_double) :: global_time, ms_push, ms_charge, ms_field
 real(c_double) :: t_run0, t_loop0, t_a, steps_s, load_s
 character(len=8) :: buf
 character(len=512) :: dump_path
-integer :: stat, verbosity
+integer :: stat, verbosity, fail_at
 integer(c_int32_t) :: timer_mode
 logical :: fused, whole_step, batched, use_rccl, loop_profile
 integer(c_signed_char) :: handle(PIC1DP_XCHG_HANDLE_BYTES), comm_id(PIC1DP_COMM_ID_BYTES)
@@ -89,6 +89,12 @@ timer_mode = 17                                      ! the reference's timers (w
                                                      ! default-size run; 0: off)
 if (stat == 0) read (buf, *, iostat=stat) timer_mode
 steps_s = 0.0_c_double
+! (tests) PIC1DP_HOST_FAIL_AT=n: at time step n the host makes a call the library refuses -- what a failure in the middle of
+! a run looks like: pic1dp_hip_check prints the library's message, the record assembled but not yet written goes to
+! pic1dp.out (pic1dp_hip_on_abort), the program stops with code 1
+fail_at = -1
+call get_environment_variable('PIC1DP_HOST_FAIL_AT', buf, status=stat)
+if (stat == 0) read (buf, *, iostat=stat) fail_at
 
 t_run0 = output_wall()
 call pic1dp_hip_check(pic1dp_hip_particle_load(ctx), 'particle_load')
@@ -112,6 +118,7 @@ call pic1dp_hip_check(pic1dp_hip_check_termination(ctx, itermination), 'check_te
 t_loop0 = output_wall()
 do while (itermination == 0)                 ! main time evolution loop
   t_a = output_wall()
+  if (global_itime == fail_at) call pic1dp_hip_check(pic1dp_hip_push(ctx, 3_c_int32_t), 'push (forced failure)')
   if (whole_step) then
     nbatch = 1
     if (batched) call pic1dp_hip_check(pic1dp_hip_steps_to_output(ctx, nbatch), 'steps_to_output')

@@ -666,3 +666,20 @@ def test_output_all_record_survives_a_fixed_point_repeat(amd, monkeypatch, two_s
         for e in (a, b):
             e.step(10)
     assert a.kernel_stats(12)[0] >= 2.0          # the records after the first one were repeated in doubles
+
+
+def test_fortran_host_writes_its_buffered_record_before_a_stop(amd, tmp_path):
+    """the host assembles a record in memory and writes it while the next steps run on the GPU; a library error in
+    between (here forced: a call the library refuses, at the step right after an output) must not lose the record the
+    reference would have written by then -- pic1dp_hip_check runs the host's abort hook before it stops"""
+    exe = fortran_host_exe()
+    from pic1dp_amd import output
+    env = dict(os.environ, PIC1DP_NPARTICLE="50001", PIC1DP_NX="64", PIC1DP_TIME_MAX="2.0", PIC1DP_FUSED="0",
+               PIC1DP_HOST_FAIL_AT="10")                # output_all at steps 0, 10, 20, ...: the failure comes right behind record 1
+    r = subprocess.run([exe], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "push (forced failure)" in r.stdout and "irk must be 1 or 2" in r.stdout
+    d = output.OutputData(str(tmp_path / "pic1dp.out"))
+    assert d.ntime == 2 and list(d.scalars[:, 0]) == accumulated_times(0.05, [0, 10])       # both records whole
+    inp = amd.make_input(nparticle_max=50001, nx=64)
+    assert os.path.getsize(str(tmp_path / "pic1dp.out")) == output.header_bytes(inp) + 2 * output.record_bytes(inp)
