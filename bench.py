@@ -900,7 +900,7 @@ def main():
         shape_gbs = max(probe.stream(4, 3, probe_n, 10, device=device) for _ in range(3))
         # the same traffic in the layout the markers are stored in (x | v | w | p tiles, three written back in
         # place): what a kernel that did nothing but stream them would reach -- the denominator that does not
-        # depend on where the allocator puts seven separate arrays (DESIGN.md section 2)
+        # depend on where the allocator puts seven separate arrays (DESIGN.md section 0)
         tiled_ms = min(probe.layout(probe_n, 12, 10, device=device)[1] for _ in range(2))
         tiled_gbs = 56.0 * (probe_n // 4096 * 4096) / (tiled_ms * 1e-3) / 1e9
         # bytes the timed steps had to move: every launch of the three whole-step kernels at its own price

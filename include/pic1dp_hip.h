@@ -246,10 +246,10 @@ int pic1dp_hip_solve_field(pic1dp_ctx *ctx);
  * collect_charge, solve_field the push is only noted and the collect_charge
  * that follows runs one whole-step kernel for both; from the second step on the
  * collect_charge after push(1) touches no marker at all -- the previous step's
- * kernel has predicted its charge (DESIGN.md 3.2) -- so a step is ONE pass over
+ * kernel has predicted its charge (DESIGN.md 2.2) -- so a step is ONE pass over
  * the markers (56 instead of 184 bytes per marker and step), and on one rank the
  * solve_field after the second collect_charge solves both fields of the step in one
- * launch: two launches per time step (DESIGN.md 3.9).  Whatever looks at the markers in between first gets the
+ * launch: two launches per time step (DESIGN.md 0).  Whatever looks at the markers in between first gets the
  * ordinary kernels run, so every observable state is the eager one, bit for
  * bit.  PIC1DP_LAZY_CALLS=0 in the environment: one kernel per call, at once. */
 int pic1dp_hip_push(pic1dp_ctx *ctx, int32_t irk);
@@ -262,7 +262,7 @@ int pic1dp_hip_push(pic1dp_ctx *ctx, int32_t irk);
  * marker (1-8 B) goes to the host, which walks the keys exactly as these sequential
  * routines walk the markers (visiting order, swap-with-last, the block's random
  * stream; the blocks side by side on host threads), and the decisions are applied on
- * the device (DESIGN.md 3.8; PIC1DP_OPT_HOST=1: the pass on host copies of the
+ * the device (DESIGN.md 2.9; PIC1DP_OPT_HOST=1: the pass on host copies of the
  * markers, kept as the cross-check).  Off the timed path and disabled by default.  pic1dp_hip_step calls
  * this itself.  Needs markers loaded by pic1dp_hip_particle_load (the blocks'
  * generators continue from the load), delta-f only like the reference. */
@@ -552,7 +552,7 @@ int pic1dp_hip_kernel_bytes(pic1dp_ctx *ctx, int32_t which, double *read_bytes,
                             int32_t name_len);
 
 /* Debugging aid: checks the relations between the flags of the library's internal state machine (lazy call sites,
- * prediction, call-site pair, accumulator sets: DESIGN.md 3.9) that have to hold between any two calls, whatever the
+ * prediction, call-site pair, accumulator sets: DESIGN.md 0) that have to hold between any two calls, whatever the
  * calls were.  deep != 0 also synchronises and looks at device memory (accumulator sets nobody owes anything to are
  * zero).  PIC1DP_ERR_STATE + pic1dp_hip_last_error() name the relation that does not hold.  Replaces nothing in the
  * reference; the randomised call-sequence tests call it after every call. */

@@ -427,6 +427,8 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     // the first sub-step call that needs it (ensure_second_set) -- pic1dp_hip_step
     // never does
     HIP_TRY_C(hipMalloc(&S.slab[0], sizeof(double) * static_cast<size_t>(slab_doubles(nalloc + 2))));
+    HIP_TRY_C(hipMalloc(&S.fxb, 2 * sizeof(double)));
+    HIP_TRY_C(hipMemsetAsync(S.fxb, 0, 2 * sizeof(double), c->st));
     const int64_t as = slab_array_stride(nalloc + 2);
     S.set[0].x = S.slab[0];
     S.set[0].v = S.slab[0] + as;
@@ -597,6 +599,7 @@ int pic1dp_hip_destroy(pic1dp_ctx *c) {
     (void)hipFree(S.slab[0]);
     (void)hipFree(S.slab[1]);
     (void)hipFree(S.t2);
+    (void)hipFree(S.fxb);
   }
   double *bufs[] = {c->d_rho_all, c->d_charge, c->d_chargeden, c->d_E,   c->d_mode_re, c->d_mode_im,
                     c->d_fre,    c->d_fim,    c->d_ginv,      c->d_hist, c->d_scratch, c->d_dist, c->d_Eh, c->d_diag_part, c->d_E0, c->d_rho_dummy, c->d_stage, c->d_tabA, c->d_tabB, c->d_pred_all, c->d_cd_h, c->d_mode_h, c->d_Ehn, c->d_pack};
@@ -662,6 +665,30 @@ int pic1dp_hip_local_sizes(pic1dp_ctx *c, int32_t isp, int64_t *nalloc, int64_t 
 }
 
 
+// Bounds for the prediction tiles' fixed-point sums (kernels_step.hip FxTiles) from markers the host holds: b[0] >= |q|
+// (w, or p in a full-f run), b[1] >= |c| = dt/2 |p - w| |f0'/f0|(v) |Z/m| -- the latter from max |p| + max |w| and a bound on
+// |f0'/f0| over the velocities markers can reach (src/pic1dp_interaction.F90:274-326: a blend of v / (T/m) and
+// (v - v0) / (T2/m); two-stream1's v - 2/v only away from v = 0).  They need not be tight, nor even hold: a term beyond
+// 16x its bound takes the kernel's double path, and the kernels raise the bounds to what they meet.
+static void fx_bounds_of(const pic1dp_input &in, int isp, const double *p, const double *w, int64_t n, double b[2]) {
+  double maxp = 0.0, maxw = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double ap = std::fabs(p[i]), aw = std::fabs(w[i]);
+    if (ap > maxp) maxp = ap;   // (NaN compares false)
+    if (aw > maxw) maxw = aw;
+  }
+  const double m = std::fabs(in.species_mass[isp]), tm = std::fabs(in.species_temperature[isp]) / m,
+               tm2 = std::fabs(in.species_temperature2[isp]) / m, v0 = std::fabs(in.species_v0[isp]);
+  const double vm = 1.5 * in.v_max + v0;
+  double d = vm / tm;
+  if (in.iptcldist == 1) d = vm + 200.0;
+  if (in.iptcldist == 2) d = (vm + v0) / tm;
+  if (in.iptcldist == 3) d = std::max(vm / tm, (vm + v0) / tm2);
+  const double cb = 0.5 * in.dt * (maxp + maxw) * d * std::fabs(in.species_charge[isp]) / m;
+  b[0] = std::max(b[0], in.deltaf ? maxw : maxp);
+  if (std::isfinite(cb)) b[1] = std::max(b[1], cb);
+}
+
 int pic1dp_hip_set_seed_offset(pic1dp_ctx *c, int32_t offset) {
   CHECK_CTX(c);
   if (offset < 0) return fail(PIC1DP_ERR_ARG, "seed offset < 0");
@@ -700,6 +727,7 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   c->rng_ready = false;
   std::vector<int64_t> voff(ns, 0), toff(ns);
   for (int s = 0; s < ns; ++s) toff[s] = c->sp[s].np;
+  std::vector<double> fxb(2 * static_cast<size_t>(ns), 0.0);
   int rc = 0;
   for (int b = 0; b < c->nblk && !rc; ++b) {
     const int mype = c->blk0 + b;
@@ -710,6 +738,7 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
       Species &S = c->sp[s];
       load_block_species(in, s, g, n, hx, hv, hp, hw, nthreads);
       const int64_t np = block_np(in, s, mype, npe), nt = n - np;
+      fx_bounds_of(in, s, hp, hw, np, &fxb[2 * static_cast<size_t>(s)]);
       struct {
         double *d;
         const double *h;
@@ -725,6 +754,7 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   }
   (void)hipHostFree(stage);
   if (rc) return rc;
+  for (int s = 0; s < ns; ++s) HIP_TRY(hipMemcpy(c->sp[s].fxb, &fxb[2 * static_cast<size_t>(s)], 2 * sizeof(double), hipMemcpyHostToDevice));
   c->rng_ready = true;
   std::fill(c->diag_max_p.begin(), c->diag_max_p.end(), 0.0);  // (new markers: the fixed-point diagnostics' bounds are void)
   std::fill(c->diag_max_w.begin(), c->diag_max_w.end(), 0.0);
@@ -767,6 +797,11 @@ int pic1dp_hip_particles_upload(pic1dp_ctx *c, int32_t isp, const double *x, con
   if (int rc = put_range(c, A.w, 0, w, n)) return rc;
   if (int rc = put_range(c, S.p, 0, p, n)) return rc;
   S.np = np;
+  {  // (the prediction tiles' fixed-point bounds start over with these markers)
+    double b[2] = {0.0, 0.0};
+    fx_bounds_of(c->in, isp, p, w, np, b);
+    HIP_TRY(hipMemcpy(S.fxb, b, sizeof b, hipMemcpyHostToDevice));
+  }
   if (c->nblk == 1) c->blk_np[isp][0] = np;
   c->rng_ready = false;  // the host's loader owns the random stream now
   std::fill(c->diag_max_p.begin(), c->diag_max_p.end(), 0.0);

@@ -684,6 +684,7 @@ static int step_particles(pic1dp_ctx *c, bool full, const double *E0, const doub
                                  : c->d_pred + static_cast<size_t>(s) * (1 + 2 * c->in.nmode) * c->in.nx;
       a.pred_nm = c->in.nmode;
       a.pred_private = priv ? 1 : 0;
+      a.fxb = S.fxb;
       if (c->pred_kind == 2) {
         a.eh_re = c->eh_modes == 2 ? c->d_mode_h : c->fa.mode_re;
         a.eh_im = c->eh_modes == 2 ? c->d_mode_h + 1 : c->fa.mode_im;
@@ -1016,7 +1017,7 @@ int pic1dp_hip_step(pic1dp_ctx *c, int32_t nsteps) {
 }
 
 // ---------------------------------------------------------------------------
-// pic1dp_hip_check_state: the relations between the flags of the state machine above (DESIGN.md 3.9, the table of
+// pic1dp_hip_check_state: the relations between the flags of the state machine above (DESIGN.md 0, the table of
 // invariants) checked at an API boundary -- between two calls of the library every one of them has to hold, whatever the
 // calls were.  deep != 0 also looks at device memory (one stream synchronisation and small copies): the accumulator sets
 // nobody owes anything to are zero, the tail's ticket is back at zero.  A debugging aid and what the randomised call-

@@ -54,7 +54,7 @@ constexpr int kEnergyBlocks = 1024;
 constexpr size_t kCuLds = 160 * 1024, kStaticLds = 1024;  // LDS of a CU; static LDS of a marker kernel (the exp table)
 // states of the lazy call sites (pic1dp_ctx::lz)
 // ---------------------------------------------------------------------------
-// The call sites' state (capi_step.cpp "lazy call sites"; DESIGN.md 3.9).  Two variables, each an enum, and a table of
+// The call sites' state (capi_step.cpp "lazy call sites"; DESIGN.md 0).  Two variables, each an enum, and a table of
 // the pairs that can occur -- until round 6 this was lz, half_pair, half_solved and cd_lazy, 4 x 2 x 2 x 6 combinations of
 // which 20 are legal, policed from outside by pic1dp_hip_check_state; now an illegal one cannot be stored (set_call_state).
 //
@@ -119,6 +119,8 @@ struct Species {
   uint64_t t2_version = 0;  // state_version whose step-start velocities the values in t2 belong to (0: none)
   double *slab[2] = {nullptr, nullptr};  // tiled storage of set 0 (+ p) and of the RK ping-pong set (kernels.hpp)
   double *rho = nullptr;  // slice of rho_sp
+  double *fxb = nullptr;  // device [2]: bounds on |q| and |c| of this species' markers for the prediction tiles' fixed-point
+                          // sums (kernels_step.hip FxTiles): seeded from the markers the host loads, raised by the kernels
   SpeciesConst sc{};
 };
 

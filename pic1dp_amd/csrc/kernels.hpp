@@ -262,6 +262,7 @@ struct StepArgs {
   DistScale dscale;  // k_step_full<DIAG>: the histograms as fixed-point sums (diag_fx != 0)
   int diag_fx;
   int dyn_tail;      // every whole-step kernel: sixteenths of a workgroup's chunks that its waves draw from an LDS counter (0: all dealt)
+  double *fxb;       // pred_kind 1: [2] device bounds on |q|, |c| of this species, for the tiles' fixed-point sums
 };
 constexpr int PRED_MAX_MODES = 2;  // kept modes k_step_one's prediction tiles are instantiated for (1, 2; three and four were
                                     // built in round 4 and lost to the two passes by measurement: HISTORY.md)

@@ -5,7 +5,7 @@
 // All kernels are HBM-bound streaming passes over the tiled FP64 marker slabs (16 B per lane, coalesced,
 // grid-stride); no dense contraction, so no MFMA.  Grid tiles (E0, Eh, rho, the prediction's tables and
 // accumulators) live in LDS; deposits are ds_add_f64, flushed with one global atomic per cell and workgroup.
-// DESIGN.md section 3 has the numbers.
+// DESIGN.md section 2 has the numbers.
 //
 // One translation unit per distribution: the build compiles this file once for every value of
 // -DPIC1DP_STEP_DIST (0 Maxwellian, 1 two-stream1, 2 two-stream2, 3 bump-on-tail, 4 / 5 the one-exp forms of 2 / 3),
@@ -278,7 +278,7 @@ __device__ __forceinline__ double pred_coef(double v, double w, double p, double
 // (ix, wl): cell and left weight of n.x, where the next step gathers its field (:250-257) -- the deposit
 // of the new state has just computed them.
 // The kernel runs at the package power limit with its FP64 pipes ~77 % busy at the clock that leaves
-// (DESIGN.md 7), so instructions are what this part is written for:
+// (DESIGN.md 6), so instructions are what this part is written for:
 // * the tables lie cell by cell, sAB[cell][A_0 B_0 (A_1 B_1)] with a guard cell, and the accumulators likewise,
 //   sP[cell][R0 RA_0 RB_0 (...)] with TWO guard cells (folded into cells 0 and 1 at the flush): one address
 //   per cell instead of one per tile and cell, no wrap-around of the right-hand cell, no clamp;
@@ -291,22 +291,53 @@ __device__ __forceinline__ double pred_coef(double v, double w, double p, double
 // * the number of kept modes is a template parameter (1 or 2): the tile and accumulator addresses of a cell
 //   are immediate offsets of one base address instead of a run-time loop's address arithmetic (a dozen integer
 //   instructions per marker).
-#ifdef PIC1DP_TUNE_FXTILES  // EXPERIMENT (tuning build): the prediction tiles as 64-bit fixed-point sums
-constexpr double FX_S0 = 0x1p40 / 1e-9, FX_S1 = 0x1p40 / 1e-4;   // fixed scales: what the timing needs, not the product
-__device__ __forceinline__ void pred_add(double *p, double v, double s) {
+// The prediction tiles as 64-bit FIXED-POINT sums (round 6; the diagnostics' trick, device_diag.hpp):
+// ten of the tiles' twelve LDS atomics per marker (two kept modes) hit random cells, where ds_add_u64 runs at 4.5 ns per
+// wave-instruction against ds_add_f64's 8.7 (tools/lds_atomic_rate.hip) -- and the prediction only has to be right to
+// rounding (the rho tile, whose sums are the reference's charge, stays in doubles).  Two kept modes at 1e8 markers:
+// kernel 1.235 -> 1.08 ms (profiles/r06/experiments/ab_fx_tiles*.log).
+//   * fxb[0], fxb[1] (device, per species): bounds on |q| (w, or p in full-f) and on |c| = dt/2 |p - w| |f0'/f0| |Z/m| -- seeded
+//     by the host from the markers it loads, raised by the kernels to the largest value they meet (atomic max, monotone);
+//   * a term within 16x its bound (to be precise: below the cap the power-of-two scale leaves) is rounded ONCE to a power-of-two quantum chosen such that a workgroup's sums stay below
+//     2^61 (about 2^-41 of the bound at 2e5 markers per workgroup: 1e-13 of a cell's sum), the sums themselves are exact and
+//     independent of the atomics' order;
+//   * a marker beyond 16x (two-stream1's v - 2/v near v = 0; weights scaled behind the library's back; NaN) adds its terms
+//     straight into the global accumulators in doubles -- exact, slow, rare.
+struct FxTiles {
+  double s0, s1;      // quanta^-1 of the R0 slice and of the RA / RB slices (powers of two, wave-uniform: scalar registers; +inf with
+                      // an unknown bound: every term then fails the test below and goes through the doubles)
+  float mx0, mx1;     // largest |q|, |c| this thread has met (single precision: a bound, and a register each)
+};
+// a value every lane holds alike, moved to scalar registers (the marker loop is at its VGPR budget)
+__device__ __forceinline__ double wave_uniform(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(b)));
+  const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32)));
+  return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+__device__ __forceinline__ double fx_scale(double lim, double markers) {  // 2^k with lim * markers * 2^k <= 2^61
+  const double t = lim * markers;
+  return t > 0.0 && t < 0x1p900 ? ldexp(1.0, 60 - ilogb(t)) : __builtin_inf();   // (unknown bound: nothing passes the cap)
+}
+__device__ __forceinline__ void pred_add_fx(double *p, double v, double s) {  // RN(v s) added as a two's-complement integer
   const double t = fma(v, s, 6755399441055744.0);
   __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(p),
                          static_cast<unsigned long long>(__double_as_longlong(t)) - 0x4338000000000000ull, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-#else
-constexpr double FX_S0 = 1.0, FX_S1 = 1.0;
-__device__ __forceinline__ void pred_add(double *p, double v, double) { lds_add(p, v); }
-#endif
+__device__ __forceinline__ void fx_raise(double *bound, float seen_f) {  // bound = max(bound, seen): positive doubles order as integers
+  for (int off = 32; off > 0; off >>= 1) seen_f = fmaxf(seen_f, __shfl_down(seen_f, off, 64));
+  if ((threadIdx.x & 63) == 0) {
+    const double seen = static_cast<double>(seen_f) * (1.0 + 0x1p-20);   // (the float was rounded to nearest: not below what was met)
+    if (seen > __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && seen < 0x1p120)
+      __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(bound), static_cast<unsigned long long>(__double_as_longlong(seen)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 template <int DIST, int MODE, int POW2, int NM>
 __device__ __forceinline__ double pred_one(const One &n, double p, int ix, double wl, const double *sAB, double *sP,
-                                           const StepArgsDev &a) {
+                                           const StepArgsDev &a, FxTiles &fx) {
   constexpr int nm = NM, np1 = 1 + 2 * NM;
   const double xh = fma(a.dt_half, n.v, n.x);     // the next step's half push of x (:261), to rounding
   const double sh = xh * a.snx;                   // its cell, wrapped as an integer (:102-108 to rounding)
@@ -321,12 +352,28 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
   }
   double *cl = sP + __mul24(ih, np1), *cr = cl + np1;
   double t2 = 0.0;
+  // the overflow path (rare): slice k of this marker straight into the global accumulators' cells of cl, cr (the guard
+  // cells nx, nx + 1 are cells 0, 1)
+  auto slow = [&](int k, double vl, double vr) {
+    const int nx = a.g.nx;
+    const int gl_c = ih >= nx ? ih - nx : ih;
+    int gr_c = ih + 1;
+    gr_c = gr_c >= nx ? gr_c - nx : gr_c;
+    gr_c = gr_c >= nx ? gr_c - nx : gr_c;   // (nx = 1: cell nx + 1 is cell 0 as well)
+    if (vl != 0.0) glb_add(a.pred + static_cast<size_t>(k) * nx + gl_c, vl);   // (zeros: a species without perturbation has no bound)
+    if (vr != 0.0) glb_add(a.pred + static_cast<size_t>(k) * nx + gr_c, vr);
+  };
+  // a term t goes the fixed-point way if |t| s <= fx_cap = 2^61 / (markers a workgroup takes): its sums then stay in 63 bits
   if constexpr (MODE == MODE_FULLF) {
-    pred_add(cl, wh * p, FX_S0);
-    pred_add(cr, wr * p, FX_S0);
+    const double aq = fabs(p);
+    fx.mx0 = fmaxf(fx.mx0, static_cast<float>(aq));
+    if (aq * fx.s0 <= a.fx_cap) {
+      pred_add_fx(cl, wh * p, fx.s0);
+      pred_add_fx(cr, wr * p, fx.s0);
+    } else {
+      slow(0, wh * p, wr * p);
+    }
   } else {
-    pred_add(cl, wh * n.w, FX_S0);
-    pred_add(cr, wr * n.w, FX_S0);
     const double tmp1 = (MODE == MODE_DF_LIN) ? p : (p - n.w);
     if constexpr (POW2 == 0) {
       if (a.s.fastc) {
@@ -345,6 +392,16 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
       t2 = dlnf0<DIST, POW2>(n.v, a.s, dt);
     }
     const double c = tmp1 * t2 * a.pred_k;
+    const double aq = fabs(n.w), ac = fabs(c);
+    fx.mx0 = fmaxf(fx.mx0, static_cast<float>(aq));
+    fx.mx1 = fmaxf(fx.mx1, static_cast<float>(ac));
+    const bool fixed = aq * fx.s0 <= a.fx_cap && 2.0 * ac * fx.s1 <= a.fx_cap;   // (|A|, |B| <= 2; false for NaN)
+    if (fixed) {
+      pred_add_fx(cl, wh * n.w, fx.s0);
+      pred_add_fx(cr, wr * n.w, fx.s0);
+    } else {
+      slow(0, wh * n.w, wr * n.w);
+    }
     const double *gl = sAB + __mul24(ix, 2 * nm), *gr = gl + 2 * nm;
     const double wlr = 1.0 - wl;
 #pragma unroll
@@ -352,10 +409,15 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
       const double2 tl = *reinterpret_cast<const double2 *>(gl + 2 * m), tr = *reinterpret_cast<const double2 *>(gr + 2 * m);
       const double A = fma(tr.x, wlr, tl.x * wl), B = fma(tr.y, wlr, tl.y * wl);  // (contraction is fine here)
       const double cA = c * A, cB = c * B;
-      pred_add(cl + 1 + m, wh * cA, FX_S1);
-      pred_add(cr + 1 + m, wr * cA, FX_S1);
-      pred_add(cl + 1 + nm + m, wh * cB, FX_S1);
-      pred_add(cr + 1 + nm + m, wr * cB, FX_S1);
+      if (fixed) {
+        pred_add_fx(cl + 1 + m, wh * cA, fx.s1);
+        pred_add_fx(cr + 1 + m, wr * cA, fx.s1);
+        pred_add_fx(cl + 1 + nm + m, wh * cB, fx.s1);
+        pred_add_fx(cr + 1 + nm + m, wr * cB, fx.s1);
+      } else {
+        slow(1 + m, wh * cA, wr * cA);
+        slow(1 + nm + m, wh * cB, wr * cB);
+      }
     }
   }
   return t2;
@@ -630,6 +692,13 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   __syncthreads();
   STAMP(a, 1);
   double *sR = sR0;
+  FxTiles fx{};
+  if constexpr (!PRIV) {  // the tiles' fixed-point scales from the bounds as they stand when this workgroup starts
+    const double fxb0 = __hip_atomic_load(a.fxb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double fxb1 = __hip_atomic_load(a.fxb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fx.s0 = wave_uniform(fx_scale(16.0 * fxb0, a.fx_markers));
+    fx.s1 = wave_uniform(fx_scale(32.0 * fxb1, a.fx_markers));   // |A|, |B| <= 2 (tables 2 cos, -2 sin)
+  }
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
   constexpr bool CARRY_IN = (T2 == 2) && HAS_W;
@@ -679,13 +748,13 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     if constexpr (PRIV)
       u0 = priv_sums<DIST, MODE, POW2, NM>(n0, P.x, i0, l0, sAB, sP + threadIdx.x, a);
     else
-      u0 = pred_one<DIST, MODE, POW2, NM>(n0, P.x, i0, l0, sAB, sP, a);
+      u0 = pred_one<DIST, MODE, POW2, NM>(n0, P.x, i0, l0, sAB, sP, a, fx);
     PAIR_FENCE();
     const One n1 = step_full_one<DIST, MODE, POW2, CARRY_IN>(X.y, V.y, W.y, P.y, sE0, sEh, sR, a, T.y, &i1, &l1);
     if constexpr (PRIV)
       u1 = priv_sums<DIST, MODE, POW2, NM>(n1, P.y, i1, l1, sAB, sP + threadIdx.x, a);
     else
-      u1 = pred_one<DIST, MODE, POW2, NM>(n1, P.y, i1, l1, sAB, sP, a);
+      u1 = pred_one<DIST, MODE, POW2, NM>(n1, P.y, i1, l1, sAB, sP, a, fx);
     st2t<NT>(x2 + o, n0.x, n1.x);
     if constexpr (PUSH_V) st2t<NT>(v2 + o, n0.v, n1.v);
     if constexpr (HAS_W) st2t<NT>(w2 + o, n0.w, n1.w);
@@ -705,7 +774,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     if constexpr (PRIV)
       u = priv_sums<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP + threadIdx.x, a);
     else
-      u = pred_one<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP, a);
+      u = pred_one<DIST, MODE, POW2, NM>(n, p, ic, lc, sAB, sP, a, fx);
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
   }
   STAMP_LOOP(a, 2);
@@ -733,30 +802,25 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   if (threadIdx.x < 2 * np1) {
     const int g = threadIdx.x / np1, k = threadIdx.x - g * np1;
     const int to = (nx + g) % nx;
-#ifdef PIC1DP_TUNE_FXTILES
-    if (g == 0 || to != 0 || nx > 1)
+    if (g == 0 || to != 0 || nx > 1)   // (64-bit integers: the fixed-point sums)
       __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&sP[to * np1 + k]),
                              static_cast<unsigned long long>(__double_as_longlong(sP[(nx + g) * np1 + k])), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-    if (g == 0 || to != 0 || nx > 1) lds_add(&sP[to * np1 + k], sP[(nx + g) * np1 + k]);
-#endif
   }
   __syncthreads();
   {
+    const double q0 = 1.0 / fx.s0, q1 = 1.0 / fx.s1;   // (powers of two: exact; 1 / inf = 0 with nothing in the tiles)
     const int rot = static_cast<int>((static_cast<long long>(blockIdx.x) * nx) / gridDim.x);
     for (int i = threadIdx.x; i < np1 * nx; i += blockDim.x) {
       const int k = i / nx;
       int c = i - k * nx + rot;
       if (c >= nx) c -= nx;
-#ifdef PIC1DP_TUNE_FXTILES
-      const double val = static_cast<double>(__double_as_longlong(sP[c * np1 + k])) * (k == 0 ? 1.0 / FX_S0 : 1.0 / FX_S1);
-#else
-      const double val = sP[c * np1 + k];
-#endif
-      if (val != 0.0) glb_add(&a.pred[static_cast<size_t>(k) * nx + c], val);
+      const long long fixed = __double_as_longlong(sP[c * np1 + k]);
+      if (fixed != 0) glb_add(&a.pred[static_cast<size_t>(k) * nx + c], static_cast<double>(fixed) * (k == 0 ? q0 : q1));
     }
   }
+  fx_raise(a.fxb, fx.mx0);       // the bounds follow the markers (every wave for itself: no barrier, rarely an atomic)
+  fx_raise(a.fxb + 1, fx.mx1);
   STAMP(a, 5);
 }
 
@@ -776,7 +840,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
 //   (ModeField: the same bits as a staged tile of Eh).
 // LDS: E0, A, B, rho = 4 tiles (128 KiB at nx = 4096).  The six accumulators and the extra gathers cost
 // registers (101-117 VGPRs for the exp-bearing distributions: four waves per SIMD), which is why k_step_one
-// stays the kernel wherever its tiles fit (DESIGN.md 3.2a, profiles/r02/experiments/pred_six_sums_*.log).
+// stays the kernel wherever its tiles fit (DESIGN.md 2.3, profiles/r02/experiments/pred_six_sums_*.log).
 // The second sub-step's push is untouched; Eh differs from the solve of a marker-by-marker deposit by
 // rounding only, as with k_step_one.  Full-f: q = p, K1 = K2 = 0.
 // ---------------------------------------------------------------------------

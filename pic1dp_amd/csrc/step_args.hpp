@@ -31,6 +31,8 @@ struct StepArgsDev {
   DistScale dscale;             // k_step_full<DIAG, FX>
   int diag_fx;
   int dyn_tail;                 // sixteenths of a workgroup's chunks drawn from an LDS counter
+  double *fxb;                  // k_step_one's tiles: [2] bounds on |q|, |c| of this species (kernels_step.hip FxTiles)
+  double fx_markers, fx_cap;    // ... the most markers one workgroup of this launch takes, and 2^61 over it
 #ifdef PIC1DP_TUNE_STAMPS  // tuning build (tools/stamp_probe.sh): [gridDim][8] wall-clock stamps of the phases of a workgroup
   unsigned long long *stamps;
 #endif

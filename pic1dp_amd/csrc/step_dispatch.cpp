@@ -1,5 +1,7 @@
 // step_dispatch.cpp -- launch_step: the arguments of a whole-step launch in their device form, handed to the
 // translation unit of the species' distribution (kernels_step.hip, one object per PIC1DP_STEP_DIST)
+#include <algorithm>
+
 #include "step_args.hpp"
 
 namespace pic1dp {
@@ -35,6 +37,13 @@ hipError_t launch_step(const StepArgs &a, bool full, const LaunchCfg &lc, hipStr
   d.fused = a.fused;
   d.tail = a.tail;
   d.dyn_tail = a.dyn_tail;
+  d.fxb = a.fxb;
+  {  // rows of pairs a workgroup takes (static grid stride; the drawn chunks are its own rows), two markers a pair
+    const int64_t npair = a.np >> 1, stride = static_cast<int64_t>(lc.blocks) * lc.threads;
+    // (at least 4096: a term times its scale then stays below 2^49, inside the 2^51 the conversion's magic number covers)
+    d.fx_markers = std::max(4096.0, 2.0 * static_cast<double>((npair + stride - 1) / stride) * lc.threads + 2.0);
+    d.fx_cap = 0x1p61 / d.fx_markers;
+  }
   d.dscale = a.dscale;
   d.diag_fx = a.diag_fx;
   // full-f evaluates no f0 derivative: one instantiation (in the DIST 0 unit) serves every distribution

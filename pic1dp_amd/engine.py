@@ -227,7 +227,7 @@ class Pic1dp:
 
     def check_state(self, deep=True):
         """debugging aid: the relations between the flags of the library's state machine that hold between any two
-        calls (DESIGN.md 3.9); deep also looks at the device's accumulator sets.  Raises Pic1dpError naming the
+        calls (DESIGN.md 0); deep also looks at the device's accumulator sets.  Raises Pic1dpError naming the
         relation that does not hold."""
         check(self.L.pic1dp_hip_check_state(self._ctx, 1 if deep else 0))
 

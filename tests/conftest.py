@@ -24,7 +24,7 @@ def oracle_mod():
 
 def _check_state_after_every_call(cls):
     """every public method of the engine is followed by pic1dp_hip_check_state (host side only: no device work, no
-    synchronisation): the relations between the flags of the library's state machine (DESIGN.md 3.9) are asserted at
+    synchronisation): the relations between the flags of the library's state machine (DESIGN.md 0) are asserted at
     every API boundary of every test, not only where a wrong result would show"""
     import functools
     import inspect

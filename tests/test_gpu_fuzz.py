@@ -24,7 +24,7 @@ def seeds(n):
 
 class Checked:
     """an engine whose every call is followed by pic1dp_hip_check_state(deep): the relations between the flags of the
-    state machine (DESIGN.md 3.9) and the zeroness of the accumulator sets nobody owes anything to, asserted at
+    state machine (DESIGN.md 0) and the zeroness of the accumulator sets nobody owes anything to, asserted at
     every API boundary of a random call sequence"""
 
     def __init__(self, eng):
@@ -198,7 +198,7 @@ def test_random_call_sequences_lazy_equals_eager(amd, monkeypatch, seed):
 @pytest.mark.parametrize("kind", [1, 2], ids=["tiles", "sums"])
 @pytest.mark.parametrize("seed", seeds(10))
 def test_random_call_sequences_predicted_equals_two_pass(amd, monkeypatch, seed, kind):
-    """differential test of the state machine behind the one-pass step (DESIGN.md 3.9: state_version,
+    """differential test of the state machine behind the one-pass step (DESIGN.md 0: state_version,
     field_version, pred_version, eh_*, t2_version, cd_lazy, lz): random VALID sequences of every entry point that
     reads, bumps or voids one of them -- step(n), substep, the three call sites, the split-phase deposit
     (charge_local / charge_reduced), set_chargeden, set_electric, set_field_solver, diagnostics, downloads --

@@ -768,3 +768,51 @@ def test_chunks_drawn_from_the_lds_counter(oracle_mod, amd, monkeypatch, tuning,
     ga, gb = a.particles_download(), b.particles_download()
     for k in "xvw":
         assert np.max(np.abs(ga[k] - gb[k])) < 1e-11 * max(1.0, np.max(np.abs(gb[k]))), k
+
+
+@pytest.mark.parametrize("case", ["two_stream1_singular", "field_jump", "no_perturbation", "full_f"])
+def test_fixed_point_prediction_tiles_and_their_double_path(oracle_mod, amd, monkeypatch, case):
+    """round 6: the prediction tiles (two kept modes) are 64-bit fixed-point sums in the LDS, scaled from
+    per-species bounds on |w| and |c| that the host seeds from the markers it loads and the kernels raise; a marker beyond 16x
+    its bound adds its terms straight into the global accumulators in doubles.  Cases that take that path: two-stream1's
+    -f0'/f0 = v - 2/v near v = 0; a field set by the host that makes the weights jump by orders of magnitude within a step;
+    a species without any perturbation (no bound at all: zeros are skipped); and full-f (q = p, one slice).  Every step's
+    field energy against the two-pass engine 1e-11 and against the oracle 1e-10."""
+    kw = dict(nparticle_max=N, nx=96, nmode=2, modes=[1, 3], init_nmode=2, init_mode=[1, 3], init_mode_cos=[0.0, 2e-6],
+              init_mode_sin=[1e-5, 0.0])
+    if case == "two_stream1_singular":
+        kw.update(iptcldist=1, species_density=[1.0])
+    elif case == "field_jump":
+        kw.update(linear=1)           # (the linearised equations: the jump scales the weights, the orbits stay what they are)
+    elif case == "no_perturbation":
+        kw.update(init_mode_cos=[0.0, 0.0], init_mode_sin=[0.0, 0.0])
+    elif case == "full_f":
+        kw.update(deltaf=0, iptcldist=0, species_density=[1.0], species_v0=[0.0])
+    a = engine(amd, monkeypatch, True, 1, **kw)
+    b = engine(amd, monkeypatch, False, **kw)
+    assert a.predict_kind() == 1 and b.predict_kind() == 0
+    sim = oracle_mod.Sim(oracle_mod.make_input(**kw))
+    assert sim.load() == 0
+    sim.collect_charge()
+    sim.solve_field()
+    a.kernel_stats_enable(True)
+    nsteps = 30
+    eo = []
+    for it in range(nsteps):
+        if case == "field_jump" and it == 10:     # the weights of every marker grow by ~1e7 in this step
+            E = 1e3 * np.sin(2 * np.pi * np.arange(96) / 96)
+            for e in (a, b):
+                e.set_electric(E)
+            sim.set_field(E)
+        a.step(1)
+        b.step(1)
+        sim.step(1)
+        eo.append(sim.field_energy())
+    ea, eb, eo = a.energy_history(), b.energy_history(), np.array(eo)
+    scale = max(np.max(eo), 1e-300)
+    assert np.max(np.abs(ea - eb)) <= 1e-11 * scale
+    assert np.max(np.abs(ea - eo)) <= 1e-10 * scale
+    assert a.kernel_stats(6)[1] >= nsteps - 3        # one pass per step all along (the jump costs the prediction one step)
+    ga, gb = a.particles_download(), b.particles_download()
+    for k in "xvw":
+        assert np.max(np.abs(ga[k] - gb[k])) <= 1e-10 * max(1.0, np.max(np.abs(gb[k]))), k
