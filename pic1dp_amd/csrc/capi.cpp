@@ -483,8 +483,9 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     const bool private_fits = 2 * (step_one_private_lds_bytes(nx) + kStaticLds) <= kCuLds;
     // The prediction tiles cost 2 + 4 nm LDS atomics at random cells per marker.  Measured against the two passes
     // (profiles/r04/experiments/ab_kept_modes.log, 1e8 markers / nx 1024, ms per step): two kept modes 1.23 against 1.46,
-    // three 1.49 against 1.45, four 2.05 (nx 512) against 1.46 -- so the tiles serve up to two kept modes and three and
-    // more take the two passes (the three- and four-mode instantiations of round 4 were retired in round 6).
+    // three 1.49 against 1.45, four 2.05 (nx 512) against 1.46.  With the tiles as fixed-point sums (round 6: kernels_step.hip
+    // FxTiles) two kept modes run 1.06 and three 1.17 ms against the two passes' 1.40 (profiles/r06/experiments/ab_fx_tiles.log,
+    // ab_nm3.log): the tiles serve up to three kept modes, four and more take the two passes.
     if (nm <= PRED_MAX_MODES && step_one_lds_bytes(nx, nm) <= PARTICLE_LDS_CAP)
       c->pred_kind = 1;
     // (the six sums travel in the head of an nx-vector on the call-site path: nx >= 8)

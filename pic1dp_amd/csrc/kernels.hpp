@@ -264,8 +264,12 @@ struct StepArgs {
   int dyn_tail;      // every whole-step kernel: sixteenths of a workgroup's chunks that its waves draw from an LDS counter (0: all dealt)
   double *fxb;       // pred_kind 1: [2] device bounds on |q|, |c| of this species, for the tiles' fixed-point sums
 };
-constexpr int PRED_MAX_MODES = 2;  // kept modes k_step_one's prediction tiles are instantiated for (1, 2; three and four were
-                                    // built in round 4 and lost to the two passes by measurement: HISTORY.md)
+#ifndef PIC1DP_PRED_MAX_MODES
+#define PIC1DP_PRED_MAX_MODES 3
+#endif
+constexpr int PRED_MAX_MODES = PIC1DP_PRED_MAX_MODES;  // kept modes k_step_one's prediction tiles are instantiated for: 1 ... 3.  (Round 4
+                                    // built three and four with double sums and lost to the two passes; with the fixed-point
+                                    // sums of round 6 three win -- 1.20 against 1.40 ms at 1e8 markers --, four were not rebuilt)
 // pred_kind 2: the six sums (padded to 8) are kept in this many copies -- workgroup b of the marker kernel adds into
 // copy b % PRED_SUM_COPIES, the field kernels add the copies up: six addresses shared by all workgroups serialise
 constexpr int PRED_SUM_COPIES = 16;

@@ -1080,12 +1080,18 @@ hipError_t launch_step_kernel(K kern, const StepArgsDev &d0, const LaunchCfg &lc
 #ifdef PIC1DP_TUNING
 template <int DIST>
 constexpr bool kCarryBuilt = true;
+template <int DIST>
+constexpr bool kNoCarryBuilt = true;
 #else
 template <int DIST>
 constexpr bool kCarryBuilt = DIST == 2 || DIST == 3;
+// ... and the reference-order units (DIST 2, 3) ALWAYS carry (capi_step.cpp: carry_one), so their carry-less one-pass
+// instantiations are a tuning build's too (PIC1DP_CARRY=0): a third of those two units, the largest of the library
+template <int DIST>
+constexpr bool kNoCarryBuilt = !(DIST == 2 || DIST == 3);
 #endif
 
-static_assert(PRED_MAX_MODES == 2, "k_step_one is instantiated for one and two kept modes");
+static_assert(PRED_MAX_MODES == 2 || PRED_MAX_MODES == 3, "k_step_one is instantiated for one and two (three) kept modes");
 static_assert(PRIV_THREADS == STEP_PRIVATE_THREADS, "slot stride of k_step_one<PRIV> = its workgroup size");
 template <int DIST, int MODE, int POW2, int NM>
 hipError_t launch_step_one(const StepArgsDev &d, int t2m, const LaunchCfg &lc, hipStream_t st) {
@@ -1095,14 +1101,16 @@ hipError_t launch_step_one(const StepArgsDev &d, int t2m, const LaunchCfg &lc, h
       if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, NM>, d, lc, st);
     }
     if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-    return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, NM>, d, lc, st);
+    if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, NM>, d, lc, st);
+    return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
   }
   if constexpr (kCarryBuilt<DIST>) {
     if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, NM>, d, lc, st);
     if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, NM>, d, lc, st);
   }
   if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-  return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, NM>, d, lc, st);
+  if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, NM>, d, lc, st);
+  return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
 }
 
 template <int DIST, int MODE, int POW2, bool CARRY = false>
@@ -1116,14 +1124,16 @@ hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc,
           if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, 1, true, true>, d, lc, st);
         }
         if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-        return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 1, true, true>, d, lc, st);
+        if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 1, true, true>, d, lc, st);
+        return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
       }
       if constexpr (kCarryBuilt<DIST>) {
         if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, 1, true, true>, d, lc, st);
         if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, 1, true, true>, d, lc, st);
       }
       if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-      return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 1, true, true>, d, lc, st);
+      if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 1, true, true>, d, lc, st);
+      return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
     }
     if (d.nt) {
       if constexpr (kCarryBuilt<DIST>) {
@@ -1131,14 +1141,16 @@ hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc,
         if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 1, 1, true>, d, lc, st);
       }
       if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-      return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 1, true>, d, lc, st);
+      if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_one<DIST, MODE, POW2, true, 0, 1, true>, d, lc, st);
+      return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
     }
     if constexpr (kCarryBuilt<DIST>) {
       if (t2m == 2) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 2, 1, true>, d, lc, st);
       if (t2m == 1) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 1, 1, true>, d, lc, st);
     }
     if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-    return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 1, true>, d, lc, st);
+    if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_one<DIST, MODE, POW2, false, 0, 1, true>, d, lc, st);
+    return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
   }
   if (full && d.pred && d.pred_nm < 0) {  // one pass per step, prediction as six sums (large grids)
     const int t2m = d.t2 ? d.t2_mode : 0;
@@ -1149,14 +1161,16 @@ hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc,
           if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1, true>, d, lc, st);
         }
         if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-        return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 0, true>, d, lc, st);
+        if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 0, true>, d, lc, st);
+        return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
       }
       if constexpr (kCarryBuilt<DIST>) {
         if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 2, true>, d, lc, st);
         if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 1, true>, d, lc, st);
       }
       if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-      return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 0, true>, d, lc, st);
+      if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 0, true>, d, lc, st);
+      return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
     }
     if (d.nt) {
       if constexpr (kCarryBuilt<DIST>) {
@@ -1164,19 +1178,23 @@ hipError_t launch_step_dmp(const StepArgsDev &d, bool full, const LaunchCfg &lc,
         if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 1>, d, lc, st);
       }
       if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-      return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 0>, d, lc, st);
+      if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, true, 0>, d, lc, st);
+      return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
     }
     if constexpr (kCarryBuilt<DIST>) {
       if (t2m == 2) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 2>, d, lc, st);
       if (t2m == 1) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 1>, d, lc, st);
     }
     if (t2m != 0) return hipErrorInvalidValue;  // (a carry this build has no kernel for)
-    return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 0>, d, lc, st);
+    if constexpr (kNoCarryBuilt<DIST>) return launch_step_kernel(k_step_sums<DIST, MODE, POW2, false, 0>, d, lc, st);
+    return hipErrorInvalidValue;  // (no carry-less kernel in this unit: its distribution always carries)
   }
   if (full && d.pred) {  // one pass per step: also predicts the next step's first-sub-step charge
     const int t2m = d.t2 ? d.t2_mode : 0;
     if (d.pred_nm == 1) return launch_step_one<DIST, MODE, POW2, 1>(d, t2m, lc, st);
     if (d.pred_nm == 2) return launch_step_one<DIST, MODE, POW2, 2>(d, t2m, lc, st);
+    if constexpr (PRED_MAX_MODES >= 3)
+      if (d.pred_nm == 3) return launch_step_one<DIST, MODE, POW2, 3>(d, t2m, lc, st);
     return hipErrorInvalidValue;  // PRED_MAX_MODES
   }
   if (full && d.dist_out) {  // with the diagnostics of output_all (their histograms as fixed-point sums where the host knows bounds)

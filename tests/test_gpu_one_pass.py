@@ -306,9 +306,9 @@ def test_prediction_is_dropped_when_it_no_longer_applies(amd, monkeypatch, kind)
 @pytest.mark.parametrize("kw,predicted", [
     (dict(nmode=2, modes=[1, 3], init_nmode=2, init_mode=[1, 3], init_mode_cos=[0.0, 2e-6], init_mode_sin=[1e-5, 0.0]), True),
     (dict(nmode=3, modes=[1, 2, 5], init_nmode=3, init_mode=[1, 2, 5], init_mode_cos=[0.0, 2e-6, 1e-6],
-          init_mode_sin=[1e-5, 0.0, 3e-6]), False),             # three and more kept modes: two passes (the tiles are built
+          init_mode_sin=[1e-5, 0.0, 3e-6]), True),              # three kept modes: tiles too (fixed-point sums, round 6)
     (dict(nmode=4, modes=[1, 2, 3, 7], init_nmode=2, init_mode=[1, 7], init_mode_cos=[0.0, 2e-6], init_mode_sin=[1e-5, 0.0]), False),
-    (dict(nmode=5, modes=[1, 2, 3, 4, 5]), False),              # for one and two: round 4's three / four lost by measurement)
+    (dict(nmode=5, modes=[1, 2, 3, 4, 5]), False),              # four and more kept modes: two passes
     (dict(nspecies=2, iptcldist=0, species_charge=[-1.0, 1.0], species_mass=[1.0, 25.0], species_temperature=[1.0, 0.5],
           species_temperature2=[1.0, 1.0], species_density=[1.0, 1.0], species_v0=[0.0, 0.0], lx=4 * np.pi), True),
     (dict(nx=4096), True),                                      # eight tiles of 32 KiB do not fit the LDS: six sums
@@ -323,7 +323,7 @@ def test_prediction_is_dropped_when_it_no_longer_applies(amd, monkeypatch, kind)
 def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind):
     kw = dict(dict(nparticle_max=N, nx=96), **kw)
     if kind == 2 and kw.get("nmode", 1) in (2, 3, 4) and kw["nx"] < 4096:
-        pytest.skip("two to four kept modes: the tiles' case")
+        pytest.skip("two to four kept modes: the tiles' case (or two passes)")
     a = engine(amd, monkeypatch, True, kind, **kw)
     assert a.predict_kind() == (0 if not predicted else 2 if (kind == 2 or kw["nx"] == 4096) else 1)
     b = engine(amd, monkeypatch, False, **kw)
@@ -342,9 +342,11 @@ def test_one_pass_modes_species_fallbacks(amd, monkeypatch, kw, predicted, kind)
 @pytest.mark.parametrize("kw,kind", [
     (dict(nx=2542), 1), (dict(nx=2543), 2),                                   # the last grid the tiles hold, the first for the sums
     (dict(nx=1694, nmode=2, modes=[1, 3]), 1), (dict(nx=1695, nmode=2, modes=[1, 3]), 0),
-    (dict(nx=512, nmode=4, modes=[1, 2, 3, 5]), 0),                           # three and more kept modes: two passes
+    (dict(nx=1270, nmode=3, modes=[1, 2, 5]), 1), (dict(nx=1271, nmode=3, modes=[1, 2, 5]), 0),
+    (dict(nx=512, nmode=4, modes=[1, 2, 3, 5]), 0),                           # four and more kept modes: two passes
     (dict(nx=5063), 2), (dict(nx=5064), 0)],                                  # the last grid for the sums, then two passes
-    ids=["tiles_last", "sums_first", "two_modes_last", "two_modes_beyond", "four_modes_two_passes", "sums_last", "beyond"])
+    ids=["tiles_last", "sums_first", "two_modes_last", "two_modes_beyond", "three_modes_last", "three_modes_beyond",
+         "four_modes_two_passes", "sums_last", "beyond"])
 def test_one_pass_at_the_lds_limits(amd, monkeypatch, kw, kind):
     """the grids at which the one-pass kernels' LDS tiles just fit and just do not (kernels.hpp step_one_lds_bytes,
     step_sums_lds_bytes against PARTICLE_LDS_CAP): the choice, and the run against the two-pass engine"""
@@ -599,10 +601,10 @@ def test_fused_solve_with_output_steps(oracle_mod, amd, monkeypatch):
 @pytest.mark.parametrize("modes", [[1, 2, 3], [1, 2, 3, 5]], ids=["three_modes", "four_modes"])
 @pytest.mark.parametrize("mname,mkw", MODES, ids=[m[0] for m in MODES])
 def test_three_and_four_kept_modes_against_oracle(oracle_mod, amd, monkeypatch, modes, mname, mkw):
-    """the reference allows any input_nmode (src/pic1dp_input.F90:75-80).  With three and four kept modes
-    a step is the two passes (k_step_half + k_step_full; the prediction tiles built for them in round 4 measured slower,
-    profiles/r04/experiments/ab_kept_modes.log, and were retired in round 6) -- also when the tiles are asked for by name --
-    against the oracle directly: field energy at every one of 80 steps within 1e-10, the field and the markers at the end"""
+    """the reference allows any input_nmode (src/pic1dp_input.F90:75-80).  Three kept modes are ONE pass
+    per step (prediction tiles R0, RA_m, RB_m as fixed-point sums: round 6, 1.20 against the two passes' 1.40 ms at 1e8
+    markers, profiles/r06/experiments/ab_nm3.log), four the two passes (k_step_half + k_step_full) -- against the oracle
+    directly: field energy at every one of 80 steps within 1e-10, the field and the markers at the end"""
     nm = len(modes)
     kw = dict(nparticle_max=N, nx=128, nmode=nm, modes=modes, init_nmode=nm, init_mode=modes,
               init_mode_cos=[0.0, 2e-6, 1e-6, 5e-7][:nm], init_mode_sin=[1e-5, 3e-6, 0.0, 2e-6][:nm], **mkw)
@@ -612,8 +614,8 @@ def test_three_and_four_kept_modes_against_oracle(oracle_mod, amd, monkeypatch, 
     assert sim.load() == 0
     sim.collect_charge()
     sim.solve_field()
-    eng = engine(amd, monkeypatch, True, 1, **kw)
-    assert eng.predict_kind() == 0           # no one-pass kernel for three and more kept modes, asked for or not
+    eng = engine(amd, monkeypatch, True, None, **kw)
+    assert eng.predict_kind() == (1 if nm == 3 else 0)           # the library's own choice
     eng.kernel_stats_enable(True)
     nsteps = 80
     eo = []
@@ -622,7 +624,10 @@ def test_three_and_four_kept_modes_against_oracle(oracle_mod, amd, monkeypatch, 
         eo.append(sim.field_energy())
     eng.step(nsteps)
     assert np.max(np.abs(eng.energy_history() / np.array(eo) - 1.0)) < 1e-10
-    assert eng.kernel_stats(3)[1] == nsteps and eng.kernel_stats(4)[1] == nsteps and eng.kernel_stats(6)[1] == 0
+    if nm == 3:
+        assert eng.kernel_stats(3)[1] == 1 and eng.kernel_stats(6)[1] == nsteps and eng.kernel_stats(4)[1] == 0
+    else:
+        assert eng.kernel_stats(3)[1] == nsteps and eng.kernel_stats(4)[1] == nsteps and eng.kernel_stats(6)[1] == 0
     f = eng.get_field()
     so = sim.get_field()
     assert relerr(f["electric"], so[0]) < 1e-10
