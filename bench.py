@@ -504,6 +504,11 @@ def main():
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus))            # before anything of this process has touched the GPU
     global pic1dp_amd
+    # (tests) PIC1DP_BENCH_ENGINE=<dir>: a stand-in for the pic1dp_amd package (tests/fake_engine) -- the control plane of an
+    # N-rank run rehearsed on CPUs at rank counts the GPU box cannot host; the line then says so in "data"
+    fake_engine = os.environ.get("PIC1DP_BENCH_ENGINE")
+    if fake_engine:
+        sys.path.insert(0, fake_engine)
     import pic1dp_amd       # loads libpic1dp_hip.so first: one HIP runtime per process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -919,7 +924,7 @@ def main():
             "value_note": "median of %d back-to-back timed blocks of %d steps each (every block bracketed by barrier + "
                           "device sync, max over ranks); kernel averages are over all blocks" % (repeats, a.steps),
             "scaling": "strong" if (strong_cfg or headline_strong) else "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not fake_engine else "NOT A MEASUREMENT: stand-in engine (%s), control-plane rehearsal" % fake_engine,
             "speedup_basis": (("value(N) / value(1) is the STRONG-scaling speed-up: the same %g markers in total on 1, 2, 4, 8 "
                                "GPUs -- the curve north_star's '>= 6x from 1 -> 8 GPUs' is judged on; the weak reading (%g "
                                "markers per GPU) is weak_per_gpu, measured in this run with the same charge sum")
