@@ -1148,7 +1148,9 @@ int pic1dp_hip_charge_local(pic1dp_ctx *c, double *charge2) {
   CHECK_CTX(c);
   if (!charge2) return fail(PIC1DP_ERR_ARG, "null array");
   if (int rc = require_loaded_keep_lazy(c)) return rc;
-  if (c->owed == Owed::AdoptHalfField)   // (left over by an inspection that settled a pair before its solve_field: void now)
+  if (pair_of(c->seq) && c->seq != Seq::Push2PairSolved)  // out of sequence (as in collect_charge): memory as the eager calls leave it
+    if (int rc = settle_half_pair(c)) return rc;
+  if (c->owed == Owed::AdoptHalfField)   // (left over by a pair settled before its solve_field: void now)
     if (int rc = set_owed(c, Owed::Nothing)) return rc;
   if (c->seq == Seq::Push1 && pred_usable(c)) {  // predicted by the previous step's kernel: no marker pass
     HIP_TRY(hipMemcpyAsync(c->d_E0, c->d_E, sizeof(double) * c->in.nx, hipMemcpyDeviceToDevice, c->st));

@@ -156,7 +156,8 @@ def test_random_call_sequences_lazy_equals_eager(amd, monkeypatch, seed):
         if r < 0.70:
             op = ops[i % 6]
         else:
-            op = str(rng.choice(["push1", "push2", "collect", "solve", "setE", "look", "bak", "sums", "dist", "optimize"]))
+            op = str(rng.choice(["push1", "push2", "collect", "solve", "setE", "look", "bak", "sums", "dist", "optimize",
+                                 "hostsum", "setcd"]))      # (round 6: the split-phase deposit and a host's own charge density, anywhere)
         pushes = [o for o in log if o in ("push1", "push2")]
         if op == "push2" and not (pushes and pushes[-1] == "push1"):
             op = "push1"       # push(2) without a push(1) before it reads an undefined RK backup
@@ -192,6 +193,13 @@ def test_random_call_sequences_lazy_equals_eager(amd, monkeypatch, seed):
         elif op == "optimize":
             for e in (a, b):
                 e.particle_optimize(2)
+        elif op == "hostsum":                   # a host that owns the reduction: charge_local / charge_reduced in place of collect_charge
+            for e in (a, b):
+                e.charge_reduced(e.charge_local())
+        elif op == "setcd":
+            cd = b.get_field()["chargeden"]
+            for e in (a, b):
+                e.set_chargeden(cd)
     same("end: " + " ".join(log[-8:]))
 
 
@@ -294,7 +302,12 @@ def test_random_call_sequences_predicted_equals_two_pass(amd, monkeypatch, seed,
             for e in (a, b):
                 e.set_electric(E)
         elif op == "sums":
-            assert np.allclose(a.energy_sums(), b.energy_sums(), rtol=1e-9, atol=0)
+            # (sum v^2 w cancels -- w has both signs --, so its bar is that of its TERMS: the markers agree to TOL of max |w|,
+            # hence the sum to TOL * sum v^2 * max |w|; found flaking once in 4 320 seeds against a bar relative to the sum itself)
+            sa, sb = a.energy_sums(), b.energy_sums()
+            wmax = float(np.max(np.abs(b.particles_download()["w"])))
+            assert np.allclose(sa[:2], sb[:2], rtol=1e-9, atol=0)
+            assert abs(sa[2] - sb[2]) <= 1e-9 * abs(sb[2]) + TOL * sb[0] * wmax, (sa, sb, wmax)
         elif op == "dist":
             da, db = a.ptcldist(0, finish=False), b.ptcldist(0, finish=False)
             assert np.allclose(da["markr_xv"], db["markr_xv"], rtol=1e-9, atol=1e-9)
