@@ -683,22 +683,28 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     sEh[nx] = a.Eh[0];
   }
   unsigned *sDraw = reinterpret_cast<unsigned *>(PRIV ? sP + NS * PT : sP + np1 * (nx + 2));  // the chunk counter of the drawn tail
+  FxTiles fx{};
   if constexpr (PRIV) {
     for (int k = 0; k < NS; ++k) sP[k * PT + threadIdx.x] = 0.0;
   } else {
+    // The tiles' fixed-point scales from the bounds as they stand when this WORKGROUP starts: read by ONE thread and handed
+    // to the others through the LDS.  (Every thread reading them for itself was a race: the workgroups that finish first
+    // raise the bounds while later ones start, two waves of one workgroup could see different values and add into the same
+    // tile in different units -- found by the suite on a tuning build, one case in 596, energies off by 3e-4.)
+    if (threadIdx.x == 0) {
+      sP[0] = __hip_atomic_load(a.fxb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sP[1] = __hip_atomic_load(a.fxb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    fx.s0 = wave_uniform(fx_scale(16.0 * sP[0], a.fx_markers));
+    fx.s1 = wave_uniform(fx_scale(32.0 * sP[1], a.fx_markers));   // |A|, |B| <= 2 (tables 2 cos, -2 sin)
+    __syncthreads();
     for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
   }
   if (threadIdx.x == 0) *sDraw = 0u;
   __syncthreads();
   STAMP(a, 1);
   double *sR = sR0;
-  FxTiles fx{};
-  if constexpr (!PRIV) {  // the tiles' fixed-point scales from the bounds as they stand when this workgroup starts
-    const double fxb0 = __hip_atomic_load(a.fxb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double fxb1 = __hip_atomic_load(a.fxb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    fx.s0 = wave_uniform(fx_scale(16.0 * fxb0, a.fx_markers));
-    fx.s1 = wave_uniform(fx_scale(32.0 * fxb1, a.fx_markers));   // |A|, |B| <= 2 (tables 2 cos, -2 sin)
-  }
   constexpr bool HAS_W = (MODE != MODE_FULLF);
   constexpr bool PUSH_V = (MODE != MODE_DF_LIN);
   constexpr bool CARRY_IN = (T2 == 2) && HAS_W;
