@@ -297,7 +297,11 @@ __device__ __forceinline__ double pred_coef(double v, double w, double p, double
 // rounding (the rho tile, whose sums are the reference's charge, stays in doubles).  Two kept modes at 1e8 markers:
 // kernel 1.235 -> 1.08 ms (profiles/r06/experiments/ab_fx_tiles*.log).
 //   * fxb[0], fxb[1] (device, per species): bounds on |q| (w, or p in full-f) and on |c| = dt/2 |p - w| |f0'/f0| |Z/m| -- seeded
-//     by the host from the markers it loads, raised by the kernels to the largest value they meet (atomic max, monotone);
+//     by the host from the markers it loads and raised by the kernels (atomic max, monotone) to the largest value met AMONG
+//     THE MARKERS THAT WENT THE FIXED-POINT WAY: the population's growth moves them, an outlier never does (one marker of
+//     two-stream1 at v = 1e-9 would otherwise coarsen everybody's quantum by nine orders of magnitude, for good).  A
+//     workgroup that finds NOT ONE of its markers within a bound -- the whole population has jumped: a field set by the host
+//     -- raises that bound 256-fold per launch until the markers fit again;
 //   * a term within 16x its bound (to be precise: below the cap the power-of-two scale leaves) is rounded ONCE to a power-of-two quantum chosen such that a workgroup's sums stay below
 //     2^61 (about 2^-41 of the bound at 2e5 markers per workgroup: 1e-13 of a cell's sum), the sums themselves are exact and
 //     independent of the atomics' order;
@@ -306,7 +310,8 @@ __device__ __forceinline__ double pred_coef(double v, double w, double p, double
 struct FxTiles {
   double s0, s1;      // quanta^-1 of the R0 slice and of the RA / RB slices (powers of two, wave-uniform: scalar registers; +inf with
                       // an unknown bound: every term then fails the test below and goes through the doubles)
-  float mx0, mx1;     // largest |q|, |c| this thread has met (single precision: a bound, and a register each)
+  float mx0, mx1;     // largest |q|, |c| this thread has met among the markers within the bound (single precision: a register
+                      // each); -1: markers met, none within the bound; -2: no marker met
 };
 // a value every lane holds alike, moved to scalar registers (the marker loop is at its VGPR budget)
 __device__ __forceinline__ double wave_uniform(double v) {
@@ -325,14 +330,22 @@ __device__ __forceinline__ void pred_add_fx(double *p, double v, double s) {  //
                          static_cast<unsigned long long>(__double_as_longlong(t)) - 0x4338000000000000ull, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void fx_raise(double *bound, float seen_f) {  // bound = max(bound, seen): positive doubles order as integers
+// the workgroup's view of a bound: every wave folds its threads' mx into an LDS word (floats >= -2 order as unsigned integers
+// once 3 is added), and behind the workgroup's barrier one thread raises the bound (positive doubles order as integers)
+__device__ __forceinline__ void fx_note(unsigned *slot, float seen_f) {
   for (int off = 32; off > 0; off >>= 1) seen_f = fmaxf(seen_f, __shfl_down(seen_f, off, 64));
-  if ((threadIdx.x & 63) == 0) {
-    const double seen = static_cast<double>(seen_f) * (1.0 + 0x1p-20);   // (the float was rounded to nearest: not below what was met)
-    if (seen > __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && seen < 0x1p120)
-      __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(bound), static_cast<unsigned long long>(__double_as_longlong(seen)),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if ((threadIdx.x & 63) == 0)
+    __hip_atomic_fetch_max(slot, __float_as_uint(seen_f + 3.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void fx_raise(double *bound, unsigned noted) {
+  const float seen_f = __uint_as_float(noted) - 3.0f;   // (the +3 costs nothing that matters: the value is a bound)
+  const double cur = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double want = 0.0;
+  if (seen_f >= 0.0f) want = static_cast<double>(seen_f) * (1.0 + 0x1p-18);   // (rounded twice on the way: not below what was met)
+  else if (seen_f > -1.5f && cur > 0.0) want = 256.0 * cur;                     // markers, and none of them within the bound
+  if (want > cur && want < 0x1p120)
+    __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(bound), static_cast<unsigned long long>(__double_as_longlong(want)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int DIST, int MODE, int POW2, int NM>
@@ -366,8 +379,9 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
   // a term t goes the fixed-point way if |t| s <= fx_cap = 2^61 / (markers a workgroup takes): its sums then stay in 63 bits
   if constexpr (MODE == MODE_FULLF) {
     const double aq = fabs(p);
-    fx.mx0 = fmaxf(fx.mx0, static_cast<float>(aq));
-    if (aq * fx.s0 <= a.fx_cap) {
+    const bool fixed = aq * fx.s0 <= a.fx_cap;
+    fx.mx0 = fmaxf(fx.mx0, (fixed || fx.s0 > 0x1p1000) ? static_cast<float>(aq) : -1.0f);   // (no bound yet: whatever is met)
+    if (fixed) {
       pred_add_fx(cl, wh * p, fx.s0);
       pred_add_fx(cr, wr * p, fx.s0);
     } else {
@@ -393,9 +407,10 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
     }
     const double c = tmp1 * t2 * a.pred_k;
     const double aq = fabs(n.w), ac = fabs(c);
-    fx.mx0 = fmaxf(fx.mx0, static_cast<float>(aq));
-    fx.mx1 = fmaxf(fx.mx1, static_cast<float>(ac));
-    const bool fixed = aq * fx.s0 <= a.fx_cap && 2.0 * ac * fx.s1 <= a.fx_cap;   // (|A|, |B| <= 2; false for NaN)
+    const bool ok0 = aq * fx.s0 <= a.fx_cap, ok1 = 2.0 * ac * fx.s1 <= a.fx_cap;   // (|A|, |B| <= 2; false for NaN)
+    fx.mx0 = fmaxf(fx.mx0, (ok0 || fx.s0 > 0x1p1000) ? static_cast<float>(aq) : -1.0f);   // (no bound yet: whatever is met)
+    fx.mx1 = fmaxf(fx.mx1, (ok1 || fx.s1 > 0x1p1000) ? static_cast<float>(ac) : -1.0f);
+    const bool fixed = ok0 && ok1;
     if (fixed) {
       pred_add_fx(cl, wh * n.w, fx.s0);
       pred_add_fx(cr, wr * n.w, fx.s0);
@@ -684,6 +699,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
   }
   unsigned *sDraw = reinterpret_cast<unsigned *>(PRIV ? sP + NS * PT : sP + np1 * (nx + 2));  // the chunk counter of the drawn tail
   FxTiles fx{};
+  fx.mx0 = fx.mx1 = -2.0f;
   if constexpr (PRIV) {
     for (int k = 0; k < NS; ++k) sP[k * PT + threadIdx.x] = 0.0;
   } else {
@@ -701,7 +717,7 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     __syncthreads();
     for (int i = threadIdx.x; i < np1 * (nx + 2); i += blockDim.x) sP[i] = 0.0;
   }
-  if (threadIdx.x == 0) *sDraw = 0u;
+  if (threadIdx.x == 0) sDraw[0] = sDraw[1] = sDraw[2] = 0u;   // ([1], [2]: the workgroup's view of the tiles' two bounds, fx_note)
   __syncthreads();
   STAMP(a, 1);
   double *sR = sR0;
@@ -784,6 +800,10 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
     if constexpr (CARRY_OUT) a.t2[a.np - 1] = u;
   }
   STAMP_LOOP(a, 2);
+  if constexpr (!PRIV) {
+    fx_note(sDraw + 1, fx.mx0);
+    fx_note(sDraw + 2, fx.mx1);
+  }
   __syncthreads();
   STAMP_LOOP(a, 3);
   flush_rho(sR0, a.rho, a.g);
@@ -825,8 +845,10 @@ __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepAr
       if (fixed != 0) glb_add(&a.pred[static_cast<size_t>(k) * nx + c], static_cast<double>(fixed) * (k == 0 ? q0 : q1));
     }
   }
-  fx_raise(a.fxb, fx.mx0);       // the bounds follow the markers (every wave for itself: no barrier, rarely an atomic)
-  fx_raise(a.fxb + 1, fx.mx1);
+  if (threadIdx.x == 0) {   // the bounds follow the population (rarely an atomic: they only ever grow)
+    fx_raise(a.fxb, sDraw[1]);
+    fx_raise(a.fxb + 1, sDraw[2]);
+  }
   STAMP(a, 5);
 }
 
