@@ -642,7 +642,7 @@ __device__ __forceinline__ double pred_one_private(const One &n, double p, int i
 }
 
 
-// the private sums of one marker: six for one kept mode (tuning build: twenty for two)
+// the private sums of one marker: six for one kept mode (two kept modes would take twenty: tried, HISTORY.md round 5)
 template <int DIST, int MODE, int POW2, int NM>
 __device__ __forceinline__ double priv_sums(const One &n, double p, int ix, double wl, const double *sAB, double *sS,
                                             const StepArgsDev &a) {
@@ -651,7 +651,7 @@ __device__ __forceinline__ double priv_sums(const One &n, double p, int ix, doub
 
 // T2: 0 no carry of -f0'/f0; 1 this step evaluates it, the next step's value is stored; 2 this
 // step's value is loaded (stored by the previous k_step_one), the next step's stored
-// NM: kept modes of the prediction tiles (1 .. 4); PRIV (NM = 1): six sums in thread-private slots instead
+// NM: kept modes of the prediction tiles (1 .. PRED_MAX_MODES); PRIV (NM = 1): six sums in thread-private slots instead
 template <int DIST, int MODE, int POW2, bool NT, int T2, int NM, bool PRIV = false, bool FUSED = false>
 __global__ void __launch_bounds__(1024) PIC1DP_SIX_WAVES k_step_one(const StepArgsDev a) {
   static_assert(!FUSED || PRIV, "the fused solve serves the six-sum prediction");
