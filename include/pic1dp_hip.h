@@ -536,7 +536,11 @@ int pic1dp_hip_get_stream(pic1dp_ctx *ctx, void **stream);
  * which = 12: *launches = diagnostics passes (k_ptcldist) whose (x, v) histograms were summed as
  * 64-bit fixed-point numbers in the LDS (1.9x the atomic rate of double sums; scaled by the
  * species' max |p|, max |w| of the pass before; PIC1DP_DIAG_FX=0: always doubles), *ms = how many
- * of them met a marker beyond those bounds and were repeated with double sums */
+ * of them met a marker beyond those bounds and were repeated with double sums;
+ * which = 13: *launches = terms of the one-pass kernel's prediction tiles (two and three kept modes: 64-bit
+ * fixed-point LDS sums scaled by per-species bounds that follow the markers) that lay beyond 16x their bound and
+ * were added in doubles straight into the global accumulators -- rare by design, a count that grows with every
+ * step says the bounds have lost the population; *ms = the first species' bound on |q| as it stands (waits for the stream) */
 int pic1dp_hip_kernel_stats(pic1dp_ctx *ctx, int32_t which, double *ms,
                             int64_t *launches);
 int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *ctx, int32_t on);

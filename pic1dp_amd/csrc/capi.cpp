@@ -427,8 +427,8 @@ int pic1dp_hip_create(const pic1dp_input *in, const pic1dp_layout *layout, pic1d
     // the first sub-step call that needs it (ensure_second_set) -- pic1dp_hip_step
     // never does
     HIP_TRY_C(hipMalloc(&S.slab[0], sizeof(double) * static_cast<size_t>(slab_doubles(nalloc + 2))));
-    HIP_TRY_C(hipMalloc(&S.fxb, 2 * sizeof(double)));
-    HIP_TRY_C(hipMemsetAsync(S.fxb, 0, 2 * sizeof(double), c->st));
+    HIP_TRY_C(hipMalloc(&S.fxb, 4 * sizeof(double)));   // two bounds, a 64-bit count (kernel_stats 13), one word spare
+    HIP_TRY_C(hipMemsetAsync(S.fxb, 0, 4 * sizeof(double), c->st));
     const int64_t as = slab_array_stride(nalloc + 2);
     S.set[0].x = S.slab[0];
     S.set[0].v = S.slab[0] + as;
@@ -755,7 +755,10 @@ int pic1dp_hip_particle_load(pic1dp_ctx *c) {
   }
   (void)hipHostFree(stage);
   if (rc) return rc;
-  for (int s = 0; s < ns; ++s) HIP_TRY(hipMemcpy(c->sp[s].fxb, &fxb[2 * static_cast<size_t>(s)], 2 * sizeof(double), hipMemcpyHostToDevice));
+  for (int s = 0; s < ns; ++s) {
+    HIP_TRY(hipMemcpy(c->sp[s].fxb, &fxb[2 * static_cast<size_t>(s)], 2 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(c->sp[s].fxb + 2, 0, 2 * sizeof(double)));   // (the count of terms past the bounds starts over)
+  }
   c->rng_ready = true;
   std::fill(c->diag_max_p.begin(), c->diag_max_p.end(), 0.0);  // (new markers: the fixed-point diagnostics' bounds are void)
   std::fill(c->diag_max_w.begin(), c->diag_max_w.end(), 0.0);
@@ -1108,7 +1111,23 @@ int pic1dp_hip_kernel_stats_enable(pic1dp_ctx *c, int32_t on) {
 
 int pic1dp_hip_kernel_stats(pic1dp_ctx *c, int32_t which, double *ms, int64_t *launches) {
   CHECK_CTX(c);
-  if (which < 0 || which > 12) return fail(PIC1DP_ERR_ARG, "which must be 0..12");
+  if (which < 0 || which > 13) return fail(PIC1DP_ERR_ARG, "which must be 0..13");
+  if (which == 13) {  // prediction tiles: terms that went past the fixed-point sums (beyond 16x the bound); *ms: the first species' bound on |q|
+    HIP_TRY(hipStreamSynchronize(c->st));
+    int64_t n = 0;
+    double b0 = 0.0;
+    for (size_t s = 0; s < c->sp.size(); ++s) {
+      double h[3] = {0.0, 0.0, 0.0};
+      HIP_TRY(hipMemcpy(h, c->sp[s].fxb, sizeof h, hipMemcpyDeviceToHost));
+      int64_t k;
+      std::memcpy(&k, &h[2], sizeof k);
+      n += k;
+      if (s == 0) b0 = h[0];
+    }
+    if (launches) *launches = n;
+    if (ms) *ms = b0;
+    return PIC1DP_OK;
+  }
   if (which == 12) {  // diagnostics passes with 64-bit fixed-point histogram sums; *ms: of them, repeated in doubles (overflow)
     if (ms) *ms = static_cast<double>(c->diag_fx_repeats);
     if (launches) *launches = c->diag_fx_passes;

@@ -330,19 +330,24 @@ __device__ __forceinline__ void pred_add_fx(double *p, double v, double s) {  //
                          static_cast<unsigned long long>(__double_as_longlong(t)) - 0x4338000000000000ull, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// the workgroup's view of a bound: every wave folds its threads' mx into an LDS word (floats >= -2 order as unsigned integers
-// once 3 is added), and behind the workgroup's barrier one thread raises the bound (positive doubles order as integers)
+// the workgroup's view of a bound: every wave folds its threads' mx into an LDS word as an integer CODE that orders like the
+// values -- 0: no marker met, 1: markers met and none within the bound, 2 + the bits of the float (non-negative floats order as
+// their bits) -- and behind the workgroup's barrier one thread raises the bound (positive doubles order as integers).
+// (The code is exact: the weights of a delta-f run are ~1e-11 of order one at 1e8 markers, an encoding that shifted the
+// value, mx + 3, rounded all of them to "0" and the bound never followed a growing mode.)
 __device__ __forceinline__ void fx_note(unsigned *slot, float seen_f) {
   for (int off = 32; off > 0; off >>= 1) seen_f = fmaxf(seen_f, __shfl_down(seen_f, off, 64));
-  if ((threadIdx.x & 63) == 0)
-    __hip_atomic_fetch_max(slot, __float_as_uint(seen_f + 3.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned code = seen_f >= 0.0f ? __float_as_uint(seen_f) + 2u : (seen_f > -1.5f ? 1u : 0u);
+    __hip_atomic_fetch_max(slot, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
 }
 __device__ __forceinline__ void fx_raise(double *bound, unsigned noted) {
-  const float seen_f = __uint_as_float(noted) - 3.0f;   // (the +3 costs nothing that matters: the value is a bound)
+  if (noted == 0u) return;
   const double cur = __hip_atomic_load(bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   double want = 0.0;
-  if (seen_f >= 0.0f) want = static_cast<double>(seen_f) * (1.0 + 0x1p-18);   // (rounded twice on the way: not below what was met)
-  else if (seen_f > -1.5f && cur > 0.0) want = 256.0 * cur;                     // markers, and none of them within the bound
+  if (noted >= 2u) want = static_cast<double>(__uint_as_float(noted - 2u)) * (1.0 + 0x1p-18);   // (rounded twice on the way: not below what was met)
+  else if (cur > 0.0) want = 256.0 * cur;                                                        // markers, and none of them within the bound
   if (want > cur && want < 0x1p120)
     __hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(bound), static_cast<unsigned long long>(__double_as_longlong(want)),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -375,6 +380,8 @@ __device__ __forceinline__ double pred_one(const One &n, double p, int ix, doubl
     gr_c = gr_c >= nx ? gr_c - nx : gr_c;   // (nx = 1: cell nx + 1 is cell 0 as well)
     if (vl != 0.0) glb_add(a.pred + static_cast<size_t>(k) * nx + gl_c, vl);   // (zeros: a species without perturbation has no bound)
     if (vr != 0.0) glb_add(a.pred + static_cast<size_t>(k) * nx + gr_c, vr);
+    if (vl != 0.0 || vr != 0.0)   // counted (pic1dp_hip_kernel_stats 13): a run whose count keeps growing has lost its bounds
+      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.fxb + 2), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // a term t goes the fixed-point way if |t| s <= fx_cap = 2^61 / (markers a workgroup takes): its sums then stay in 63 bits
   if constexpr (MODE == MODE_FULLF) {

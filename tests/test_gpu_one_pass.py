@@ -821,3 +821,31 @@ def test_fixed_point_prediction_tiles_and_their_double_path(oracle_mod, amd, mon
     ga, gb = a.particles_download(), b.particles_download()
     for k in "xvw":
         assert np.max(np.abs(ga[k] - gb[k])) <= 1e-10 * max(1.0, np.max(np.abs(gb[k]))), k
+
+
+@pytest.mark.gpu
+def test_fixed_point_bounds_follow_a_growing_mode(amd, monkeypatch):
+    """The tiles' bounds have to follow weights of the size a run has -- ~1e-10 here (p ~ lx 16 f0 / N, w = 1e-7 p), 1e-11 at
+    1e8 markers -- as an unstable mode multiplies them: a bound that stays behind sends more and more markers through the
+    double path (global atomics: correct and slow).  (Found by reading: the workgroup's maximum travelled as float(mx + 3),
+    which is 3 for every weight below 1e-7.)  kernel_stats 13 counts the terms that went the double path."""
+    kw = dict(nparticle_max=N, nx=64, nmode=2, modes=[1, 2], init_nmode=1, init_mode=[1], init_mode_cos=[0.0],
+              init_mode_sin=[1e-7], linear=1, dt=0.2)
+    a = engine(amd, monkeypatch, True, 1, **kw)
+    b = engine(amd, monkeypatch, False, **kw)
+    assert a.predict_kind() == 1
+    w0 = np.max(np.abs(a.particles_download()["w"]))
+    bound0, slow0 = a.kernel_stats(13)
+    assert slow0 == 0 and w0 <= bound0 <= 1.01 * w0 and w0 < 1e-8
+    a.kernel_stats_enable(True)
+    nsteps = 300
+    a.step(nsteps)
+    b.step(nsteps)
+    ea, eb = a.energy_history(), b.energy_history()
+    assert np.max(np.abs(ea - eb)) <= 1e-11 * np.max(eb)
+    assert a.kernel_stats(6)[1] >= nsteps - 2
+    w1 = np.max(np.abs(a.particles_download()["w"]))
+    bound1, slow1 = a.kernel_stats(13)
+    assert w1 >= 20.0 * w0, (w0, w1)                       # the mode grew ...
+    assert 0.9 * w1 <= bound1 <= 1.5 * w1, (bound1, w1)    # ... the bound with it (as of the last launches: a step behind) ...
+    assert slow1 <= 1e-6 * N * nsteps, slow1               # ... and the double path stayed the exception

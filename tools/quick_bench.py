@@ -49,6 +49,8 @@ for mode in ((0,) if only0 else (0, 1)):
     print("mode %d: %.4e updates/s  %.4f ms/step  | %s | with the events in the stream %.4f ms/step | host enqueue %.4f ms/step"
           % (mode, n * 2 * steps / dt, dt / steps * 1e3, ", ".join(parts), dt_ev / steps * 1e3, t_enq / steps * 1e3), flush=True)
     eng.kernel_stats_enable(False)
+    if eng.predict_kind() == 1:   # the tiles: their bound on |w| and the terms that went past the fixed-point sums so far
+        print("        tiles: bound on |q| %.3e, %d terms in doubles so far" % eng.kernel_stats(13), flush=True)
 
 if only0:
     eng.close()
