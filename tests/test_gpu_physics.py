@@ -41,6 +41,42 @@ def ensemble_tool():
     return mod
 
 
+def test_dispersion_relation_away_from_the_baseline_wavenumbers(amd):
+    """The rates of test_growth_rates_ensemble are taken at ONE wavenumber per case (BASELINE.md's).  Two more points on the
+    dispersion curves, lx = 2 pi / k moved with them (every normalisation of the hot path holds lx: the deposit's nx / lx, the
+    solve's 1 / k, the loader's lx 2 v_max / N): Landau damping at k = 0.4 and two-stream growth at k = 0.25, two members of
+    1e8 markers each, against the roots of the Vlasov dispersion function.  tools/dispersion_sweep.py runs the whole sweep
+    (six and five wavenumbers, profiles/r06/experiments/dispersion_sweep.log: omega_r within 0.03 %, rates within 0.2 % --
+    about what dt = 0.05 costs)."""
+    import importlib.util
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    spec = importlib.util.spec_from_file_location("dispersion_sweep", os.path.join(ROOT, "tools", "dispersion_sweep.py"))
+    ds = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ds)
+    pe = ds.pe
+    guess = pe.vlasov_root([(1.0, 0.0, 1.0)], 0.45, 1.35 - 0.106j)
+    pe.CASES["landau_k0.4"], w = ds.landau_case(0.4, guess)
+    assert abs(w - (1.2850569697 - 0.0661279587j)) < 1e-8            # (the root itself, pinned)
+    c = pe.CASES["landau_k0.4"]
+    fits = [pe.fit_damped_wave(*pe.member_series(amd, "landau_k0.4", 1e8, 0.05, m), c["t_fit"][0], c["t_fit"][1], c["two_gamma"], c["omega"])
+            for m in range(2)]
+    g2, om = np.mean([f[0] for f in fits]), np.mean([f[1] for f in fits])
+    print("Landau k = 0.4: omega_r %.6f (theory %.6f), 2 gamma %.6f (theory %.6f)" % (om, w.real, g2, 2 * w.imag))
+    assert abs(om / w.real - 1.0) < 1e-3
+    assert abs(g2 / (2 * w.imag) - 1.0) < 6e-3
+    pe.CASES["two_stream_k0.25"], w = ds.two_stream_case(0.25, 0.28j)
+    assert abs(w - 0.2749222215j) < 1e-8
+    c = pe.CASES["two_stream_k0.25"]
+    fits = [pe.fit_growing_amplitude(*pe.member_series(amd, "two_stream_k0.25", 1e8, 0.05, m), c["t_fit"][0], c["t_fit"][1], 0.5 * c["two_gamma"])
+            for m in range(2)]
+    g2 = np.mean([f[0] for f in fits])
+    print("two-stream k = 0.25: 2 gamma %.6f (theory %.6f)" % (g2, 2 * w.imag))
+    assert abs(g2 / (2 * w.imag) - 1.0) < 3e-3
+
+
 def conservation_tool():
     import importlib.util
     import os
