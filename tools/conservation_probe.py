@@ -55,7 +55,7 @@ def run(amd, n, nx, steps, every, extra):
             pw, nw = float(np.sum(g["w"] * g["v"])), float(np.sum(g["w"]))
         else:
             pw = nw = float("nan")
-        rows.append((it * inp.dt, eng.field_energy(), eng.energy_sums()[2], pw, nw))
+        rows.append((it * inp.dt, eng.field_energy(), eng.energy_sums()[2 if inp.deltaf else 1], pw, nw))   # (full-f: sum v^2 p)
     eng.close()
     return np.array(rows), (eps / k) ** 2 * inp.lx / 2.0
 
