@@ -87,7 +87,7 @@ def conservation_tool():
     return mod
 
 
-@pytest.mark.parametrize("case", ["bump", "two_stream", "landau"])
+@pytest.mark.parametrize("case", ["bump", "two_stream", "two_stream_full_f", "landau"])
 def test_energy_balance(amd, case):
     """An anchor that needs neither the oracle nor a dispersion solver (round 6): Vlasov-Poisson conserves
     sum_i w_i v_i^2 + int E^2 dx (output_field's sum, src/pic1dp_output.F90:126-172, and its field energy, :120-124), and a
@@ -105,12 +105,14 @@ def test_energy_balance(amd, case):
     rows, f0 = cp.run(amd, 10**8, c["nx"], c["steps"], c["every"], c["inp"])
     cp.report(case, rows, f0)
     imb, slope, nbig = cp.balance(rows)
-    assert abs(rows[0, 1] / f0 - 1.0) < 3e-3, (rows[0, 1], f0)
+    full_f = c["inp"].get("deltaf", 1) == 0       # (full-f: sum p v^2 + int E^2 dx, drift 0.16 % of the field energy, slope -0.9989;
+    if not full_f:                                 # its initial field energy is the marker noise's)
+        assert abs(rows[0, 1] / f0 - 1.0) < 3e-3, (rows[0, 1], f0)
     assert nbig >= 8
     assert imb < c["imbalance"], imb
     assert abs(slope + 1.0) < c["slope"], slope
     if case != "landau":
-        assert rows[:, 1].max() > 1e6 * rows[0, 1]        # the run did reach saturation
+        assert rows[:, 1].max() > (1e5 if full_f else 1e6) * rows[0, 1]        # the run did reach saturation
     else:
         assert rows[-1, 1] < 2e-3 * rows[0, 1]            # the field is gone
 

@@ -10,7 +10,7 @@ the weights (the lx / nx of the deposit, the 1 / k of the solve, charge or mass 
 weight equation) breaks the balance at FIRST order; the RK2 step, the grid and the marker noise only at the per-cent level
 and below (measured: the imbalance does not move with dt 0.1 / 0.05 / 0.025 and falls as 1 / sqrt(markers)).
 
-    python tools/conservation_probe.py [case | all] [markers]        cases: bump two_stream landau
+    python tools/conservation_probe.py [case | all] [markers]        cases: bump two_stream two_stream_full_f landau
     python tools/conservation_probe.py custom markers nx steps every '{"json": "input overrides"}'
 
 tests/test_gpu_physics.py::test_energy_balance asserts the three cases at 1e8 markers; the momentum sum_i w_i v_i and the
@@ -31,6 +31,10 @@ CASES = {
     "bump": dict(inp=dict(), nx=1024, steps=3000, every=100, imbalance=0.05, slope=0.03),
     "two_stream": dict(inp=dict(iptcldist=2, species_v0=[3.0], species_density=[1.0]), nx=512, steps=1600, every=50,
                        imbalance=0.01, slope=0.005),
+    # the same instability with full-f markers (deltaf = 0: the sum is sum p v^2, 174.5 here, of which the field takes 3.0 at
+    # saturation; the initial field energy is the marker noise's, not the perturbation's): measured 1.6e-3, slope -0.9989
+    "two_stream_full_f": dict(inp=dict(deltaf=0, iptcldist=2, species_v0=[3.0], species_density=[1.0]), nx=512, steps=1600, every=50,
+                              imbalance=0.01, slope=0.005),
     # Landau damping of a perturbation large enough for the energy to rise above the marker noise (eps = 0.05: the bounce
     # time 2 pi / sqrt(eps) = 28 is long against the damping time 1 / 0.153): the field hands its energy to the markers
     "landau": dict(inp=dict(iptcldist=0, species_density=[1.0], species_v0=[0.0], lx=4.0 * math.pi, init_mode_sin=[0.05]),
