@@ -225,18 +225,21 @@ def test_long_run_through_saturation(oracle_mod, amd):
 BASELINE_CASES = [
     # id, input, reference ranks (virtual ranks on the one GPU), steps, per-marker checks
     # configs[0]: the reference's own default input at its own size, 1 MPI rank
-    # (src/pic1dp_input.F90:113,128); the oracle runs it on one thread (~30 s)
-    ("C1_default_1rank", dict(nparticle_max=6_400_000, nx=192), 1, 100, True),
+    # (src/pic1dp_input.F90:113,128); the oracle runs it on one thread (~20 s)
+    ("C1_default_1rank", dict(nparticle_max=6_400_000, nx=192), 1, 60, True),
     ("C2_bump_1e7", dict(nparticle_max=10**7, nx=256), 16, 200, True),
     ("C3_bump_1e8", dict(nparticle_max=10**8, nx=1024), 16, 60, True),
     # the same through the reference's three call sites per sub-step (src/pic1dp.F90:80-89), served lazily by the
     # one-pass kernel: the path bench.py times as drop_in_call_sites, at the size it times it
     ("C3_bump_1e8_call_sites", dict(nparticle_max=10**8, nx=1024), 16, 60, False),
     ("C4_two_stream_1e8_4ranks", dict(nparticle_max=10**8, nx=512, iptcldist=2, species_density=[1.0],
-                                      species_v0=[3.0]), 4, 60, True),
+                                      species_v0=[3.0]), 4, 30, True),
     ("C5_landau_8e8_8ranks", dict(nparticle_max=8 * 10**8, nx=4096, iptcldist=0, species_density=[1.0],
                                   species_v0=[0.0], lx=4 * np.pi), 8, 12, False),
 ]
+
+
+_ORACLE_SERIES = {}
 
 
 @pytest.mark.parametrize("name,kw,npe,nsteps,per_marker", BASELINE_CASES, ids=[c[0] for c in BASELINE_CASES])
@@ -247,19 +250,26 @@ def test_baseline_sizes_against_oracle(oracle_mod, amd, name, kw, npe, nsteps, p
     per host thread.  int E^2 dx within 1e-10 at every step, the fitted rate within
     1e-10, every marker's cell the reference expression of its position."""
     nx = kw["nx"]
-    sim = oracle_mod.Sim(oracle_mod.make_input(**kw), npe=npe, nthreads=npe)
-    assert sim.load() == 0
     eng = amd.Pic1dp(amd.make_input(**kw), npe=npe)
     eng.particle_load()
-    sim.collect_charge()
-    sim.solve_field()
     eng.interaction_collect_charge()
     eng.field_solve_electric()
-    eo = [sim.field_energy()]
-    for _ in range(nsteps):
-        sim.step(1)
-        eo.append(sim.field_energy())
-    eo = np.array(eo)
+    # (the oracle's series of a case whose markers are not looked at is kept for the next case with the same input: C3 through
+    # step() and through the call sites are one oracle run of 1e8 markers, not two)
+    key = (repr(sorted(kw.items())), npe, nsteps)
+    if not per_marker and key in _ORACLE_SERIES:
+        eo, sim = _ORACLE_SERIES[key], None
+    else:
+        sim = oracle_mod.Sim(oracle_mod.make_input(**kw), npe=npe, nthreads=npe)
+        assert sim.load() == 0
+        sim.collect_charge()
+        sim.solve_field()
+        eo = [sim.field_energy()]
+        for _ in range(nsteps):
+            sim.step(1)
+            eo.append(sim.field_energy())
+        eo = np.array(eo)
+        _ORACLE_SERIES[key] = eo
     eg = np.concatenate([[eng.field_energy()], np.zeros(nsteps)])
     if name.endswith("call_sites"):
         eng.kernel_stats_enable(True)
