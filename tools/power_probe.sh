@@ -17,10 +17,9 @@ echo "== pure stream, 4 arrays read + 3 written"
 python - <<'PY' & P=$!
 import os, sys
 sys.path.insert(0, os.getcwd())
-import pic1dp_amd
-eng = pic1dp_amd.Pic1dp(pic1dp_amd.make_input(nparticle_max=1000, nx=64))
+from pic1dp_amd import probe
 for _ in range(9):
-    eng.stream_probe(4, 3, 10**8, 1000)
+    probe.stream(4, 3, 10**8, 1000)
 PY
 sample; wait $P
 echo "== idle"
